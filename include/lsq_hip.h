@@ -1,0 +1,149 @@
+/* include/lsq_hip.h -- the drop-in boundary of the MI355X LSQ fake-quantize hot path.
+ *
+ * A plain C ABI (extern "C", raw device pointers and sizes, no torch types) exported by
+ * `liblsq_hip.so` (built from lsqfakequantize-pytorch_amd/csrc/ for gfx950).  These entry points
+ * are exactly what a binding for the reference's backend kernels would call: each one replaces
+ * one `TORCH_LIBRARY_IMPL(torchlsq, CUDA)` kernel of the reference
+ *   /root/reference/torchlsq/csrc/ops/cuda/lsq_cuda.cu:301-314
+ * (whose CPU twins, lsq_cpu.cpp:298-311, are the parity oracle) -- see INTEGRATION.md for the
+ * binding a maintainer of the reference would add.
+ *
+ * Contract:
+ *  - the caller owns every buffer (outputs and workspace included); the library never allocates
+ *    or frees tensor memory and keeps no reference after return;
+ *  - all pointers are DEVICE pointers on the current HIP device; kernels are enqueued on the
+ *    `stream` argument (a hipStream_t passed as void*; NULL = the default stream) and the call
+ *    returns without synchronising -- scale/shift are read on the device, never on the host
+ *    (the reference's `scale[0].item()` host syncs, lsq_cuda.cu:52-53,120-121, are gone);
+ *  - re-entrant, no mutable global state: forward (caller thread) and backward (autograd engine
+ *    thread) may run concurrently;
+ *  - functions return 0 on success, a negative LSQ_E* code for rejected arguments, or a positive
+ *    hipError_t value; they never throw.  lsq_hip_last_error() describes the last failure of the
+ *    calling thread.
+ *
+ * Memory layout: tensors are dense in memory order.  Per-tensor ops see a flat array of `n`
+ * elements.  Per-channel ops see the 3-D view [outer, C, inner] of the same dense memory (the
+ * view reference lsq_cpu.cpp:168-176 builds by reshaping scale/shift to [1,..,C,..,1]); e.g. an
+ * NCHW activation quantised on axis 1 is (N, C, H*W), a conv weight on axis 0 is (1, Cout, Cin*kh*kw),
+ * a channels-last activation is (N*H*W, C, 1).
+ */
+#ifndef LSQ_HIP_H_
+#define LSQ_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSQ_HIP_ABI_VERSION 1
+
+/* Storage type of x / grad / y / dx.  Arithmetic is fp32 for F32, BF16 and F16 storage and fp64
+ * for F64 (reference CPU path: AT_DISPATCH_FLOATING_TYPES, lsq_cpu.cpp:37,92,182,243).
+ * scale / shift / ds / db are float for F32|BF16|F16 storage and double for F64. */
+enum lsq_dtype {
+    LSQ_F32 = 0,
+    LSQ_F64 = 1,
+    LSQ_BF16 = 2, /* extension (BASELINE config 5): bf16 in/out, fp32 math, RNE on store */
+    LSQ_F16 = 3   /* extension: fp16 in/out, fp32 math (the reference's CUDA path computes in half) */
+};
+
+enum lsq_status {
+    LSQ_OK = 0,
+    LSQ_EINVAL = -1,    /* bad argument (null pointer, negative size, unknown dtype, ...) */
+    LSQ_EWORKSPACE = -2 /* workspace too small or misaligned */
+};
+
+/* Scalar arguments shared by the four ops; field-for-field the trailing arguments of the
+ * reference schemas (lsq.cpp:138-145).  `numel_for_scaler` is new: the element count used in the
+ * gradient scaler 1/sqrt(numel*quant_max[/C]) (lsq_cpu.cpp:103,250).  <= 0 means "this call's own
+ * numel" (the reference behaviour); the batch-sharded multi-GPU path passes the GLOBAL numel so
+ * that the summed shards equal the unsharded result. */
+typedef struct lsq_params {
+    int32_t quant_min;
+    int32_t quant_max;
+    int32_t type_min;
+    int32_t type_max;
+    int32_t use_grad_scaling;
+    int32_t sym;       /* 1: symmetric, d_shift forced to 0 (lsq_kernel.h:118) */
+    int32_t eval_mode; /* 1: backward produces dx only, ds = db = 0 (lsq_kernel.h:126-145) */
+    int32_t init_mode; /* 1: forward is the identity, backward uses 2*(x_r - x) (lsq_kernel.h:13,116) */
+    double grad_scaler;
+    int64_t numel_for_scaler;
+} lsq_params;
+
+/* Optional extra outputs of the forward (NULL = not wanted).
+ *  levels: int8 quantised integer level of every element,
+ *          q = rne(clamp(x/s + zp, quant_min, quant_max))  (lsq_kernel.h:13), stored as
+ *          (int8_t)(q - level_bias); level_bias lets quint8 ranges (0..255) fit (use 128). */
+typedef struct lsq_fwd_extras {
+    void* levels;
+    int32_t level_bias;
+    int32_t reserved;
+} lsq_fwd_extras;
+
+/* ---- library / build information -------------------------------------------------------- */
+
+/* LSQ_HIP_ABI_VERSION the library was built with. */
+int lsq_hip_abi_version(void);
+
+/* HIP runtime version the library was compiled against (HIP_VERSION), the counterpart of the
+ * reference's torchlsq::_cuda_version (torchlsq.cpp:25-31, which returns CUDA_VERSION or -1). */
+int64_t lsq_hip_runtime_version(void);
+
+/* Message for the last non-zero status returned to the calling thread ("" if none). */
+const char* lsq_hip_last_error(void);
+
+/* The gradient scaler of lsq_cpu.cpp:103-104 (per_channel = 0) / :250-251 (per_channel = 1) with
+ * the reference's precision chain for the given dtype's arithmetic type; returned widened to
+ * double.  Host-only helper (no GPU needed). */
+double lsq_hip_grad_scaler(int dtype, int per_channel, int64_t numel, int32_t quant_max,
+                           int64_t channels, int32_t use_grad_scaling, double grad_scaler);
+
+/* ---- per-tensor ------------------------------------------------------------------------- */
+
+/* Bytes of scratch the backward needs (block partial sums); 256-byte aligned buffer expected.
+ * Does not depend on the data, only on the size; never more than 1 MiB. */
+size_t lsq_hip_backward_per_tensor_workspace(int dtype, int64_t n);
+
+/* y = fake_quant(x).  Replaces lsq_forward_per_tensor_impl, lsq_cuda.cu:18-61 (CPU twin
+ * lsq_cpu.cpp:15-53).  scale, shift: device pointers to 1 element. */
+int lsq_hip_forward_per_tensor(int dtype, const void* x, void* y, int64_t n, const void* scale,
+                               const void* shift, const lsq_params* p, const lsq_fwd_extras* extras,
+                               void* stream);
+
+/* dx, ds[1], db[1] from grad and x in ONE pass over HBM (+ a tiny finalize launch).
+ * Replaces lsq_backward_per_tensor_impl, lsq_cuda.cu:64-143 (three elementwise kernels, three
+ * N-sized temporaries and two at::sum; CPU twin lsq_cpu.cpp:56-141).
+ * dsdb_wide (optional, NULL ok): double[2] = {sum ds terms, sum db terms} before rounding to the
+ * parameter type -- what the sharded path all-reduces. */
+int lsq_hip_backward_per_tensor(int dtype, const void* grad, const void* x, void* dx, void* ds,
+                                void* db, double* dsdb_wide, int64_t n, const void* scale,
+                                const void* shift, const lsq_params* p, void* workspace,
+                                size_t workspace_bytes, void* stream);
+
+/* ---- per-channel ------------------------------------------------------------------------ */
+
+size_t lsq_hip_backward_per_channel_workspace(int dtype, int64_t outer, int64_t channels, int64_t inner);
+
+/* Replaces lsq_forward_per_channel_impl, lsq_cuda.cu:147-199 (CPU twin lsq_cpu.cpp:145-193).
+ * scale, shift: device pointers to `channels` elements. */
+int lsq_hip_forward_per_channel(int dtype, const void* x, void* y, int64_t outer, int64_t channels,
+                                int64_t inner, const void* scale, const void* shift,
+                                const lsq_params* p, const lsq_fwd_extras* extras, void* stream);
+
+/* Replaces lsq_backward_per_channel_impl, lsq_cuda.cu:202-297 (CPU twin lsq_cpu.cpp:197-294).
+ * ds, db: `channels` elements each.  dsdb_wide (optional): double[2*channels], ds sums first.
+ * NOTE the gradient scaler follows the CPU oracle (/C inside the sqrt, lsq_cpu.cpp:250), not the
+ * reference's CUDA kernel (lsq_cuda.cu:274), which omits it. */
+int lsq_hip_backward_per_channel(int dtype, const void* grad, const void* x, void* dx, void* ds,
+                                 void* db, double* dsdb_wide, int64_t outer, int64_t channels,
+                                 int64_t inner, const void* scale, const void* shift,
+                                 const lsq_params* p, void* workspace, size_t workspace_bytes,
+                                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSQ_HIP_H_ */

@@ -1,0 +1,192 @@
+// lsq_capi.hip -- the extern "C" boundary declared in include/lsq_hip.h.
+//
+// Thin by design: argument validation, dtype dispatch, error bookkeeping.  No tensor memory is
+// allocated or freed here and no state outlives a call (the only statics are an immutable device
+// table and a thread-local error string).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include <hip/hip_version.h>
+
+#include "lsq_internal.h"
+#include "lsq_kernels.hpp"
+
+namespace {
+
+thread_local char g_last_error[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_status(hipError_t e, const char* what) {
+    if (e == hipSuccess) return LSQ_OK;
+    return fail(static_cast<int>(e), "%s: %s (%s)", what, hipGetErrorName(e), hipGetErrorString(e));
+}
+
+bool dtype_ok(int dtype) { return dtype >= LSQ_F32 && dtype <= LSQ_F16; }
+int io_vec(int dtype) { return dtype == LSQ_F32 ? 4 : dtype == LSQ_F64 ? 2 : 8; }
+
+int check_common(int dtype, const lsq_params* p) {
+    if (!dtype_ok(dtype)) return fail(LSQ_EINVAL, "unknown dtype code %d", dtype);
+    if (!p) return fail(LSQ_EINVAL, "lsq_params pointer is NULL");
+    if (p->quant_min > p->quant_max) return fail(LSQ_EINVAL, "quant_min %d > quant_max %d", p->quant_min, p->quant_max);
+    if (p->type_min > p->type_max) return fail(LSQ_EINVAL, "type_min %d > type_max %d", p->type_min, p->type_max);
+    return LSQ_OK;
+}
+
+int check_levels(const lsq_params* p, const lsq_fwd_extras* ex) {
+    if (ex && ex->levels) {
+        const int lo = p->quant_min - ex->level_bias, hi = p->quant_max - ex->level_bias;
+        if (lo < -128 || hi > 127)
+            return fail(LSQ_EINVAL, "levels: [quant_min, quant_max] - level_bias = [%d, %d] does not fit int8", lo, hi);
+    }
+    return LSQ_OK;
+}
+
+}  // namespace
+
+#define LSQ_DISPATCH_IO(dtype, CALL)                          \
+    switch (dtype) {                                          \
+        case LSQ_F32: { using IO = lsq::io_f32; CALL; } break;   \
+        case LSQ_F64: { using IO = lsq::io_f64; CALL; } break;   \
+        case LSQ_BF16: { using IO = lsq::io_bf16; CALL; } break; \
+        default: { using IO = lsq::io_f16; CALL; } break;        \
+    }
+
+extern "C" {
+
+int lsq_hip_abi_version(void) { return LSQ_HIP_ABI_VERSION; }
+
+int64_t lsq_hip_runtime_version(void) { return static_cast<int64_t>(HIP_VERSION); }
+
+const char* lsq_hip_last_error(void) { return g_last_error; }
+
+double lsq_hip_grad_scaler(int dtype, int per_channel, int64_t numel, int32_t quant_max, int64_t channels,
+                           int32_t use_grad_scaling, double grad_scaler) {
+    const bool use = use_grad_scaling != 0;
+    if (dtype == LSQ_F64) {
+        return per_channel ? lsq::grad_scaler_per_channel<double>(numel, quant_max, channels, use, grad_scaler)
+                           : lsq::grad_scaler_per_tensor<double>(numel, quant_max, use, grad_scaler);
+    }
+    return per_channel
+               ? static_cast<double>(lsq::grad_scaler_per_channel<float>(numel, quant_max, channels, use, grad_scaler))
+               : static_cast<double>(lsq::grad_scaler_per_tensor<float>(numel, quant_max, use, grad_scaler));
+}
+
+size_t lsq_hip_backward_per_tensor_workspace(int dtype, int64_t n) {
+    (void)dtype;
+    (void)n;
+    return lsq::bwd_pt_workspace_bytes();
+}
+
+size_t lsq_hip_backward_per_channel_workspace(int dtype, int64_t outer, int64_t channels, int64_t inner) {
+    if (!dtype_ok(dtype) || outer <= 0 || channels <= 0 || inner <= 0) return 256;
+    return lsq::bwd_pc_workspace_bytes(io_vec(dtype), outer, channels, inner);
+}
+
+int lsq_hip_forward_per_tensor_ex(int dtype, const void* x, void* y, int64_t n, const void* scale, const void* shift,
+                                  const lsq_params* p, const lsq_fwd_extras* extras, void* stream, int variant) {
+    if (int rc = check_common(dtype, p)) return rc;
+    if (n < 0) return fail(LSQ_EINVAL, "negative element count %lld", static_cast<long long>(n));
+    if (n == 0) return LSQ_OK;
+    if (!x || !y || !scale || !shift) return fail(LSQ_EINVAL, "forward_per_tensor: NULL buffer");
+    if (int rc = check_levels(p, extras)) return rc;
+    hipError_t e = hipSuccess;
+    LSQ_DISPATCH_IO(dtype, e = lsq::forward_per_tensor<IO>(x, y, n, scale, shift, *p, extras, variant,
+                                                            static_cast<hipStream_t>(stream)));
+    return hip_status(e, "lsq_hip_forward_per_tensor");
+}
+
+int lsq_hip_forward_per_tensor(int dtype, const void* x, void* y, int64_t n, const void* scale, const void* shift,
+                               const lsq_params* p, const lsq_fwd_extras* extras, void* stream) {
+    return lsq_hip_forward_per_tensor_ex(dtype, x, y, n, scale, shift, p, extras, stream, 0);
+}
+
+int lsq_hip_backward_per_tensor_ex(int dtype, const void* grad, const void* x, void* dx, void* ds, void* db,
+                                   double* dsdb_wide, int64_t n, const void* scale, const void* shift,
+                                   const lsq_params* p, void* workspace, size_t workspace_bytes, void* stream,
+                                   int variant) {
+    if (int rc = check_common(dtype, p)) return rc;
+    if (n <= 0) return fail(LSQ_EINVAL, "backward_per_tensor: element count must be positive (the caller handles the "
+                                        "empty case, reference lsq_cpu.cpp:76-78)");
+    if (!grad || !x || !dx || !ds || !db || !scale || !shift) return fail(LSQ_EINVAL, "backward_per_tensor: NULL buffer");
+    if (!workspace || workspace_bytes < lsq::bwd_pt_workspace_bytes())
+        return fail(LSQ_EWORKSPACE, "backward_per_tensor: workspace of %zu bytes, need %zu", workspace_bytes,
+                    lsq::bwd_pt_workspace_bytes());
+    if (reinterpret_cast<uintptr_t>(workspace) & 15u) return fail(LSQ_EWORKSPACE, "workspace must be 16-byte aligned");
+    hipError_t e = hipSuccess;
+    LSQ_DISPATCH_IO(dtype, e = lsq::backward_per_tensor<IO>(grad, x, dx, ds, db, dsdb_wide, n, scale, shift, *p,
+                                                             workspace, variant, static_cast<hipStream_t>(stream)));
+    return hip_status(e, "lsq_hip_backward_per_tensor");
+}
+
+int lsq_hip_backward_per_tensor(int dtype, const void* grad, const void* x, void* dx, void* ds, void* db,
+                                double* dsdb_wide, int64_t n, const void* scale, const void* shift,
+                                const lsq_params* p, void* workspace, size_t workspace_bytes, void* stream) {
+    return lsq_hip_backward_per_tensor_ex(dtype, grad, x, dx, ds, db, dsdb_wide, n, scale, shift, p, workspace,
+                                          workspace_bytes, stream, 0);
+}
+
+static int check_ocl(int64_t outer, int64_t channels, int64_t inner) {
+    if (outer < 0 || channels <= 0 || inner < 0)
+        return fail(LSQ_EINVAL, "bad [outer, C, inner] = [%lld, %lld, %lld]", static_cast<long long>(outer),
+                    static_cast<long long>(channels), static_cast<long long>(inner));
+    return LSQ_OK;
+}
+
+int lsq_hip_forward_per_channel_ex(int dtype, const void* x, void* y, int64_t outer, int64_t channels, int64_t inner,
+                                   const void* scale, const void* shift, const lsq_params* p,
+                                   const lsq_fwd_extras* extras, void* stream, int variant) {
+    if (int rc = check_common(dtype, p)) return rc;
+    if (int rc = check_ocl(outer, channels, inner)) return rc;
+    if (outer == 0 || inner == 0) return LSQ_OK;
+    if (!x || !y || !scale || !shift) return fail(LSQ_EINVAL, "forward_per_channel: NULL buffer");
+    if (int rc = check_levels(p, extras)) return rc;
+    hipError_t e = hipSuccess;
+    LSQ_DISPATCH_IO(dtype, e = lsq::forward_per_channel<IO>(x, y, outer, channels, inner, scale, shift, *p, extras,
+                                                             variant, static_cast<hipStream_t>(stream)));
+    return hip_status(e, "lsq_hip_forward_per_channel");
+}
+
+int lsq_hip_forward_per_channel(int dtype, const void* x, void* y, int64_t outer, int64_t channels, int64_t inner,
+                                const void* scale, const void* shift, const lsq_params* p,
+                                const lsq_fwd_extras* extras, void* stream) {
+    return lsq_hip_forward_per_channel_ex(dtype, x, y, outer, channels, inner, scale, shift, p, extras, stream, 0);
+}
+
+int lsq_hip_backward_per_channel_ex(int dtype, const void* grad, const void* x, void* dx, void* ds, void* db,
+                                    double* dsdb_wide, int64_t outer, int64_t channels, int64_t inner,
+                                    const void* scale, const void* shift, const lsq_params* p, void* workspace,
+                                    size_t workspace_bytes, void* stream, int variant) {
+    if (int rc = check_common(dtype, p)) return rc;
+    if (int rc = check_ocl(outer, channels, inner)) return rc;
+    if (outer == 0 || inner == 0)
+        return fail(LSQ_EINVAL, "backward_per_channel: empty tensor (the caller handles it, reference lsq_cpu.cpp:221-223)");
+    if (!grad || !x || !dx || !ds || !db || !scale || !shift) return fail(LSQ_EINVAL, "backward_per_channel: NULL buffer");
+    if (!workspace) return fail(LSQ_EWORKSPACE, "backward_per_channel: NULL workspace");
+    if (reinterpret_cast<uintptr_t>(workspace) & 15u) return fail(LSQ_EWORKSPACE, "workspace must be 16-byte aligned");
+    hipError_t e = hipSuccess;
+    LSQ_DISPATCH_IO(dtype, e = lsq::backward_per_channel<IO>(grad, x, dx, ds, db, dsdb_wide, outer, channels, inner,
+                                                              scale, shift, *p, workspace, workspace_bytes, variant,
+                                                              static_cast<hipStream_t>(stream)));
+    if (e == hipErrorInvalidValue)
+        return fail(LSQ_EWORKSPACE, "backward_per_channel: workspace of %zu bytes is too small (ask "
+                                    "lsq_hip_backward_per_channel_workspace)", workspace_bytes);
+    return hip_status(e, "lsq_hip_backward_per_channel");
+}
+
+int lsq_hip_backward_per_channel(int dtype, const void* grad, const void* x, void* dx, void* ds, void* db,
+                                 double* dsdb_wide, int64_t outer, int64_t channels, int64_t inner,
+                                 const void* scale, const void* shift, const lsq_params* p, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    return lsq_hip_backward_per_channel_ex(dtype, grad, x, dx, ds, db, dsdb_wide, outer, channels, inner, scale, shift,
+                                           p, workspace, workspace_bytes, stream, 0);
+}
+
+}  // extern "C"

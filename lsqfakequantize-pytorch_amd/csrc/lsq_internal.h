@@ -1,0 +1,28 @@
+/* lsq_internal.h -- NOT part of the drop-in boundary (include/lsq_hip.h is).
+ * `_ex` twins of the four ops with one extra argument, a launch-variant code
+ * (unroll | nt << 8 | blocks_per_cu << 16; 0 = the tuned default), used only by the tuning
+ * sweep in tools/tune_stream.py.  A build without -DLSQ_TUNING ignores everything but
+ * blocks_per_cu. */
+#ifndef LSQ_INTERNAL_H_
+#define LSQ_INTERNAL_H_
+#include "../../include/lsq_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+int lsq_hip_forward_per_tensor_ex(int dtype, const void* x, void* y, int64_t n, const void* scale, const void* shift,
+                                  const lsq_params* p, const lsq_fwd_extras* extras, void* stream, int variant);
+int lsq_hip_backward_per_tensor_ex(int dtype, const void* grad, const void* x, void* dx, void* ds, void* db,
+                                   double* dsdb_wide, int64_t n, const void* scale, const void* shift,
+                                   const lsq_params* p, void* workspace, size_t workspace_bytes, void* stream,
+                                   int variant);
+int lsq_hip_forward_per_channel_ex(int dtype, const void* x, void* y, int64_t outer, int64_t channels, int64_t inner,
+                                   const void* scale, const void* shift, const lsq_params* p,
+                                   const lsq_fwd_extras* extras, void* stream, int variant);
+int lsq_hip_backward_per_channel_ex(int dtype, const void* grad, const void* x, void* dx, void* ds, void* db,
+                                    double* dsdb_wide, int64_t outer, int64_t channels, int64_t inner,
+                                    const void* scale, const void* shift, const lsq_params* p, void* workspace,
+                                    size_t workspace_bytes, void* stream, int variant);
+#ifdef __cplusplus
+}
+#endif
+#endif

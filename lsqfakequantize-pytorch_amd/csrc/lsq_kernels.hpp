@@ -1,0 +1,171 @@
+// lsq_kernels.hpp -- declarations shared by the kernel translation units and the C ABI layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+
+#include "../../include/lsq_hip.h"
+#include "lsq_math.hpp"
+
+namespace lsq {
+
+constexpr int kBlock = 256;          // 4 wave64 per workgroup
+constexpr int kMaxCUs = 1024;        // upper bound used to size workspaces (MI355X: 256)
+constexpr int kMaxBlocksPerCU = 16;
+
+// ---- launch variants (tuning knobs; the defaults are what bench/profiles were measured with) ----
+struct Variant {
+    int unroll;         // 16-byte packets in flight per lane per stream
+    bool nt;            // non-temporal loads/stores (stream past the caches)
+    int blocks_per_cu;  // persistent-grid size = CUs * blocks_per_cu
+};
+// encoded as unroll | nt << 8 | blocks_per_cu << 16 ; 0 = "use the default"
+constexpr int encode_variant(int unroll, bool nt, int bpc) { return unroll | (nt ? 1 << 8 : 0) | (bpc << 16); }
+constexpr int kDefaultFwdVariant = encode_variant(4, true, 8);
+constexpr int kDefaultBwdVariant = encode_variant(4, true, 8);
+constexpr int kDefaultPcVariant = encode_variant(4, true, 8);
+
+inline Variant decode_variant(int code, int dflt) {
+    if (code == 0) code = dflt;
+    Variant v;
+    v.unroll = code & 0xff;
+    v.nt = ((code >> 8) & 1) != 0;
+    v.blocks_per_cu = (code >> 16) & 0xff;
+    if (v.unroll != 1 && v.unroll != 2 && v.unroll != 4 && v.unroll != 8) v.unroll = 4;
+    if (v.blocks_per_cu < 1) v.blocks_per_cu = 1;
+    if (v.blocks_per_cu > kMaxBlocksPerCU) v.blocks_per_cu = kMaxBlocksPerCU;
+    return v;
+}
+
+// LAUNCH(U, NT) is a macro taking the compile-time unroll and non-temporal flag.
+#ifdef LSQ_TUNING
+#define LSQ_DISPATCH_VARIANT(v, LAUNCH)                                   \
+    do {                                                                  \
+        if ((v).nt) {                                                     \
+            switch ((v).unroll) {                                         \
+                case 1: LAUNCH(1, true); break;                           \
+                case 2: LAUNCH(2, true); break;                           \
+                case 8: LAUNCH(8, true); break;                           \
+                default: LAUNCH(4, true); break;                          \
+            }                                                             \
+        } else {                                                          \
+            switch ((v).unroll) {                                         \
+                case 1: LAUNCH(1, false); break;                          \
+                case 2: LAUNCH(2, false); break;                          \
+                case 8: LAUNCH(8, false); break;                          \
+                default: LAUNCH(4, false); break;                         \
+            }                                                             \
+        }                                                                 \
+    } while (0)
+#else
+// production build: one code path per kernel (the tuned one) to keep the code object small
+#define LSQ_DISPATCH_VARIANT(v, LAUNCH) \
+    do {                                \
+        (void)(v);                      \
+        LAUNCH(4, true);                \
+    } while (0)
+#endif
+
+// ---- device info (immutable after first use; benign race on initialisation) --------------------
+struct DeviceInfo {
+    int cu_count;
+};
+inline const DeviceInfo& device_info() {
+    static DeviceInfo table[64];
+    static std::atomic<int> ready[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!ready[dev].load(std::memory_order_acquire)) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        if (cus > kMaxCUs) cus = kMaxCUs;
+        table[dev].cu_count = cus;
+        ready[dev].store(1, std::memory_order_release);
+    }
+    return table[dev];
+}
+
+inline bool is_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename T>
+inline Range<T> make_range(const lsq_params& p) {
+    Range<T> r;
+    r.qmin = static_cast<T>(p.quant_min);
+    r.qmax = static_cast<T>(p.quant_max);
+    r.tmin = static_cast<T>(p.type_min);
+    r.tmax = static_cast<T>(p.type_max);
+    return r;
+}
+
+// ---- gradient scaler (host) ---------------------------------------------------------------------
+// lsq_cpu.cpp:103-104: static_cast<scalar_t>(grad_scaler / sqrt(x.numel()*qmax)).  The product is
+// int64 * scalar_t evaluated in scalar_t, sqrt is the scalar_t overload, the quotient is formed in
+// double and rounded once to scalar_t (chain pinned by tests/golden/small_cases.json "scaler_chain").
+template <typename T>
+inline T grad_scaler_per_tensor(int64_t numel, int32_t quant_max, bool use_grad_scaling, double grad_scaler) {
+    if (!use_grad_scaling) return static_cast<T>(grad_scaler);
+    const T prod = static_cast<T>(numel) * static_cast<T>(quant_max);
+    const T root = std::sqrt(prod);
+    return static_cast<T>(grad_scaler / static_cast<double>(root));
+}
+// lsq_cpu.cpp:250-251: grad_scaler / sqrt(x.numel()*qmax / x.size(axis))
+template <typename T>
+inline T grad_scaler_per_channel(int64_t numel, int32_t quant_max, int64_t channels, bool use_grad_scaling,
+                                 double grad_scaler) {
+    if (!use_grad_scaling) return static_cast<T>(grad_scaler);
+    const T prod = static_cast<T>(numel) * static_cast<T>(quant_max);
+    const T per_ch = prod / static_cast<T>(channels);
+    const T root = std::sqrt(per_ch);
+    return static_cast<T>(grad_scaler / static_cast<double>(root));
+}
+
+// ---- packed int8 levels of one packet -----------------------------------------------------------
+template <int VEC>
+struct LevelPack {
+    int8_t b[VEC];
+    __device__ __forceinline__ void store(int8_t* dst) const {
+        if constexpr (VEC == 8) {
+            uint64_t w;
+            __builtin_memcpy(&w, b, 8);
+            *reinterpret_cast<uint64_t*>(dst) = w;
+        } else if constexpr (VEC == 4) {
+            uint32_t w;
+            __builtin_memcpy(&w, b, 4);
+            *reinterpret_cast<uint32_t*>(dst) = w;
+        } else if constexpr (VEC == 2) {
+            uint16_t w;
+            __builtin_memcpy(&w, b, 2);
+            *reinterpret_cast<uint16_t*>(dst) = w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) dst[j] = b[j];
+        }
+    }
+};
+
+// ---- entry points implemented in lsq_per_tensor.hip / lsq_per_channel.hip ------------------------
+size_t bwd_pt_workspace_bytes();
+size_t bwd_pc_workspace_bytes(int elem_bytes, int64_t outer, int64_t channels, int64_t inner);
+
+template <typename IO>
+hipError_t forward_per_tensor(const void* x, void* y, int64_t n, const void* scale, const void* shift,
+                              const lsq_params& p, const lsq_fwd_extras* ex, int variant, hipStream_t stream);
+template <typename IO>
+hipError_t backward_per_tensor(const void* grad, const void* x, void* dx, void* ds, void* db, double* wide,
+                               int64_t n, const void* scale, const void* shift, const lsq_params& p,
+                               void* workspace, int variant, hipStream_t stream);
+template <typename IO>
+hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t channels, int64_t inner,
+                               const void* scale, const void* shift, const lsq_params& p,
+                               const lsq_fwd_extras* ex, int variant, hipStream_t stream);
+template <typename IO>
+hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void* ds, void* db, double* wide,
+                                int64_t outer, int64_t channels, int64_t inner, const void* scale,
+                                const void* shift, const lsq_params& p, void* workspace, size_t workspace_bytes,
+                                int variant, hipStream_t stream);
+
+}  // namespace lsq

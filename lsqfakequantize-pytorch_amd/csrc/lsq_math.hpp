@@ -1,0 +1,221 @@
+// lsq_math.hpp -- per-element LSQ arithmetic for gfx950, shared by the per-tensor and the
+// per-channel kernels.
+//
+// The arithmetic contract is the reference's scalar header
+//   /root/reference/torchlsq/csrc/ops/kernels/lsq_kernel.h   (fwd :6-14, fused bwd :94-123, eval :126-145)
+// as built for its CPU backend (global_scope.h:8-20: FASTROUND = std::nearbyint, i.e. round half
+// to even; FMIN/FMAX = std::fmin/std::fmax, NaN-suppressing), because the CPU path is the parity
+// oracle.  To be bit-identical with that build (x86-64 without FMA):
+//   * every multiply and add is an individually rounded IEEE operation -- this directory is
+//     compiled with -ffp-contract=off, so `x * inv_s + zp` is v_mul_f32 + v_add_f32, never v_fma;
+//   * 1/s is a correctly rounded division (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt);
+//   * rounding is v_rndne_f32 / v_rndne_f64 (__builtin_rint*: current mode = nearest-even);
+//   * fp32 denormals are preserved (hipcc default for gfx9).
+// Written for the CDNA4 execution model: everything here is branch-free straight-line VALU code
+// (selects, no divergent control flow), so a wave64 runs it at full lane occupancy.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lsq {
+
+// ---- arithmetic-type helpers ------------------------------------------------------------------
+__device__ __forceinline__ float rne(float v) { return __builtin_rintf(v); }
+__device__ __forceinline__ double rne(double v) { return __builtin_rint(v); }
+__device__ __forceinline__ float fmin_(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double fmin_(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double fmax_(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float fabs_(float a) { return __builtin_fabsf(a); }
+__device__ __forceinline__ double fabs_(double a) { return __builtin_fabs(a); }
+
+template <typename T> struct eps_of;
+template <> struct eps_of<float> { static constexpr float value = 1.1920928955078125e-07f; };   // FLT_EPSILON
+template <> struct eps_of<double> { static constexpr double value = 2.220446049250313e-16; };    // DBL_EPSILON
+
+// Quantisation range in the arithmetic type (lsq_cpu.cpp:40-43: static_cast<scalar_t>(quant_min) ...).
+template <typename T>
+struct Range {
+    T qmin, qmax, tmin, tmax;
+};
+
+// Per-quantiser constants derived once from (scale, shift): what every element of the reference
+// recomputes (lsq_kernel.h:12 and :157-158).
+template <typename T>
+struct QParams {
+    T s;      // sanitised scale
+    T inv_s;  // 1 / s
+    T zp;     // rne(fmin(tmax, fmax(tmin, -b * inv_s)))
+};
+
+// per-tensor sanitising: s = std::max(|scale[0]|, eps)  (lsq_cpu.cpp:45-46; std::max keeps a NaN scale)
+template <typename T>
+__device__ __forceinline__ T sanitize_scale_per_tensor(T scale0) {
+    const T a = fabs_(scale0);
+    return (a < eps_of<T>::value) ? eps_of<T>::value : a;
+}
+
+// per-channel sanitising: _s = FMAX(eps, ABS(s))  (lsq_kernel.h:157; fmax drops a NaN scale)
+template <typename T>
+__device__ __forceinline__ T sanitize_scale_per_channel(T scale_c) {
+    return fmax_(eps_of<T>::value, fabs_(scale_c));
+}
+
+template <typename T>
+__device__ __forceinline__ QParams<T> make_qparams(T s_sanitized, T shift, const Range<T>& r) {
+    QParams<T> q;
+    q.s = s_sanitized;
+    q.inv_s = static_cast<T>(1) / s_sanitized;
+    q.zp = rne(fmin_(r.tmax, fmax_(r.tmin, -shift * q.inv_s)));  // lsq_kernel.h:12
+    return q;
+}
+
+// ---- forward (lsq_kernel.h:6-14) ---------------------------------------------------------------
+// the integer level, still in floating point: FASTROUND(FMIN(qmax, FMAX(qmin, x*inv_s + zp)))
+template <typename T>
+__device__ __forceinline__ T level(T x, const QParams<T>& q, const Range<T>& r) {
+    return rne(fmin_(r.qmax, fmax_(r.qmin, x * q.inv_s + q.zp)));
+}
+
+template <typename T>
+__device__ __forceinline__ T dequant(T lvl, const QParams<T>& q) {
+    return (lvl - q.zp) * q.s;
+}
+
+// ---- backward (lsq_kernel.h:94-123) ------------------------------------------------------------
+// Returns dX; ds_term / db_term are the per-element contributions (already multiplied by the
+// gradient scaler, :122) that the reference writes to ds_buffer / db_buffer (lsq_cpu.cpp:131-133).
+template <typename T, bool SYM, bool INIT>
+__device__ __forceinline__ T backward_elem(T grad, T x, const QParams<T>& q, const Range<T>& r,
+                                           T grad_scaler, T& ds_term, T& db_term) {
+    const T xq = fmax_(fmin_(x * q.inv_s + q.zp, r.qmax), r.qmin);  // :108, clamp = min then max, unrounded
+    const bool inside = (r.qmin < xq) && (xq < r.qmax);            // :109
+    const T mask = inside ? static_cast<T>(1) : static_cast<T>(0);
+    const T dX = INIT ? grad : grad * mask;                        // :112 (a real multiply: inf*0 = NaN)
+    const T xfq = (rne(xq) - q.zp) * q.s;                          // :115
+    const T err = xfq - x;
+    const T g_ = INIT ? static_cast<T>(2) * err : grad;            // :116
+    const T border = (xq <= r.qmin) ? g_ * (r.qmin - q.zp) : g_ * (r.qmax - q.zp);  // :120
+    const T dS = inside ? g_ * err * q.inv_s : border;             // :121
+    ds_term = dS * grad_scaler;                                    // :122
+    if (SYM) {
+        db_term = static_cast<T>(0);                               // :118 (0 * scaler)
+    } else {
+        const T dB = (static_cast<T>(1) - mask) * g_;              // :118 static_cast<scalar_t>(!mask) * _grad
+        db_term = dB * grad_scaler;
+    }
+    return dX;
+}
+
+// eval mode (lsq_kernel.h:126-145): dx only
+template <typename T, bool INIT>
+__device__ __forceinline__ T backward_elem_eval(T grad, T x, const QParams<T>& q, const Range<T>& r) {
+    if (INIT) return grad;
+    const T xq = fmax_(fmin_(x * q.inv_s + q.zp, r.qmax), r.qmin);
+    const bool inside = (r.qmin < xq) && (xq < r.qmax);
+    return grad * (inside ? static_cast<T>(1) : static_cast<T>(0));
+}
+
+// ---- storage types: 16-byte vectors in HBM, arithmetic type in registers ------------------------
+// IO traits: `vec` is the 16-byte register image, VEC elements per vector, arith = math type.
+struct io_f32 {
+    using elem = float;
+    using arith = float;
+    static constexpr int VEC = 4;
+    __device__ static __forceinline__ float load1(const void* p, int64_t i) { return static_cast<const float*>(p)[i]; }
+    __device__ static __forceinline__ void store1(void* p, int64_t i, float v) { static_cast<float*>(p)[i] = v; }
+};
+struct io_f64 {
+    using elem = double;
+    using arith = double;
+    static constexpr int VEC = 2;
+    __device__ static __forceinline__ double load1(const void* p, int64_t i) { return static_cast<const double*>(p)[i]; }
+    __device__ static __forceinline__ void store1(void* p, int64_t i, double v) { static_cast<double*>(p)[i] = v; }
+};
+struct io_bf16 {
+    using elem = __bf16;
+    using arith = float;
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ float load1(const void* p, int64_t i) {
+        return static_cast<float>(static_cast<const __bf16*>(p)[i]);
+    }
+    __device__ static __forceinline__ void store1(void* p, int64_t i, float v) {
+        static_cast<__bf16*>(p)[i] = static_cast<__bf16>(v);  // RNE (v_cvt_pk_bf16_f32 on gfx950)
+    }
+};
+struct io_f16 {
+    using elem = _Float16;
+    using arith = float;
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ float load1(const void* p, int64_t i) {
+        return static_cast<float>(static_cast<const _Float16*>(p)[i]);
+    }
+    __device__ static __forceinline__ void store1(void* p, int64_t i, float v) {
+        static_cast<_Float16*>(p)[i] = static_cast<_Float16>(v);
+    }
+};
+
+// A 16-byte packet of IO::VEC storage elements, moved with one global_load/store_dwordx4.
+template <typename IO>
+struct alignas(16) Packet {
+    typename IO::elem v[IO::VEC];
+};
+
+template <typename IO>
+__device__ __forceinline__ Packet<IO> load_packet(const void* base, int64_t elem_index) {
+    using V4 = __attribute__((ext_vector_type(4))) unsigned int;
+    const V4 raw = *reinterpret_cast<const V4*>(static_cast<const typename IO::elem*>(base) + elem_index);
+    Packet<IO> p;
+    __builtin_memcpy(&p, &raw, 16);
+    return p;
+}
+
+template <typename IO>
+__device__ __forceinline__ Packet<IO> load_packet_nt(const void* base, int64_t elem_index) {
+    using V4 = __attribute__((ext_vector_type(4))) unsigned int;
+    const V4 raw = __builtin_nontemporal_load(
+        reinterpret_cast<const V4*>(static_cast<const typename IO::elem*>(base) + elem_index));
+    Packet<IO> p;
+    __builtin_memcpy(&p, &raw, 16);
+    return p;
+}
+
+template <typename IO>
+__device__ __forceinline__ void store_packet(void* base, int64_t elem_index, const Packet<IO>& p) {
+    using V4 = __attribute__((ext_vector_type(4))) unsigned int;
+    V4 raw;
+    __builtin_memcpy(&raw, &p, 16);
+    *reinterpret_cast<V4*>(static_cast<typename IO::elem*>(base) + elem_index) = raw;
+}
+
+template <typename IO>
+__device__ __forceinline__ void store_packet_nt(void* base, int64_t elem_index, const Packet<IO>& p) {
+    using V4 = __attribute__((ext_vector_type(4))) unsigned int;
+    V4 raw;
+    __builtin_memcpy(&raw, &p, 16);
+    __builtin_nontemporal_store(raw, reinterpret_cast<V4*>(static_cast<typename IO::elem*>(base) + elem_index));
+}
+
+// ---- wave64 / block reductions -----------------------------------------------------------------
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, mask, 64);
+    hi = __shfl_xor(hi, mask, 64);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_down_f64(double v, int delta) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_down(lo, delta, 64);
+    hi = __shfl_down(hi, delta, 64);
+    return __hiloint2double(hi, lo);
+}
+
+// butterfly sum over the 64 lanes of a wavefront; every lane ends with the total
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);
+    return v;
+}
+
+}  // namespace lsq

@@ -1,0 +1,102 @@
+"""Batch-sharded LSQ across the GPUs of one node: one process per GPU, ONE collective per backward.
+
+The reference has no distributed code.  The hot path is elementwise
+plus a reduction, so it shards by splitting dim 0 (the batch) across ranks:
+  * forward and dx need no communication;
+  * d_scale / d_shift are sums over all elements, so each rank reduces its shard to the *un-rounded*
+    fp64 pair [sum ds terms, sum db terms] (per-tensor: 2 doubles; per-channel: 2*C doubles), and a
+    single RCCL all-reduce(SUM) over xGMI combines them -- 16 bytes for the per-tensor case, i.e. a
+    latency-bound message: one packed call, launched on the same stream right behind the backward
+    kernel, no host synchronisation;
+  * the gradient scaler 1/sqrt(numel*quant_max) uses the GLOBAL element count, so the result equals
+    the reference's on the concatenated (unsharded) tensor (lsq_cpu.cpp:103 uses x.numel()).
+`backend="nccl"` is RCCL on ROCm builds of PyTorch; the CPU tests use gloo.
+"""
+import torch
+import torch.distributed as dist
+
+from .extension import _assert_has_ops, _param_dtype
+
+
+def _world(group):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def sharded_backward(grad, x, scale, shift, quant_min, quant_max, type_min, type_max, axis=1,
+                     use_grad_scaling=True, grad_scaler=1.0, is_affine=True, is_perchannel=False,
+                     eval_mode=False, init_mode=False, group=None, global_numel=None, async_op=False):
+    """Local fused backward + the one all-reduce.  Returns (dx, ds, db[, work]).
+
+    `global_numel` defaults to local numel * world size (equal shards)."""
+    ws = _world(group)
+    n4s = int(global_numel) if global_numel is not None else x.numel() * ws
+    sym = not is_affine
+    ops = torch.ops.torchlsq
+    if is_perchannel:
+        dx, wide = ops.lsq_backward_per_channel_wide(grad, x, scale, shift, axis, quant_min, quant_max, type_min,
+                                                     type_max, use_grad_scaling, grad_scaler, sym, eval_mode, init_mode,
+                                                     n4s)
+    else:
+        dx, wide = ops.lsq_backward_per_tensor_wide(grad, x, scale, shift, quant_min, quant_max, type_min, type_max,
+                                                    use_grad_scaling, grad_scaler, sym, eval_mode, init_mode, n4s)
+    work = None
+    if ws > 1:
+        work = dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    pd = _param_dtype(x)
+    if async_op and work is not None:
+        return dx, wide, work           # caller waits, then rounds: wide[0].to(pd), wide[1].to(pd)
+    ds = wide[0].to(pd).reshape(-1)
+    db = wide[1].to(pd).reshape(-1)
+    return dx, ds, db
+
+
+class _ShardedLSQ(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, shift, cfg):
+        (qmin, qmax, tmin, tmax, axis, use_gs, gs, is_affine, is_pc, eval_mode, init_mode, group, gnumel) = cfg
+        ops = torch.ops.torchlsq
+        sym = not is_affine
+        if is_pc:
+            y = ops.lsq_forward_per_channel(x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode,
+                                            init_mode)
+        else:
+            y = ops.lsq_forward_per_tensor(x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
+        ctx.save_for_backward(x, scale, shift)
+        ctx.cfg = cfg
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, scale, shift = ctx.saved_tensors
+        (qmin, qmax, tmin, tmax, axis, use_gs, gs, is_affine, is_pc, eval_mode, init_mode, group, gnumel) = ctx.cfg
+        dx, ds, db = sharded_backward(grad_out, x, scale, shift, qmin, qmax, tmin, tmax, axis, use_gs, gs, is_affine,
+                                      is_pc, eval_mode, init_mode, group, gnumel)
+        return dx, ds, db, None
+
+
+def lsq_sharded(x, scale, shift, quant_min=0, quant_max=255, type_min=None, type_max=None, axis=1,
+                use_grad_scaling=True, grad_scaler=1., is_affine=True, is_perchannel=False,
+                eval_mode=False, init_mode=False, group=None, global_numel=None):
+    """`torchlsq.functional.lsq` for a tensor whose dim 0 is sharded across the ranks of `group`.
+
+    scale/shift are replicated; their gradients come back already summed over all ranks and equal
+    (to the 1e-6 parity budget) the gradients of the unsharded op on the concatenated tensor.
+    Per-channel quantisation along the sharded dim itself (axis 0) needs no collective and is not
+    handled here -- use the plain op on each shard."""
+    _assert_has_ops()
+    if not is_affine:
+        assert quant_min <= 0 <= quant_max, 'quantization range must be covered 0 in symmetric quantization'
+    assert not (is_perchannel and axis == 0), "axis 0 is the sharded dim: channels are disjoint, use lsq() per shard"
+    type_min = quant_min if type_min is None else type_min
+    type_max = quant_max if type_max is None else type_max
+    if scale.dim() != 1:
+        raise RuntimeError("scale should be a 1-D tensor, even in per tensor case(please, avoid torch.Scalar too)")
+    if shift.dim() != 1:
+        raise RuntimeError("shift should be a 1-D tensor, even in per tensor case(please, avoid torch.Scalar too)")
+    if is_perchannel:
+        size = max(scale.size(0), shift.size(0))
+        scale = scale if scale.size(0) == size else scale.repeat(size)
+        shift = shift if shift.size(0) == size else shift.repeat(size)
+    cfg = (quant_min, quant_max, type_min, type_max, axis, use_grad_scaling, grad_scaler, is_affine, is_perchannel,
+           eval_mode, init_mode, group, global_numel)
+    return _ShardedLSQ.apply(x, scale, shift, cfg)

@@ -1,0 +1,560 @@
+"""Op loader and registration for the MI355X build of torchlsq.
+
+This module replaces two pieces of the reference:
+  * torchlsq/extension.py (reference :12-56), which located `_C.so` and `torch.ops.load_library`-ed
+    it: here the native part is `liblsq_hip.so`, a C-ABI HIP library (include/lsq_hip.h) opened
+    with ctypes;
+  * the registration blocks of the C++ extension -- the schemas (csrc/ops/lsq.cpp:137-146,
+    csrc/torchlsq.cpp:35-39), the composite front op `lsq` (lsq.cpp:104-134), the autograd-key
+    kernels (csrc/ops/autograd/lsq_autograd.cpp) and the backend kernels' argument checks
+    (lsq_cpu.cpp:28-29,72-78,159-163,214-223) -- which are restated with `torch.library`.
+
+Dispatch keys: HIP tensors carry PyTorch's "CUDA" dispatch key on ROCm builds, so the gfx950
+kernels are registered under "CUDA".  Nothing is registered for "CPU": this is the MI355X build,
+CPU tensors raise NotImplementedError from the dispatcher (there is no silent fallback; the test
+suite plugs the independent CPU oracle in under the CPU key to exercise this Python layer on a
+machine without a GPU).
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HAS_OPS = False
+error_str = ""
+_LIB = None
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblsq_hip.so")
+
+# dtype codes of include/lsq_hip.h
+LSQ_F32, LSQ_F64, LSQ_BF16, LSQ_F16 = 0, 1, 2, 3
+_DTYPE_CODE = {torch.float32: LSQ_F32, torch.float64: LSQ_F64, torch.bfloat16: LSQ_BF16, torch.float16: LSQ_F16}
+
+
+class LsqParams(ctypes.Structure):
+    """struct lsq_params (include/lsq_hip.h)."""
+    _fields_ = [("quant_min", ctypes.c_int32), ("quant_max", ctypes.c_int32),
+                ("type_min", ctypes.c_int32), ("type_max", ctypes.c_int32),
+                ("use_grad_scaling", ctypes.c_int32), ("sym", ctypes.c_int32),
+                ("eval_mode", ctypes.c_int32), ("init_mode", ctypes.c_int32),
+                ("grad_scaler", ctypes.c_double), ("numel_for_scaler", ctypes.c_int64)]
+
+
+class LsqFwdExtras(ctypes.Structure):
+    """struct lsq_fwd_extras (include/lsq_hip.h)."""
+    _fields_ = [("levels", ctypes.c_void_p), ("level_bias", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+_vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
+_PP = ctypes.POINTER(LsqParams)
+_EP = ctypes.POINTER(LsqFwdExtras)
+
+# every symbol include/lsq_hip.h declares: (restype, argtypes)
+C_ABI = {
+    "lsq_hip_abi_version": (_int, []),
+    "lsq_hip_runtime_version": (_i64, []),
+    "lsq_hip_last_error": (ctypes.c_char_p, []),
+    "lsq_hip_grad_scaler": (ctypes.c_double, [_int, _int, _i64, ctypes.c_int32, _i64, ctypes.c_int32, ctypes.c_double]),
+    "lsq_hip_backward_per_tensor_workspace": (_sz, [_int, _i64]),
+    "lsq_hip_forward_per_tensor": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _PP, _EP, _vp]),
+    "lsq_hip_backward_per_tensor": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _PP, _vp, _sz, _vp]),
+    "lsq_hip_backward_per_channel_workspace": (_sz, [_int, _i64, _i64, _i64]),
+    "lsq_hip_forward_per_channel": (_int, [_int, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP, _EP, _vp]),
+    "lsq_hip_backward_per_channel": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP, _vp,
+                                            _sz, _vp]),
+}
+# tuning twins (csrc/lsq_internal.h): same signatures + a trailing launch-variant code
+C_ABI_INTERNAL = {
+    "lsq_hip_forward_per_tensor_ex": (_int, C_ABI["lsq_hip_forward_per_tensor"][1] + [_int]),
+    "lsq_hip_backward_per_tensor_ex": (_int, C_ABI["lsq_hip_backward_per_tensor"][1] + [_int]),
+    "lsq_hip_forward_per_channel_ex": (_int, C_ABI["lsq_hip_forward_per_channel"][1] + [_int]),
+    "lsq_hip_backward_per_channel_ex": (_int, C_ABI["lsq_hip_backward_per_channel"][1] + [_int]),
+}
+
+
+def _load_library():
+    """dlopen liblsq_hip.so and type its entry points (the replacement of reference extension.py:39-45)."""
+    global _LIB
+    if not os.path.isfile(_LIB_PATH):
+        raise ImportError("%s not found -- build it with `python __graft_entry__.py` or "
+                          "`make -C lsqfakequantize-pytorch_amd/csrc`" % _LIB_PATH)
+    lib = ctypes.CDLL(_LIB_PATH)
+    for table in (C_ABI, C_ABI_INTERNAL):
+        for name, (res, args) in table.items():
+            fn = getattr(lib, name)  # AttributeError -> OSError-like failure below
+            fn.restype = res
+            fn.argtypes = args
+    abi = lib.lsq_hip_abi_version()
+    if abi != 1:
+        raise ImportError("liblsq_hip.so has ABI version %d, this package needs 1" % abi)
+    _LIB = lib
+
+
+try:
+    _load_library()
+    _HAS_OPS = True
+except (ImportError, OSError, AttributeError) as e:  # surfaced by _assert_has_ops(), like the reference
+    error_str = str(e)
+
+
+def _has_ops():
+    return _HAS_OPS
+
+
+def _assert_has_ops():
+    if not _HAS_OPS:
+        raise RuntimeError(
+            "torchlsq (MI355X build): the native HIP library could not be loaded, so the LSQ ops are "
+            "unavailable.  There is no CPU or eager fallback.  Build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950).\n\nImport error details:\n\t%s" % error_str)
+
+
+def library():
+    """The ctypes handle of liblsq_hip.so (raises if it is missing)."""
+    _assert_has_ops()
+    return _LIB
+
+
+def _check_hip_version():
+    """Counterpart of the reference's _check_cuda_version (extension.py:71-96): the HIP runtime the
+    library was compiled against must have the same major version as the one PyTorch uses."""
+    if not _HAS_OPS:
+        return -1
+    v = int(_LIB.lsq_hip_runtime_version())
+    hip = getattr(torch.version, "hip", None)
+    if v > 0 and hip is not None:
+        lib_major = v // 10000000
+        t_major = int(hip.split(".")[0])
+        if lib_major != t_major:
+            raise RuntimeError("Detected that PyTorch and torchlsq were compiled with different HIP versions. "
+                               "PyTorch has HIP Version=%s and torchlsq has HIP_VERSION=%d. "
+                               "Please rebuild torchlsq against your PyTorch's ROCm." % (hip, v))
+    return v
+
+
+# -------------------------------------------------------------------------------------------------
+# schemas -- namespace and signatures of the reference (lsq.cpp:138-145, torchlsq.cpp:36-37)
+# -------------------------------------------------------------------------------------------------
+_TAIL = ("int quant_min, int quant_max, int type_min, int type_max, bool use_grad_scaling, float grad_scaler, "
+         "bool sym, bool eval_mode, bool init_mode")
+_lib_def = torch.library.Library("torchlsq", "DEF")
+_lib_def.define("_cuda_version() -> int")
+_lib_def.define("lsq(Tensor x, Tensor scale, Tensor shift, int quant_min, int quant_max, int type_min, int type_max, "
+                "int axis, bool use_grad_scaling, float grad_scale, bool is_affine, bool is_perchannel, "
+                "bool eval_mode, bool init_mode) -> Tensor")
+_lib_def.define("lsq_forward_per_tensor(Tensor x, Tensor scale, Tensor shift, " + _TAIL + ") -> Tensor")
+_lib_def.define("lsq_backward_per_tensor(Tensor grad, Tensor x, Tensor scale, Tensor shift, " + _TAIL +
+                ") -> (Tensor, Tensor, Tensor)")
+_lib_def.define("lsq_forward_per_channel(Tensor x, Tensor scale, Tensor shift, int axis, " + _TAIL + ") -> Tensor")
+_lib_def.define("lsq_backward_per_channel(Tensor grad, Tensor x, Tensor scale, Tensor shift, int axis, " + _TAIL +
+                ") -> (Tensor, Tensor, Tensor)")
+# Additions of this build (not in the reference):
+#  * `*_wide`: backward that also takes the element count for the gradient scaler and returns the
+#    un-rounded fp64 reductions ([2] or [2, C]) -- what the batch-sharded path all-reduces;
+#  * `lsq_quantize_*`: forward that also emits the int8 integer levels (q - level_bias).
+_lib_def.define("lsq_backward_per_tensor_wide(Tensor grad, Tensor x, Tensor scale, Tensor shift, " + _TAIL +
+                ", int numel_for_scaler) -> (Tensor, Tensor)")
+_lib_def.define("lsq_backward_per_channel_wide(Tensor grad, Tensor x, Tensor scale, Tensor shift, int axis, " + _TAIL +
+                ", int numel_for_scaler) -> (Tensor, Tensor)")
+_lib_def.define("lsq_quantize_per_tensor(Tensor x, Tensor scale, Tensor shift, int quant_min, int quant_max, "
+                "int type_min, int type_max, int level_bias) -> (Tensor, Tensor)")
+_lib_def.define("lsq_quantize_per_channel(Tensor x, Tensor scale, Tensor shift, int axis, int quant_min, "
+                "int quant_max, int type_min, int type_max, int level_bias) -> (Tensor, Tensor)")
+
+
+# -------------------------------------------------------------------------------------------------
+# argument checks (same conditions and messages as the reference's TORCH_CHECKs)
+# -------------------------------------------------------------------------------------------------
+def _check(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _param_dtype(x):
+    """dtype scale/shift must have for input x (reference: identical to x, lsq_cpu.cpp:28-29).
+    Extension: 16-bit inputs take fp32 parameters."""
+    return torch.float32 if x.dtype in (torch.bfloat16, torch.float16) else x.dtype
+
+
+def check_forward_dtypes(x, scale, shift):
+    _check(x.dtype in _DTYPE_CODE, '"lsq_forward" not implemented for \'%s\'' % str(x.dtype).replace("torch.", ""))
+    pd = _param_dtype(x)
+    _check(scale.dtype == pd, "`input` and `scale` must have the same floating-point type")
+    _check(shift.dtype == pd, "`input` and `shift` must have the same floating-point type")
+
+
+def check_backward_dtypes(grad, x, scale, shift):
+    _check(x.dtype in _DTYPE_CODE, '"lsq_backward" not implemented for \'%s\'' % str(x.dtype).replace("torch.", ""))
+    pd = _param_dtype(x)
+    _check(grad.dtype == x.dtype, "`grad` and `input` must have the same floating-point type")
+    _check(scale.dtype == pd, "`grad` and `scale` must have the same floating-point type")
+    _check(shift.dtype == pd, "`grad` and `shift` must have the same floating-point type")
+    _check(x.numel() == grad.numel(), "`x` and `grad` are not the same size")
+
+
+def check_channel_args(x, scale, shift, axis, backward):
+    _check(scale.numel() == shift.numel(), "scale and shift need to have the same dimensions")
+    # the reference forward accepts axis == x.dim() (lsq_cpu.cpp:163, off by one) and then fails in
+    # x.size(axis); both directions are rejected here with the reference's message.
+    _check(0 <= axis < x.dim(), "`axis` must be between 0 and number of dimensions of input")
+    _check(scale.numel() == x.size(axis), "dimensions of scale and shift are not consistent with input tensor")
+
+
+# -------------------------------------------------------------------------------------------------
+# memory layout: the kernels see dense memory; find the [outer, C, inner] view of the channel axis
+# -------------------------------------------------------------------------------------------------
+def _physical_order(t):
+    """dims of t from slowest to fastest varying, or None if t is not dense & non-overlapping."""
+    dims = [d for d in range(t.dim()) if t.size(d) != 1]
+    dims.sort(key=lambda d: (-t.stride(d), d))
+    expect = 1
+    for d in reversed(dims):
+        if t.stride(d) != expect:
+            return None
+        expect *= t.size(d)
+    return dims
+
+
+def _dense(t):
+    """(tensor, physical order) with the tensor dense in memory (a contiguous copy if it was not)."""
+    order = _physical_order(t)
+    if order is None:
+        t = t.contiguous()
+        order = _physical_order(t)
+    return t, order
+
+
+def _like_layout(g, x):
+    """grad laid out exactly like the dense x (same strides), copying only if it is not already."""
+    if g.shape == x.shape and g.stride() == x.stride():
+        return g
+    out = torch.empty_like(x)  # preserve_format: x is dense, so strides are kept
+    out.copy_(g.reshape(x.shape) if g.shape != x.shape else g)
+    return out
+
+
+def _ocl(x, order, axis):
+    """[outer, C, inner] of dense x for channel `axis`, in memory order."""
+    if axis not in order:  # a size-1 channel dimension: one channel covering the whole tensor
+        return 1, 1, x.numel()
+    k = order.index(axis)
+    outer = 1
+    for d in order[:k]:
+        outer *= x.size(d)
+    inner = 1
+    for d in order[k + 1:]:
+        inner *= x.size(d)
+    return outer, x.size(axis), inner
+
+
+# -------------------------------------------------------------------------------------------------
+# the HIP backend ("CUDA" dispatch key on ROCm)
+# -------------------------------------------------------------------------------------------------
+def _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode, numel_for_scaler=0):
+    for name, v in (("quant_min", qmin), ("quant_max", qmax), ("type_min", tmin), ("type_max", tmax)):
+        _check(-2 ** 31 <= int(v) < 2 ** 31, "%s=%d does not fit a 32-bit integer" % (name, v))
+    return LsqParams(int(qmin), int(qmax), int(tmin), int(tmax), int(bool(use_gs)), int(bool(sym)),
+                     int(bool(eval_mode)), int(bool(init_mode)), float(gs), int(numel_for_scaler))
+
+
+def _status(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, _LIB.lsq_hip_last_error().decode("utf-8", "replace")))
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+_ws_lock = threading.Lock()
+_ws_size_pt = {}
+
+
+def _workspace(device, nbytes):
+    # a fresh caching-allocator block per call: stream-ordered reuse is the allocator's job, and
+    # forward/backward threads never share one.
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _require_gpu(t, what):
+    _check(t.is_cuda, "%s: expected a tensor on the GPU (HIP device) but got device %s" % (what, t.device))
+
+
+def hip_forward_per_tensor(x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode,
+                           levels_bias=None, variant=0):
+    _assert_has_ops()
+    check_forward_dtypes(x, scale, shift)
+    for t in (x, scale, shift):
+        _require_gpu(t, "lsq_forward_per_tensor")
+    xd, _ = _dense(x)
+    y = torch.empty_like(xd)
+    lv = None
+    if x.numel() == 0:
+        return (y, torch.empty(x.shape, dtype=torch.int8, device=x.device)) if levels_bias is not None else y
+    ex = None
+    if levels_bias is not None:
+        lv = torch.empty_strided(xd.shape, xd.stride(), dtype=torch.int8, device=x.device)
+        ex = ctypes.byref(LsqFwdExtras(lv.data_ptr(), int(levels_bias), 0))
+    p = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
+    scale_c, shift_c = scale.contiguous(), shift.contiguous()
+    with torch.cuda.device(x.device):
+        rc = _LIB.lsq_hip_forward_per_tensor_ex(_DTYPE_CODE[x.dtype], xd.data_ptr(), y.data_ptr(), xd.numel(),
+                                                scale_c.data_ptr(), shift_c.data_ptr(), ctypes.byref(p), ex,
+                                                _stream(x), int(variant))
+    _status(rc, "lsq_hip_forward_per_tensor")
+    return (y, lv) if levels_bias is not None else y
+
+
+def hip_backward_per_tensor(grad, x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode,
+                            numel_for_scaler=0, want_wide=False, variant=0):
+    _assert_has_ops()
+    check_backward_dtypes(grad, x, scale, shift)
+    if x.numel() <= 0:  # lsq_cpu.cpp:76-78 returns (x, scale, shift) themselves
+        if want_wide:
+            return x.clone(), torch.zeros(2, dtype=torch.float64, device=x.device)
+        return x.clone(), scale.clone(), shift.clone()
+    for t in (grad, x, scale, shift):
+        _require_gpu(t, "lsq_backward_per_tensor")
+    xd, _ = _dense(x)
+    gd = _like_layout(grad, xd)
+    dx = torch.empty_like(xd)
+    pd = _param_dtype(x)
+    ds = torch.empty(1, dtype=pd, device=x.device)
+    db = torch.empty(1, dtype=pd, device=x.device)
+    wide = torch.empty(2, dtype=torch.float64, device=x.device) if want_wide else None
+    p = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode, numel_for_scaler)
+    code = _DTYPE_CODE[x.dtype]
+    scale_c, shift_c = scale.contiguous(), shift.contiguous()
+    with torch.cuda.device(x.device):
+        nbytes = _LIB.lsq_hip_backward_per_tensor_workspace(code, xd.numel())
+        ws = _workspace(x.device, nbytes)
+        rc = _LIB.lsq_hip_backward_per_tensor_ex(code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(), ds.data_ptr(),
+                                                 db.data_ptr(), wide.data_ptr() if want_wide else None, xd.numel(),
+                                                 scale_c.data_ptr(), shift_c.data_ptr(), ctypes.byref(p),
+                                                 ws.data_ptr(), ws.numel(), _stream(x), int(variant))
+    _status(rc, "lsq_hip_backward_per_tensor")
+    if want_wide:
+        return dx, wide
+    return dx, ds, db
+
+
+def hip_forward_per_channel(x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode,
+                            levels_bias=None, variant=0):
+    _assert_has_ops()
+    check_forward_dtypes(x, scale, shift)
+    check_channel_args(x, scale, shift, axis, backward=False)
+    for t in (x, scale, shift):
+        _require_gpu(t, "lsq_forward_per_channel")
+    xd, order = _dense(x)
+    y = torch.empty_like(xd)
+    if x.numel() == 0:
+        return (y, torch.empty(x.shape, dtype=torch.int8, device=x.device)) if levels_bias is not None else y
+    outer, C, inner = _ocl(xd, order, axis)
+    lv, ex = None, None
+    if levels_bias is not None:
+        lv = torch.empty_strided(xd.shape, xd.stride(), dtype=torch.int8, device=x.device)
+        ex = ctypes.byref(LsqFwdExtras(lv.data_ptr(), int(levels_bias), 0))
+    p = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
+    scale_c, shift_c = scale.contiguous(), shift.contiguous()
+    with torch.cuda.device(x.device):
+        rc = _LIB.lsq_hip_forward_per_channel_ex(_DTYPE_CODE[x.dtype], xd.data_ptr(), y.data_ptr(), outer, C, inner,
+                                                 scale_c.data_ptr(), shift_c.data_ptr(), ctypes.byref(p), ex,
+                                                 _stream(x), int(variant))
+    _status(rc, "lsq_hip_forward_per_channel")
+    return (y, lv) if levels_bias is not None else y
+
+
+def hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode,
+                             init_mode, numel_for_scaler=0, want_wide=False, variant=0):
+    _assert_has_ops()
+    check_backward_dtypes(grad, x, scale, shift)
+    check_channel_args(x, scale, shift, axis, backward=True)
+    if x.numel() <= 0:  # lsq_cpu.cpp:221-223
+        if want_wide:
+            return x.clone(), torch.zeros(2, scale.numel(), dtype=torch.float64, device=x.device)
+        return x.clone(), scale.clone(), shift.clone()
+    for t in (grad, x, scale, shift):
+        _require_gpu(t, "lsq_backward_per_channel")
+    xd, order = _dense(x)
+    gd = _like_layout(grad, xd)
+    dx = torch.empty_like(xd)
+    outer, C, inner = _ocl(xd, order, axis)
+    pd = _param_dtype(x)
+    ds = torch.empty(C, dtype=pd, device=x.device)
+    db = torch.empty(C, dtype=pd, device=x.device)
+    wide = torch.empty(2, C, dtype=torch.float64, device=x.device) if want_wide else None
+    p = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode, numel_for_scaler)
+    code = _DTYPE_CODE[x.dtype]
+    scale_c, shift_c = scale.contiguous(), shift.contiguous()
+    with torch.cuda.device(x.device):
+        nbytes = _LIB.lsq_hip_backward_per_channel_workspace(code, outer, C, inner)
+        ws = _workspace(x.device, nbytes)
+        rc = _LIB.lsq_hip_backward_per_channel_ex(code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(), ds.data_ptr(),
+                                                  db.data_ptr(), wide.data_ptr() if want_wide else None, outer, C,
+                                                  inner, scale_c.data_ptr(), shift_c.data_ptr(), ctypes.byref(p),
+                                                  ws.data_ptr(), ws.numel(), _stream(x), int(variant))
+    _status(rc, "lsq_hip_backward_per_channel")
+    if want_wide:
+        return dx, wide
+    return dx, ds, db
+
+
+def _impl_fwd_pt(x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode):
+    return hip_forward_per_tensor(x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
+
+
+def _impl_bwd_pt(grad, x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode):
+    return hip_backward_per_tensor(grad, x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode,
+                                   init_mode)
+
+
+def _impl_fwd_pc(x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode):
+    return hip_forward_per_channel(x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode,
+                                   init_mode)
+
+
+def _impl_bwd_pc(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode):
+    return hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym,
+                                    eval_mode, init_mode)
+
+
+def _impl_bwd_pt_wide(grad, x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode, n4s):
+    return hip_backward_per_tensor(grad, x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode,
+                                   init_mode, numel_for_scaler=n4s, want_wide=True)
+
+
+def _impl_bwd_pc_wide(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode,
+                      n4s):
+    return hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym,
+                                    eval_mode, init_mode, numel_for_scaler=n4s, want_wide=True)
+
+
+def _impl_quantize_pt(x, scale, shift, qmin, qmax, tmin, tmax, level_bias):
+    return hip_forward_per_tensor(x, scale, shift, qmin, qmax, tmin, tmax, True, 1.0, False, False, False,
+                                  levels_bias=level_bias)
+
+
+def _impl_quantize_pc(x, scale, shift, axis, qmin, qmax, tmin, tmax, level_bias):
+    return hip_forward_per_channel(x, scale, shift, axis, qmin, qmax, tmin, tmax, True, 1.0, False, False, False,
+                                   levels_bias=level_bias)
+
+
+_lib_hip = torch.library.Library("torchlsq", "IMPL", "CUDA")
+_lib_hip.impl("lsq_forward_per_tensor", _impl_fwd_pt)
+_lib_hip.impl("lsq_backward_per_tensor", _impl_bwd_pt)
+_lib_hip.impl("lsq_forward_per_channel", _impl_fwd_pc)
+_lib_hip.impl("lsq_backward_per_channel", _impl_bwd_pc)
+_lib_hip.impl("lsq_backward_per_tensor_wide", _impl_bwd_pt_wide)
+_lib_hip.impl("lsq_backward_per_channel_wide", _impl_bwd_pc_wide)
+_lib_hip.impl("lsq_quantize_per_tensor", _impl_quantize_pt)
+_lib_hip.impl("lsq_quantize_per_channel", _impl_quantize_pc)
+
+
+# -------------------------------------------------------------------------------------------------
+# shape-only ("meta") kernels so the ops trace under torch.compile / FakeTensor
+# -------------------------------------------------------------------------------------------------
+def _meta_like(x):
+    return torch.empty_like(x)
+
+
+@torch.library.register_fake("torchlsq::lsq_forward_per_tensor", lib=_lib_def)
+def _fake_fwd_pt(x, scale, shift, *a):
+    return _meta_like(x)
+
+
+@torch.library.register_fake("torchlsq::lsq_forward_per_channel", lib=_lib_def)
+def _fake_fwd_pc(x, scale, shift, axis, *a):
+    return _meta_like(x)
+
+
+@torch.library.register_fake("torchlsq::lsq_backward_per_tensor", lib=_lib_def)
+def _fake_bwd_pt(grad, x, scale, shift, *a):
+    return _meta_like(x), scale.new_empty((1,)), shift.new_empty((1,))
+
+
+@torch.library.register_fake("torchlsq::lsq_backward_per_channel", lib=_lib_def)
+def _fake_bwd_pc(grad, x, scale, shift, axis, *a):
+    return _meta_like(x), torch.empty_like(scale), torch.empty_like(shift)
+
+
+# -------------------------------------------------------------------------------------------------
+# autograd (restates lsq_autograd.cpp: forward saves {input, scale, shift} + the scalars, backward
+# calls the backward op through the dispatcher and returns grads for the three tensors only)
+# -------------------------------------------------------------------------------------------------
+def _setup_pt(ctx, inputs, output):
+    x, scale, shift = inputs[:3]
+    ctx.save_for_backward(x, scale, shift)
+    ctx.lsq_scalars = tuple(inputs[3:])
+
+
+def _backward_pt(ctx, grad_out):
+    x, scale, shift = ctx.saved_tensors
+    dx, ds, db = torch.ops.torchlsq.lsq_backward_per_tensor(grad_out, x, scale, shift, *ctx.lsq_scalars)
+    return (dx, ds, db) + (None,) * 9      # lsq_autograd.cpp:69-71
+
+
+def _setup_pc(ctx, inputs, output):
+    x, scale, shift = inputs[:3]
+    ctx.save_for_backward(x, scale, shift)
+    ctx.lsq_scalars = tuple(inputs[3:])  # axis first
+
+
+def _backward_pc(ctx, grad_out):
+    x, scale, shift = ctx.saved_tensors
+    dx, ds, db = torch.ops.torchlsq.lsq_backward_per_channel(grad_out, x, scale, shift, *ctx.lsq_scalars)
+    return (dx, ds, db) + (None,) * 10     # lsq_autograd.cpp:169-170
+
+
+torch.library.register_autograd("torchlsq::lsq_forward_per_tensor", _backward_pt, setup_context=_setup_pt,
+                                lib=_lib_def)
+torch.library.register_autograd("torchlsq::lsq_forward_per_channel", _backward_pc, setup_context=_setup_pc,
+                                lib=_lib_def)
+
+
+def _no_double_backward(name):
+    def bw(ctx, *grads):
+        raise RuntimeError("double backwards on %s not supported" % name)  # lsq_autograd.cpp:106,208
+    return bw
+
+
+for _op, _nm in (("lsq_backward_per_tensor", "lsq_per_tensor"), ("lsq_backward_per_channel", "lsq_per_channel"),
+                 ("lsq_backward_per_tensor_wide", "lsq_per_tensor"),
+                 ("lsq_backward_per_channel_wide", "lsq_per_channel")):
+    torch.library.register_autograd("torchlsq::" + _op, _no_double_backward(_nm), lib=_lib_def)
+
+
+# -------------------------------------------------------------------------------------------------
+# composite front op (restates quantops::ops::lsq, lsq.cpp:104-134) and _cuda_version
+# -------------------------------------------------------------------------------------------------
+def _lsq_front(x, scale, shift, quant_min, quant_max, type_min, type_max, axis, use_grad_scaling, grad_scale,
+               is_affine, is_perchannel, eval_mode, init_mode):
+    _check(scale.dim() == 1,
+           "scale should be a 1-D tensor, even in per tensor case(please, avoid torch.Scalar too)")
+    _check(shift.dim() == 1,
+           "shift should be a 1-D tensor, even in per tensor case(please, avoid torch.Scalar too)")
+    sym = not is_affine
+    if is_perchannel:
+        # a size-1 parameter is repeated up to the larger size; `repeat` is differentiable, so the
+        # size-1 leaf still receives the summed gradient (lsq.cpp:124-126)
+        size = max(scale.size(0), shift.size(0))
+        _scale = scale if scale.size(0) == size else scale.repeat(size)
+        _shift = shift if shift.size(0) == size else shift.repeat(size)
+        return torch.ops.torchlsq.lsq_forward_per_channel(x, _scale, _shift, axis, quant_min, quant_max, type_min,
+                                                          type_max, use_grad_scaling, grad_scale, sym, eval_mode,
+                                                          init_mode)
+    return torch.ops.torchlsq.lsq_forward_per_tensor(x, scale, shift, quant_min, quant_max, type_min, type_max,
+                                                     use_grad_scaling, grad_scale, sym, eval_mode, init_mode)
+
+
+_lib_def.impl("lsq", _lsq_front, "CompositeImplicitAutograd")
+
+
+def _runtime_version():
+    """torchlsq::_cuda_version of this build: the HIP_VERSION the kernels were compiled with, or -1
+    when the native library is missing (reference torchlsq.cpp:25-31 returns CUDA_VERSION / -1)."""
+    return int(_LIB.lsq_hip_runtime_version()) if _HAS_OPS else -1
+
+
+_lib_def.impl("_cuda_version", _runtime_version, "CompositeExplicitAutograd")
+
+_check_hip_version()

@@ -1,0 +1,70 @@
+"""torchlsq.functional -- the functional entry point of the LSQ / LSQ+ fake quantizer.
+
+Drop-in for reference torchlsq/functional.py:8-97: same name, same argument list, defaults and
+assertions; the work is done by `torch.ops.torchlsq.lsq` (registered in torchlsq/extension.py on top
+of the gfx950 kernels).
+"""
+import torch
+
+from .extension import _assert_has_ops
+
+Tensor = torch.Tensor
+
+
+def lsq(x: Tensor, scale: Tensor, shift: Tensor,
+        quant_min: int = 0,
+        quant_max: int = 255,
+        type_min: int = None,
+        type_max: int = None,
+        axis: int = 1,
+        use_grad_scaling: bool = True,
+        grad_scaler: float = 1.,
+        is_affine: bool = True,
+        is_perchannel: bool = False,
+        eval_mode: bool = False,
+        init_mode: bool = False) -> Tensor:
+    """Learned Step Size Quantization (LSQ+, arXiv:2004.09576) fake quantizer: quantize -> dequantize
+    with `scale` and `shift` as learnable parameters.
+
+    Forward (per element, reference csrc/ops/kernels/lsq_kernel.h:6-14)::
+
+        s   = max(|scale|, eps)
+        zp  = round(clamp(-shift / s, type_min, type_max))          # the integer zero point
+        x_q = round(clamp(x / s + zp, quant_min, quant_max))        # round half to even
+        x_r = (x_q - zp) * s
+
+    Backward (lsq_kernel.h:94-123), with xq the *unrounded* clamped value::
+
+        d x     = grad                       if quant_min < xq < quant_max else 0
+        d scale = grad * (x_r - x) / s       inside;   grad * (quant_min|quant_max - zp) at the borders
+        d shift = 0 inside (or if symmetric); grad at the borders
+
+    `d scale` and `d shift` are summed over the tensor (per channel along `axis` when
+    `is_perchannel`) and, when `use_grad_scaling`, multiplied by
+    grad_scaler / sqrt(numel * quant_max [/ channels]) (arXiv:1902.08153).
+
+    Args:
+        x: input tensor (float32/float64; this build also takes bfloat16/float16 with fp32 parameters).
+        scale, shift: 1-D tensors -- one element for per-tensor, one per channel otherwise
+            (a single-element tensor is broadcast in the per-channel case).
+        quant_min, quant_max: bounds of the quantized range (default 0..255).
+        type_min, type_max: numeric limits of the quantized *type* used to clamp the zero point;
+            default to quant_min / quant_max.
+        axis: channel dimension of the per-channel scheme.
+        use_grad_scaling, grad_scaler: gradient scaling of the parameters, see above.
+        is_affine: asymmetric (True) or symmetric (False: no gradient for `shift`) quantization.
+        is_perchannel: per-channel (True) or per-tensor (False).
+        eval_mode: behave like a plain fake-quantizer (no parameter gradients).
+        init_mode: parameter-initialisation phase: the forward is the identity and the parameter
+            gradients are those of ||x_r - x||^2 (the upstream gradient is ignored for them).
+    """
+    _assert_has_ops()
+    if not is_affine:
+        assert quant_min <= 0 <= quant_max, 'quantization range must be covered 0 in symmetric quantization'
+    if type_min is None:
+        type_min = quant_min
+    if type_max is None:
+        type_max = quant_max
+    return torch.ops.torchlsq.lsq(x, scale, shift, quant_min, quant_max, type_min, type_max,
+                                  axis, use_grad_scaling, grad_scaler, is_affine, is_perchannel,
+                                  eval_mode, init_mode)

@@ -1,0 +1,390 @@
+"""LSQFakeQuantizer -- the `torch.quantization.FakeQuantize`-compatible module around the LSQ op.
+
+Behavioural restatement of reference torchlsq/quantized/modules/observers.py (class
+`LSQFakeQuantizer`, :72-483): same constructor arguments, attributes, parameter / buffer names
+(so state dicts interchange) and the same init -> observe/learn state machine in `forward`
+(:424-462).  The module is the caller of the hot path; the quantize/dequantize arithmetic itself
+runs in the gfx950 kernels behind `torchlsq.functional.lsq`.
+
+Two deliberate differences from the reference, both turning a crash into the documented behaviour:
+  * `LSQFakeQuantizer.with_args(...)` works (the reference calls `partial` without importing it,
+    observers.py:64);
+  * the inner observer receives the *resolved* channel axis (0 for weights / 1 for activations when
+    `ch_axis` is None) instead of the raw `None`.
+"""
+import inspect
+from functools import partial
+from math import ceil, copysign, log
+from typing import Tuple
+
+import torch
+from torch.ao.quantization.observer import ObserverBase as _TorchObserverBase
+
+from torchlsq.functional import lsq
+
+Tensor = torch.Tensor
+
+# ---- tables ------------------------------------------------------------------------------------
+OTYPES = {'weight': 0, 'activation': 1}
+TYPES_RANGE_MAPPING = {
+    torch.qint8: {'range': (-128, 127), 'bitness': 8, 'unsigned': False},
+    torch.quint8: {'range': (0, 255), 'bitness': 8, 'unsigned': True},
+}
+QSCHEMES = (torch.per_tensor_affine, torch.per_tensor_symmetric,
+            torch.per_channel_affine, torch.per_channel_symmetric)
+_PER_CHANNEL = (torch.per_channel_affine, torch.per_channel_symmetric)
+_AFFINE = (torch.per_tensor_affine, torch.per_channel_affine)
+
+
+def _known(qscheme):
+    assert qscheme in QSCHEMES, f"Only following schemes supported {QSCHEMES} but recieved {qscheme}"
+
+
+def IS_QSCHEME_PER_CHANNEL(qscheme):
+    _known(qscheme)
+    return qscheme in _PER_CHANNEL
+
+
+def IS_QSCHEME_AFFINE(qscheme):
+    _known(qscheme)
+    return qscheme in _AFFINE
+
+
+def IS_QSCHEME_PER_TENSOR(qscheme):
+    return not IS_QSCHEME_PER_CHANNEL(qscheme)
+
+
+def IS_QSCHEME_SYMMETRIC(qscheme):
+    return not IS_QSCHEME_AFFINE(qscheme)
+
+
+# ---- picklable `with_args` factories (reference :38-70) -------------------------------------------
+class _PartialWrapper(object):
+    def __init__(self, p):
+        self.p = p
+
+    def __call__(self, *args, **keywords):
+        return self.p(*args, **keywords)
+
+    def __repr__(self):
+        return self.p.__repr__()
+
+
+def _with_args(cls_or_self, **kwargs):
+    """Class factory: `Foo.with_args(a=1).with_args(b=2)()` builds `Foo(a=1, b=2)`; every call of
+    the factory makes a new instance (what QConfig expects of its activation/weight entries)."""
+    r = _PartialWrapper(partial(cls_or_self, **kwargs))
+    r.with_args = partial(_with_args, r)
+    return r
+
+
+class ObserverBase(_TorchObserverBase):
+    with_args = classmethod(_with_args)
+
+
+def _flag(value):
+    return torch.tensor([int(value)], dtype=torch.uint8)
+
+
+class LSQFakeQuantizer(ObserverBase):
+    """Fake quantizer with Learned Step Size Quantization (LSQ+, arXiv:2004.09576).
+
+    Quantize -> dequantize with learnable `scale` and `shift` (see `torchlsq.functional.lsq` for
+    the arithmetic).  PyTorch's quantized kernels expect qint8 weights and quint8 activations, so
+    `otype` fixes the dtype: 'weight' <-> qint8 (symmetric only), 'activation' <-> quint8.
+
+    Parameter initialisation
+      * weights: statically, at the first forward, `scale = max(|mean - 3 std|, |mean + 3 std|) / 2**bits`
+        (per channel for per-channel schemes);
+      * activations: during the first `init_batches` training batches, either from the wrapped
+        `observer` (init_mode='observer': the module acts as a plain fake-quantizer fed by the
+        observer's qparams) or by back-propagating ||x_r - x||^2 into scale/shift
+        (init_mode='learnable').
+    The first forward only creates the parameters and returns its input unchanged -- hand the
+    parameters to the optimizer after that call.
+
+    Default ranges are 7-bit (qint8 [-64, 63], quint8 [0, 127]) to avoid overflow in PyTorch's
+    quantized kernels; pass `avoid_torch_overflow=False` for the full 8 bits.
+
+    Args:
+        observer: observer *class* used for init_mode='observer' (e.g. MovingAverageMinMaxObserver).
+        otype: 'weight' or 'activation'.
+        dtype: torch.quint8 (default) or torch.qint8.
+        qscheme: per_tensor_affine (default), per_tensor_symmetric, per_channel_affine, per_channel_symmetric.
+        quant_min, quant_max: custom quantized range (both or neither).
+        init_scale, init_shift: initial parameters for activations (shift is overridden for symmetric schemes).
+        ch_axis: channel axis for per-channel schemes; default 0 for weights, 1 for activations.
+        learn_params: learn scale/shift with LSQ (True) or behave like FakeQuantize (False).
+        init_batches: number of initialisation batches for activations.
+        init_mode: 'observer' or 'learnable'.
+        use_grad_scaling, grad_scaler: gradient scaling of the parameters.
+        avoid_torch_overflow: use 7-bit default ranges / reduce_range in the observer.
+        debug_mode: forward is the identity.
+    """
+    init_modes = ('learnable', 'observer')
+
+    @staticmethod
+    def sign(x):
+        return copysign(1, x)
+
+    def __init__(self, observer, otype,
+                 dtype=torch.quint8,
+                 qscheme=torch.per_tensor_affine,
+                 quant_min=None, quant_max=None,
+                 init_scale=1., init_shift=0.,
+                 ch_axis=None, learn_params=True,
+                 init_batches=1000, init_mode='observer',
+                 use_grad_scaling=True, grad_scaler=1.,
+                 avoid_torch_overflow=True, debug_mode=False, **observer_kwargs):
+        super().__init__(dtype)
+        assert init_mode in self.init_modes, f'only following modes available: {("learnable", "observer")}'
+        assert otype in OTYPES, f'otype must be on of {tuple(OTYPES.keys())}, but {otype} is given'
+        assert self.dtype in TYPES_RANGE_MAPPING, \
+            f"Default Observer only works for {tuple(TYPES_RANGE_MAPPING.keys())} data types"
+        self.otype = OTYPES[otype]
+        self.qscheme = qscheme
+        # channel axis: 0 for weights, 1 for activations unless given
+        self.ch_axis = int(bool(self.otype)) if ch_axis is None else ch_axis
+
+        self.activation_post_process = None
+        if init_mode == 'observer':
+            assert inspect.isclass(observer), 'awaited Observer class not instance or function wrapper'
+            # offer the observer every constructor argument of ours that it knows by name, plus the
+            # caller's extra kwargs; reduce_range mirrors avoid_torch_overflow
+            offered = dict(dtype=dtype, qscheme=qscheme, quant_min=quant_min, quant_max=quant_max,
+                           init_scale=init_scale, init_shift=init_shift, ch_axis=self.ch_axis,
+                           learn_params=learn_params, init_batches=init_batches, init_mode=init_mode,
+                           use_grad_scaling=use_grad_scaling, grad_scaler=grad_scaler,
+                           avoid_torch_overflow=avoid_torch_overflow, debug_mode=debug_mode)
+            offered.update(observer_kwargs)
+            offered['reduce_range'] = avoid_torch_overflow
+            accepted = set(inspect.signature(observer.__init__).parameters) - {'self'}
+            self.activation_post_process = observer(**{k: v for k, v in offered.items() if k in accepted})
+
+        self.init_mode = init_mode
+        self.n_batches = init_batches
+        self.use_grad_scaling = use_grad_scaling
+        self.grad_scaler = grad_scaler
+        self.debug_mode = debug_mode
+        self.is_perchannel = IS_QSCHEME_PER_CHANNEL(self.qscheme)
+        self.is_affine = IS_QSCHEME_AFFINE(self.qscheme)
+        self.init_scale = init_scale
+        self.init_shift = init_shift
+        self.quant_min, self.quant_max = self._verify_qmin_qmax(quant_min, quant_max, lowbit=avoid_torch_overflow)
+        self.reset(learn_params=learn_params)
+
+    # ---- range bookkeeping ---------------------------------------------------------------------
+    def _verify_qmin_qmax(self, quant_min: int, quant_max: int, lowbit=True) -> Tuple[int, int]:
+        """Validate / derive the quantized range (reference :213-242)."""
+        if self.otype == OTYPES['weight']:
+            assert not self.is_affine, 'We support only symmetric scheme for weight'
+            assert self.dtype == torch.qint8, \
+                'Pytorch quantized operations implementaion requires `qint8` type for weights'
+        else:
+            assert self.dtype == torch.quint8, \
+                'Pytorch quantized operations implementaion requires `quint8` type for activation'
+        info = TYPES_RANGE_MAPPING[self.dtype]
+        bits = info['bitness'] - int(lowbit)
+        self.has_customized_qrange = (quant_min is not None) and (quant_max is not None)
+        if self.has_customized_qrange:
+            assert quant_min <= 0 <= quant_max, "User-specified quantization range must include 0."
+            assert quant_min < quant_max, \
+                "qmin must be strictly less than qmax for user-specified quantization range."
+            assert 0 < quant_max - quant_min + 1 <= int(2 ** bits), \
+                f"quantization range should be positive and not exceed the maximum bit range (=2^{bits})."
+        else:
+            quant_min, quant_max = 0, 2 ** bits - 1
+            if not info['unsigned']:
+                half = 2 ** (bits - 1)
+                quant_min, quant_max = quant_min - half, quant_max - half
+        if not self.is_affine:
+            # symmetric: the shift is fixed by the (a)symmetry of the integer range
+            mid = quant_min + quant_max
+            self.init_shift = -float(abs(mid) // 2) * self.sign(mid) * self.init_scale
+        return quant_min, quant_max
+
+    # ---- state -----------------------------------------------------------------------------------
+    @torch.jit.export
+    def reset(self, learn_params=True) -> None:
+        if self.otype == OTYPES['weight']:
+            self.n_batches = -1          # weights are initialised statically, no init phase
+        self._initialized = False
+        self.register_parameter('scale', None)
+        self.register_parameter('shift', None)
+        self.register_buffer('fake_quant_enabled', _flag(1))
+        self.register_buffer('observer_enabled', _flag(1))
+        self.register_buffer('learning_enabled', _flag(learn_params))
+        self.register_buffer('current_batch', torch.tensor([0], dtype=torch.int64))
+        self.enable_observer()           # applies the "observer not needed" rules below
+
+    def check_is_init_mode(self):
+        return (bool(self.learning_enabled[0]) and self.otype != OTYPES['weight']
+                and bool(self.current_batch[0] <= self.n_batches))
+
+    @torch.jit.export
+    def enable_observer(self) -> None:
+        needed = True
+        if self.learning_enabled[0] == 1:
+            if self.otype == OTYPES['weight']:
+                needed = False           # learned weights never use the observer
+            elif self.init_mode == 'learnable':
+                needed = False           # parameters come from back-propagation
+            elif self.init_mode == 'observer' and self.current_batch[0] > self.n_batches:
+                needed = False           # the observer-driven init phase is over
+        self.observer_enabled[0] = int(needed)
+
+    @torch.jit.export
+    def disable_observer(self) -> None:
+        self.observer_enabled[0] = 0
+
+    @torch.jit.export
+    def enable_fake_quant(self) -> None:
+        self.fake_quant_enabled[0] = 1
+
+    @torch.jit.export
+    def disable_fake_quant(self) -> None:
+        self.fake_quant_enabled[0] = 0
+
+    @torch.jit.export
+    def enable_param_learning(self):
+        """Learn scale/shift with LSQ; static observer estimates are switched off and the
+        initialisation phase is considered done."""
+        self.learning_enabled[0] = 1
+        self.disable_observer()
+        self.n_batches = -1
+
+    @torch.jit.export
+    def enable_static_estimate(self):
+        """Stop learning; scale/shift follow the observer (FakeQuantize behaviour)."""
+        self.learning_enabled[0] = 0
+        self.enable_observer()
+
+    # ---- parameters ------------------------------------------------------------------------------
+    def _init_weights(self, x: Tensor, _init_device=torch.device('cpu')) -> None:
+        """Create `scale` / `shift` from an example input (reference :314-342)."""
+        self._initialized = True
+        n = x.shape[self.ch_axis] if (self.is_perchannel and x is not None) else 1
+        device = x.device if x is not None else _init_device
+        scale = torch.full((n,), self.init_scale, dtype=torch.float32).to(device)
+        if self.otype == OTYPES['weight'] and x is not None:
+            # 3-sigma rule: s = max(|mu - 3 sigma|, |mu + 3 sigma|) / 2**bits
+            w = x.detach()
+            other_axes = [d for d in range(w.ndim) if d != self.ch_axis]
+            bits = ceil(log(self.quant_max - self.quant_min) / log(2)) - 1
+            with torch.no_grad():
+                if n == 1:
+                    mu, sigma = w.mean().unsqueeze(0), w.std().unsqueeze(0)
+                else:
+                    mu, sigma = torch.mean(w, other_axes), torch.std(w, other_axes)
+                spread = torch.max(torch.abs(mu - 3 * sigma), torch.abs(mu + 3 * sigma))
+                scale = (spread.to(device) / 2 ** bits).to(torch.float32)
+        shift = torch.full((n,), self.init_shift, dtype=torch.float32).to(device)
+        self.scale = torch.nn.Parameter(scale)
+        self.shift = torch.nn.Parameter(shift)
+        learn = bool(self.learning_enabled[0])
+        self.scale.requires_grad = learn
+        self.shift.requires_grad = learn and self.is_affine
+
+    def _set_weights(self, scale=None, shift=None, zero_point=None, _init_device=torch.device('cpu')):
+        """Copy new values into the parameters; `zero_point` is converted to a shift
+        (shift = -zero_point * scale) (reference :346-373)."""
+        if self.scale is None:
+            self._init_weights(None, _init_device=_init_device)   # per-tensor technical init
+        if scale is not None:
+            with torch.no_grad():
+                scale = scale.to(self.scale.device).to(self.scale.dtype)
+                scale.resize_(self.scale.shape)
+            self.scale.data.copy_(scale)
+        if zero_point is not None:
+            with torch.no_grad():
+                shift = -zero_point.to(self.scale.device) * self.scale.detach()
+        if shift is not None:
+            with torch.no_grad():
+                shift = shift.to(self.shift.device).to(self.shift.dtype)
+                shift.resize_(self.shift.shape)
+            self.shift.data.copy_(shift)
+
+    def set_weights(self, scale, zero_point=None, _init_device=torch.device('cpu')):
+        self._set_weights(scale, shift=None, zero_point=zero_point, _init_device=_init_device)
+
+    @staticmethod
+    def convert_shift_to_zp(shift, scale, dtype):
+        """zero_point = clamp(round(-shift / scale), type range) as int64 (reference :378-401)."""
+        lo, hi = TYPES_RANGE_MAPPING[dtype]['range']
+        with torch.no_grad():
+            zp = -shift / scale
+            zp.round_().clamp_(min=lo, max=hi)
+            return zp.to(torch.int64)
+
+    @torch.jit.export
+    def calculate_qparams(self, verbose=True, need_shift=False) -> Tuple[Tensor, Tensor]:
+        if not self._initialized:
+            if verbose:
+                print("Scale and Zero Point are not initialized properly, because  LSQObserver was never called.\
+                       You must at least run model on random tensor, before calling convert!\
+                       Returned init_scale and init_zero_point")
+            zp = self.convert_shift_to_zp(torch.tensor(self.init_shift), torch.tensor(self.init_scale),
+                                          self.dtype).item()
+            return (self.init_scale, self.init_shift, zp) if need_shift else (self.init_scale, zp)
+        scale = torch.max(self.scale.detach().clone().cpu(), torch.tensor(torch.finfo(torch.float32).eps))
+        shift = self.shift.detach().clone().cpu()
+        zero_point = self.convert_shift_to_zp(shift, scale, self.dtype)
+        return (scale, shift, zero_point) if need_shift else (scale, zero_point)
+
+    # ---- the caller of the hot path ------------------------------------------------------------
+    def forward(self, x):
+        if self.debug_mode:
+            return x
+        if not self._initialized:
+            self._init_weights(x)
+            return x                        # the creating call passes its input through
+        full_lsq = bool(self.learning_enabled[0])
+        backprop_init = False
+        if self.current_batch[0] <= self.n_batches and self.training and self.learning_enabled[0] == 1:
+            last = bool(self.current_batch[0] == self.n_batches)
+            if self.init_mode == 'observer':
+                # plain fake-quant driven by the observer until the last init batch
+                full_lsq = last
+                if last:
+                    self.disable_observer()
+            elif self.init_mode == 'learnable':
+                self.disable_observer()
+                backprop_init = not last
+            self.current_batch[0] += 1
+
+        if self.observer_enabled[0] == 1:
+            self.activation_post_process(x.detach())
+            scale, zero_point = self.activation_post_process.calculate_qparams()
+            self._set_weights(scale=scale, zero_point=zero_point)
+
+        if self.fake_quant_enabled[0] == 1:
+            backprop_init = bool(backprop_init and full_lsq)
+            tmin, tmax = TYPES_RANGE_MAPPING[self.dtype]['range']
+            self.scale.requires_grad = full_lsq
+            self.shift.requires_grad = full_lsq and self.is_affine
+            return lsq(x, self.scale, self.shift, self.quant_min, self.quant_max, tmin, tmax,
+                       self.ch_axis, self.use_grad_scaling, self.grad_scaler,
+                       self.is_affine, self.is_perchannel,
+                       eval_mode=(not full_lsq), init_mode=backprop_init)
+        return x
+
+    @torch.jit.export
+    def extra_repr(self):
+        if self.debug_mode:
+            return 'Debug mode: ON, doing nothing.'
+        scale, shift, zp = self.calculate_qparams(verbose=False, need_shift=True)
+        head = '' if self._initialized else '(Uninitialized!) '
+        if self.check_is_init_mode():
+            head += (f'(Observer in parameter init mode: {self.init_mode}; '
+                     f'{self.current_batch[0]}/{self.n_batches} batches left) ')
+        target = 'weights' if self.otype == OTYPES['weight'] else 'activation'
+        per_channel = f'Yes, channel axis - {self.ch_axis}' if self.is_perchannel else 'No'
+        torch.set_printoptions(threshold=8)
+        text = (f"{head}Observer for {target}; Learnable:{bool(self.learning_enabled[0])}; "
+                f"Observer:{bool(self.observer_enabled[0])}; FakeQuant:{bool(self.fake_quant_enabled[0])}; "
+                f"Qtype:{self.dtype}, Affine:{self.is_affine}, PerChannel:{per_channel}, "
+                f"Qrange:[{self.quant_min},{self.quant_max}], scale={scale}, zero_point={zp} (shift={shift}).")
+        if hasattr(self, 'recalibrated'):
+            text += '\nModule was recalibrated!'
+        torch.set_printoptions(threshold=1000)
+        return text

@@ -1,0 +1,386 @@
+"""GPU parity tests (run with -m gpu on the MI355X box).
+
+Everything goes through the product path: torch.ops.torchlsq.* -> ctypes -> liblsq_hip.so (C ABI)
+-> gfx950 kernels.  Expected values are the reference CPU csrc's (committed golden fixtures) and
+the CPU oracle on the same seeded inputs.  Bars (BASELINE.json north_star):
+    y, dx, integer levels : bit-exact
+    d_scale, d_shift      : |got - ref| <= 1e-6 * sum|terms|   (= 1e-6 relative when terms do not cancel)
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import TOL, assert_bits_equal, assert_reduction_close, sha
+from oracle import lsq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    import torchlsq  # noqa: F401
+    from torchlsq import extension
+    extension._assert_has_ops()   # no native library -> fail loudly, never fall back
+    return torch.device("cuda:0")
+
+
+def _lsq_fwd_bwd(dev, x, g, scale, shift, p):
+    from torchlsq.functional import lsq
+    xg = torch.from_numpy(x).to(dev).requires_grad_(True)
+    sg = torch.from_numpy(scale).to(dev).requires_grad_(True)
+    bg = torch.from_numpy(shift).to(dev).requires_grad_(True)
+    y = lsq(xg, sg, bg, p["quant_min"], p["quant_max"], p["type_min"], p["type_max"], p["axis"],
+            p["use_grad_scaling"], p["grad_scaler"], p["is_affine"], p["is_perchannel"], p["eval_mode"], p["init_mode"])
+    y.backward(torch.from_numpy(g).to(dev))
+    torch.cuda.synchronize()
+    zs = lambda t, like: np.zeros_like(like) if t is None else t.cpu().numpy()
+    return y.detach().cpu().numpy(), xg.grad.cpu().numpy(), zs(sg.grad, scale), zs(bg.grad, shift)
+
+
+def test_small_cases_match_reference(dev, small_cases):
+    manifest, arrays = small_cases
+    for case in manifest["cases"]:
+        k, p = case["key"], case["params"]
+        y, dx, ds, db = _lsq_fwd_bwd(dev, arrays[k + "x"], arrays[k + "g"], arrays[k + "scale"], arrays[k + "shift"], p)
+        assert_bits_equal(y, arrays[k + "y"], case["name"] + " y")
+        assert_bits_equal(dx, arrays[k + "dx"], case["name"] + " dx")
+        assert_reduction_close(ds, arrays[k + "ds"], arrays[k + "abs_ds"], case["name"] + " ds")
+        assert_reduction_close(db, arrays[k + "db"], arrays[k + "abs_db"], case["name"] + " db")
+
+
+def test_grad_scaler_chain_on_device(dev, small_cases):
+    """One saturated element with grad 1: ds must be fp(qmax * scaler) bit-for-bit (lsq_cpu.cpp:103,250)."""
+    manifest, _ = small_cases
+    ops = torch.ops.torchlsq
+    for r in manifest["scaler_chain"][::7]:
+        dt = torch.float32 if r["dtype"] == "float32" else torch.float64
+        shape = tuple(r["shape"])
+        n = int(np.prod(shape))
+        x = torch.zeros(shape, dtype=dt, device=dev)
+        g = torch.zeros(shape, dtype=dt, device=dev)
+        x.view(-1)[n // 2] = 1e6
+        g.view(-1)[n // 2] = 1.0
+        want = np.frombuffer(bytes.fromhex(r["ds_hex"]), dtype=r["dtype"])
+        if r["kind"] == "pt":
+            _, ds, _ = ops.lsq_backward_per_tensor(g, x, torch.ones(1, dtype=dt, device=dev), torch.zeros(1, dtype=dt, device=dev),
+                                                   0, r["qmax"], 0, 255, True, r["grad_scaler"], False, False, False)
+            got = ds.cpu().numpy()
+        else:
+            C = shape[r["axis"]]
+            _, ds, _ = ops.lsq_backward_per_channel(g, x, torch.ones(C, dtype=dt, device=dev), torch.zeros(C, dtype=dt, device=dev),
+                                                    r["axis"], 0, r["qmax"], 0, 255, True, r["grad_scaler"], False, False, False)
+            got = ds.cpu().numpy()
+            got = got[got != 0]
+        assert got.tobytes() == want.tobytes(), (r, got, want)
+
+
+def _run_config(dev, d, dtype=torch.float32):
+    """Regenerate the seeded inputs ON THE GPU (bit-identical to the CPU generator), run fwd+bwd."""
+    from torchlsq import synth
+    from torchlsq.functional import lsq
+    x, g, scale, shift = synth.make_inputs(d["config"], device=dev, dtype=dtype, abs_grad=d["abs_grad"])
+    x.requires_grad_(True)
+    scale.requires_grad_(True)
+    shift.requires_grad_(True)
+    y = lsq(x, scale, shift, **synth.op_kwargs(d["config"]))
+    y.backward(g)
+    torch.cuda.synchronize()
+    return x, g, scale, shift, y
+
+
+def _sha_t(t):
+    t = t.detach().contiguous()
+    if t.dtype == torch.bfloat16:
+        t = t.view(torch.int16)
+    return sha(t.cpu().numpy())
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg1_absgrad", "cfg3", "cfg3_absgrad", "cfg5_fp32", "cfg2", "cfg2_absgrad", "cfg4"])
+def test_baseline_configs_match_reference_digests(dev, config_digests, name):
+    """BASELINE.json shapes at FULL size against digests of the reference CPU csrc's outputs."""
+    d = config_digests[name]
+    x, g, scale, shift, y = _run_config(dev, d)
+    assert _sha_t(x) == d["inputs_sha256"]["x"], "GPU input generation is not bit-identical to the CPU generator"
+    assert _sha_t(g) == d["inputs_sha256"]["g"]
+    assert _sha_t(y) == d["y_sha256"], name + ": y differs from the reference"
+    assert _sha_t(x.grad) == d["dx_sha256"], name + ": dx differs from the reference"
+    assert_reduction_close(scale.grad.cpu().numpy(), d["ds"], d["oracle_abs_ds"], name + " ds")
+    sg = shift.grad.cpu().numpy() if shift.grad is not None else np.zeros(len(d["db"]))
+    assert_reduction_close(sg, d["db"], d["oracle_abs_db"], name + " db")
+    if name.endswith("absgrad"):  # no cancellation: plain 1e-6 relative to the reference value
+        np.testing.assert_allclose(scale.grad.cpu().numpy().astype(np.float64), np.array(d["ds"]), rtol=TOL, atol=0)
+
+
+def test_bf16_io_config5(dev, config_digests):
+    """BASELINE config 5: bf16 in/out, fp32 math.  Definition: reference fp32 CPU csrc on
+    the upcast input, y/dx rounded to bf16 (RNE); ds/db stay fp32."""
+    d = config_digests["cfg5_bf16"]
+    x, g, scale, shift, y = _run_config(dev, d, dtype=torch.bfloat16)
+    assert y.dtype == torch.bfloat16 and x.grad.dtype == torch.bfloat16 and scale.grad.dtype == torch.float32
+    assert _sha_t(x.float()) == d["inputs_sha256"]["x"]
+    assert _sha_t(y) == d["y_bf16_sha256"]
+    assert _sha_t(x.grad) == d["dx_bf16_sha256"]
+    assert_reduction_close(scale.grad.cpu().numpy(), d["ds"], d["oracle_abs_ds"], "cfg5 bf16 ds")
+    assert_reduction_close(shift.grad.cpu().numpy(), d["db"], d["oracle_abs_db"], "cfg5 bf16 db")
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg3", "cfg5_fp32", "cfg2"])
+def test_integer_levels_bit_exact(dev, config_digests, name):
+    """The quantized integer levels (int8 emission of the forward) against the reference-derived digest."""
+    from torchlsq import synth
+    d = config_digests[name]
+    p = d["params"]
+    x, _, scale, shift = synth.make_inputs(d["config"], device=dev, dtype=torch.float32)
+    bias = 128 if p["quant_max"] > 127 else 0
+    if p["is_perchannel"]:
+        y, q = torch.ops.torchlsq.lsq_quantize_per_channel(x, scale, shift, p["axis"], p["quant_min"], p["quant_max"],
+                                                           p["type_min"], p["type_max"], bias)
+    else:
+        y, q = torch.ops.torchlsq.lsq_quantize_per_tensor(x, scale, shift, p["quant_min"], p["quant_max"],
+                                                          p["type_min"], p["type_max"], bias)
+    assert q.dtype == torch.int8
+    lv = q.to(torch.int16) + bias
+    assert sha(lv.cpu().numpy()) == d["levels_int16_sha256"]
+    hist = torch.bincount((lv.view(-1).to(torch.int64) - p["quant_min"]), minlength=p["quant_max"] - p["quant_min"] + 1)
+    assert hist.cpu().tolist() == d["level_hist"]
+    assert _sha_t(y) == d["y_sha256"]
+
+
+# ---- layouts, alignment, ragged sizes -------------------------------------------------------------
+def _oracle_pt(x, g, s, b, p, **kw):
+    y = O.fwd_pt(x, s, b, p[0], p[1], p[2], p[3], kw.get("init_mode", False))
+    r = O.bwd_pt(g, x, s, b, p[0], p[1], p[2], p[3], True, 1.0, kw.get("sym", False), kw.get("eval_mode", False),
+                 kw.get("init_mode", False))
+    return y, r
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 65537,
+                               1048576 + 3, 3 * 1048576 + 1021])
+def test_per_tensor_ragged_sizes(dev, n):
+    from torchlsq import synth
+    x = synth.normal_like(n, 5, 1.5, 1.0)
+    g = synth.normal_like(n, 6, 0.0, 1e-3)
+    p = (0, 127, 0, 255)
+    ops = torch.ops.torchlsq
+    s, b = torch.tensor([0.03], device=dev), torch.tensor([0.07], device=dev)
+    y = ops.lsq_forward_per_tensor(x.to(dev), s, b, *p, True, 1.0, False, False, False)
+    dx, ds, db = ops.lsq_backward_per_tensor(g.to(dev), x.to(dev), s, b, *p, True, 1.0, False, False, False)
+    oy, r = _oracle_pt(x.numpy(), g.numpy(), 0.03, 0.07, p)
+    assert_bits_equal(y.cpu().numpy(), oy, "y n=%d" % n)
+    assert_bits_equal(dx.cpu().numpy(), r.dx, "dx n=%d" % n)
+    assert_reduction_close(ds.cpu().numpy(), r.ds_wide, r.abs_ds, "ds n=%d" % n)
+    assert_reduction_close(db.cpu().numpy(), r.db_wide, r.abs_db, "db n=%d" % n)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16, torch.float16])
+def test_misaligned_views_take_the_scalar_path(dev, dtype):
+    """x[1:] is not 16-byte aligned: the library must fall back to its element-wise kernels."""
+    from torchlsq import synth
+    n = 10007
+    pdt = torch.float64 if dtype == torch.float64 else torch.float32
+    xb = synth.normal_like(n + 1, 5, 1.5, 1.0, dtype=dtype)
+    gb = synth.normal_like(n + 1, 6, 0.0, 1e-3, dtype=dtype)
+    x, g = xb.to(dev)[1:], gb.to(dev)[1:]
+    assert x.data_ptr() % 16 != 0
+    p = (0, 127, 0, 255)
+    s, b = torch.tensor([0.03], device=dev, dtype=pdt), torch.tensor([0.07], device=dev, dtype=pdt)
+    ops = torch.ops.torchlsq
+    y = ops.lsq_forward_per_tensor(x, s, b, *p, True, 1.0, False, False, False)
+    dx, ds, db = ops.lsq_backward_per_tensor(g, x, s, b, *p, True, 1.0, False, False, False)
+    odt = np.float64 if dtype == torch.float64 else np.float32
+    xn = xb[1:].to(pdt).numpy().astype(odt)
+    gn = gb[1:].to(pdt).numpy().astype(odt)
+    sv = s.cpu().numpy()[0]
+    bv = b.cpu().numpy()[0]
+    oy, r = _oracle_pt(xn, gn, sv, bv, p)
+    want_y = torch.from_numpy(oy).to(dtype)
+    want_dx = torch.from_numpy(r.dx).to(dtype)
+    assert torch.equal(y.cpu(), want_y)
+    assert torch.equal(dx.cpu(), want_dx)
+    assert_reduction_close(ds.cpu().numpy(), r.ds_wide, r.abs_ds, "ds")
+    assert_reduction_close(db.cpu().numpy(), r.db_wide, r.abs_db, "db")
+
+
+PC_SHAPES = [
+    ((4, 8, 6, 6), 1), ((8, 4, 3, 3), 0), ((5, 16), 1), ((3, 5, 6), 2), ((3, 5, 7), 1), ((2, 3, 7, 7), 1),
+    ((64, 64, 3, 3), 0), ((16, 256, 7, 7), 1), ((2, 2048, 7, 7), 1), ((33, 1000), 1), ((1000, 33), 0), ((7, 1031), 1),
+    ((300, 16), 1), ((5000, 8), 1), ((129, 4096), 1), ((4, 3, 224, 224), 1), ((2, 512, 14, 14), 1), ((1, 1, 5), 1),
+    ((6, 1, 9), 1), ((1, 7), 1), ((257, 3), 1), ((2, 6, 2), 1), ((9, 2050, 3), 1),
+]
+
+
+@pytest.mark.parametrize("shape,axis", PC_SHAPES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_per_channel_layouts(dev, shape, axis, dtype):
+    from torchlsq import synth
+    n = int(np.prod(shape))
+    C = shape[axis]
+    x = synth.normal_like(n, 15, 0.0, 1.0, dtype=dtype).view(shape)
+    g = synth.normal_like(n, 16, 0.0, 1e-3, dtype=dtype).view(shape)
+    scale = synth.uniform_like(C, 17, 0.05, 0.35, dtype=dtype)
+    shift = synth.normal_like(C, 18, 0.0, 0.1, dtype=dtype)
+    p = (-8, 7, -128, 127)
+    ops = torch.ops.torchlsq
+    y = ops.lsq_forward_per_channel(x.to(dev), scale.to(dev), shift.to(dev), axis, *p, True, 1.0, False, False, False)
+    dx, ds, db = ops.lsq_backward_per_channel(g.to(dev), x.to(dev), scale.to(dev), shift.to(dev), axis, *p, True, 1.0,
+                                              False, False, False)
+    outer, C_, inner = O.axis_to_ocl(shape, axis)
+    oy = O.fwd_pc(x.numpy(), scale.numpy(), shift.numpy(), outer, C_, inner, *p)
+    r = O.bwd_pc(g.numpy(), x.numpy(), scale.numpy(), shift.numpy(), outer, C_, inner, *p, True, 1.0, False)
+    assert_bits_equal(y.cpu().numpy(), oy, "y")
+    assert_bits_equal(dx.cpu().numpy(), r.dx, "dx")
+    assert_reduction_close(ds.cpu().numpy(), r.ds_wide, r.abs_ds, "ds")
+    assert_reduction_close(db.cpu().numpy(), r.db_wide, r.abs_db, "db")
+
+
+def test_channels_last_and_permuted_inputs(dev):
+    """The reference preserves the memory format (empty_like(..., Preserve), lsq_cpu.cpp:31,80) and
+    accepts arbitrary strides; results must not depend on the layout."""
+    from torchlsq import synth
+    shape = (4, 16, 6, 10)
+    n = int(np.prod(shape))
+    x = synth.normal_like(n, 25, 0.0, 1.0).view(shape)
+    g = synth.normal_like(n, 26, 0.0, 1e-3).view(shape)
+    scale = synth.uniform_like(16, 27, 0.05, 0.35)
+    shift = synth.normal_like(16, 28, 0.0, 0.1)
+    p = (-8, 7, -128, 127)
+    ops = torch.ops.torchlsq
+    xd, gd, sd, bd = x.to(dev), g.to(dev), scale.to(dev), shift.to(dev)
+    y0 = ops.lsq_forward_per_channel(xd, sd, bd, 1, *p, True, 1.0, False, False, False)
+    dx0, ds0, db0 = ops.lsq_backward_per_channel(gd, xd, sd, bd, 1, *p, True, 1.0, False, False, False)
+    variants = {
+        "channels_last": (xd.contiguous(memory_format=torch.channels_last), gd.contiguous(memory_format=torch.channels_last)),
+        "grad_other_layout": (xd.contiguous(memory_format=torch.channels_last), gd),
+        "permuted": (xd.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2), gd),
+        "strided": (torch.cat([xd, xd], 3)[..., ::2][..., :10], gd),
+    }
+    for name, (xv, gv) in variants.items():
+        if name == "strided":
+            xv = torch.empty(4, 16, 6, 20, device=dev)[..., ::2]
+            xv.copy_(xd)
+            assert not xv.is_contiguous()
+        y = ops.lsq_forward_per_channel(xv, sd, bd, 1, *p, True, 1.0, False, False, False)
+        dx, ds, db = ops.lsq_backward_per_channel(gv, xv, sd, bd, 1, *p, True, 1.0, False, False, False)
+        assert torch.equal(y, y0), name
+        assert torch.equal(dx, dx0), name
+        if name == "channels_last":
+            assert y.is_contiguous(memory_format=torch.channels_last) and dx.is_contiguous(memory_format=torch.channels_last)
+        r_abs = ds0.abs().cpu().numpy() + 1e-12
+        np.testing.assert_allclose(ds.cpu().numpy(), ds0.cpu().numpy(), rtol=1e-5, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(db.cpu().numpy(), db0.cpu().numpy(), rtol=1e-5, atol=1e-9, err_msg=name)
+    # per-tensor on a channels-last tensor
+    s1, b1 = torch.tensor([0.1], device=dev), torch.tensor([0.05], device=dev)
+    ya = ops.lsq_forward_per_tensor(xd, s1, b1, *p, True, 1.0, False, False, False)
+    yb = ops.lsq_forward_per_tensor(xd.contiguous(memory_format=torch.channels_last), s1, b1, *p, True, 1.0, False, False, False)
+    assert torch.equal(ya, yb) and yb.is_contiguous(memory_format=torch.channels_last)
+
+
+def test_modes_eval_init_sym(dev):
+    from torchlsq import synth
+    n = 300_001
+    x = synth.normal_like(n, 35, 0.0, 1.0)
+    g = synth.normal_like(n, 36, 0.0, 1e-3)
+    ops = torch.ops.torchlsq
+    s, b = torch.tensor([0.02], device=dev), torch.tensor([0.01], device=dev)
+    p = (-64, 63, -128, 127)
+    for sym in (False, True):
+        for ev in (False, True):
+            for init in (False, True):
+                y = ops.lsq_forward_per_tensor(x.to(dev), s, b, *p, True, 1.0, sym, ev, init)
+                dx, ds, db = ops.lsq_backward_per_tensor(g.to(dev), x.to(dev), s, b, *p, True, 1.0, sym, ev, init)
+                oy, r = _oracle_pt(x.numpy(), g.numpy(), 0.02, 0.01, p, sym=sym, eval_mode=ev, init_mode=init)
+                tag = "sym=%s eval=%s init=%s" % (sym, ev, init)
+                assert_bits_equal(y.cpu().numpy(), oy, "y " + tag)
+                assert_bits_equal(dx.cpu().numpy(), r.dx, "dx " + tag)
+                assert_reduction_close(ds.cpu().numpy(), r.ds_wide, r.abs_ds, "ds " + tag)
+                assert_reduction_close(db.cpu().numpy(), r.db_wide, r.abs_db, "db " + tag)
+                if init:
+                    assert torch.equal(y.cpu(), x) and torch.equal(dx.cpu(), g)
+                if ev:
+                    assert ds.item() == 0.0 and db.item() == 0.0
+
+
+def test_empty_tensors(dev):
+    ops = torch.ops.torchlsq
+    xe = torch.zeros(0, 3, device=dev)
+    s, b = torch.full((1,), 0.5, device=dev), torch.full((1,), 0.25, device=dev)
+    y = ops.lsq_forward_per_tensor(xe, s, b, 0, 127, 0, 255, True, 1.0, False, False, False)
+    assert y.shape == (0, 3)
+    dx, ds, db = ops.lsq_backward_per_tensor(xe, xe, s, b, 0, 127, 0, 255, True, 1.0, False, False, False)
+    assert dx.shape == (0, 3) and ds.item() == 0.5 and db.item() == 0.25      # lsq_cpu.cpp:76-78
+
+
+def test_errors_match_reference_checks(dev):
+    from torchlsq.functional import lsq
+    x = torch.randn(4, 8, device=dev)
+    s, b = torch.ones(1, device=dev), torch.zeros(1, device=dev)
+    with pytest.raises(RuntimeError, match="scale should be a 1-D tensor"):
+        lsq(x, torch.tensor(1.0, device=dev), b)
+    with pytest.raises(RuntimeError, match="shift should be a 1-D tensor"):
+        lsq(x, s, torch.tensor(0.0, device=dev))
+    with pytest.raises(RuntimeError, match="must have the same floating-point type"):
+        lsq(x, s.double(), b)
+    with pytest.raises(RuntimeError, match="not consistent with input tensor"):
+        lsq(x, torch.ones(3, device=dev), torch.zeros(3, device=dev), is_perchannel=True)
+    with pytest.raises(AssertionError):
+        lsq(x, s, b, quant_min=1, quant_max=5, is_affine=False)
+    with pytest.raises(NotImplementedError):
+        lsq(x.cpu(), s.cpu(), b.cpu())       # no CPU fallback in this build
+
+
+def test_backward_is_deterministic_and_graph_safe(dev):
+    """No atomics in the per-tensor reduction: two runs are bit-identical; no host sync in the op
+    (scale/shift are read on the device), so it captures into a HIP graph."""
+    from torchlsq import synth
+    n = 8 * 1024 * 1024 + 5
+    x = synth.normal_like(n, 45, 1.5, 1.0, device=dev)
+    g = synth.normal_like(n, 46, 0.0, 1e-3, device=dev)
+    s, b = torch.tensor([0.03], device=dev), torch.tensor([0.0], device=dev)
+    ops = torch.ops.torchlsq
+    a = ops.lsq_backward_per_tensor(g, x, s, b, 0, 127, 0, 255, True, 1.0, False, False, False)
+    c = ops.lsq_backward_per_tensor(g, x, s, b, 0, 127, 0, 255, True, 1.0, False, False, False)
+    assert all(torch.equal(u, v) for u, v in zip(a, c))
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ops.lsq_forward_per_tensor(x, s, b, 0, 127, 0, 255, True, 1.0, False, False, False)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            yg = ops.lsq_forward_per_tensor(x, s, b, 0, 127, 0, 255, True, 1.0, False, False, False)
+            dg = ops.lsq_backward_per_tensor(g, x, s, b, 0, 127, 0, 255, True, 1.0, False, False, False)
+        s.fill_(0.05)          # the replay must see the NEW scale: nothing was baked in on the host
+        graph.replay()
+    torch.cuda.synchronize()
+    y2 = ops.lsq_forward_per_tensor(x, s, b, 0, 127, 0, 255, True, 1.0, False, False, False)
+    d2 = ops.lsq_backward_per_tensor(g, x, s, b, 0, 127, 0, 255, True, 1.0, False, False, False)
+    assert torch.equal(yg, y2) and all(torch.equal(u, v) for u, v in zip(dg, d2))
+
+
+def test_full_size_properties_cfg2(dev):
+    """Size-independent properties at BASELINE config 2 (205 M elements)."""
+    from torchlsq import synth
+    d = synth.CONFIGS["cfg2"]
+    x, g, scale, shift = synth.make_inputs("cfg2", device=dev, dtype=torch.float32)
+    ops = torch.ops.torchlsq
+    p = (d["qmin"], d["qmax"], d["tmin"], d["tmax"])
+    y = ops.lsq_forward_per_tensor(x, scale, shift, *p, True, 1.0, False, False, False)
+    # idempotence: fake-quantising a fake-quantised tensor changes nothing
+    y2 = ops.lsq_forward_per_tensor(y, scale, shift, *p, True, 1.0, False, False, False)
+    assert torch.equal(y, y2)
+    # every output is one of the (qmax-qmin+1) dequantised levels
+    assert torch.unique(y).numel() <= d["qmax"] - d["qmin"] + 1
+    # dx is grad where the input is strictly inside the range, 0 elsewhere
+    dx, ds, db = ops.lsq_backward_per_tensor(g, x, scale, shift, *p, True, 1.0, False, False, False)
+    inside = (dx != 0)
+    assert torch.equal(dx[inside], g[inside])
+    # linearity of the parameter gradients in grad: bwd(2g) == 2*bwd(g) exactly (power of two)
+    dx_2, ds_2, db_2 = ops.lsq_backward_per_tensor(g * 2, x, scale, shift, *p, True, 1.0, False, False, False)
+    assert torch.equal(dx_2, dx * 2) and torch.equal(ds_2, ds * 2) and torch.equal(db_2, db * 2)
+    # shards add up: wide sums of two halves == wide sum of the whole (the multi-GPU contract)
+    n = x.numel()
+    h = x.shape[0] // 2
+    _, w_all = ops.lsq_backward_per_tensor_wide(g, x, scale, shift, *p, True, 1.0, False, False, False, n)
+    _, w_a = ops.lsq_backward_per_tensor_wide(g[:h], x[:h], scale, shift, *p, True, 1.0, False, False, False, n)
+    _, w_b = ops.lsq_backward_per_tensor_wide(g[h:], x[h:], scale, shift, *p, True, 1.0, False, False, False, n)
+    np.testing.assert_allclose((w_a + w_b).cpu().numpy(), w_all.cpu().numpy(), rtol=1e-12, atol=0)
+    assert torch.equal(w_all.to(torch.float32)[0], ds[0])
