@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <type_traits>
 
 #include "../../include/lsq_hip.h"
 #include "lsq_math.hpp"
@@ -20,53 +21,65 @@ constexpr int kMaxBlocksPerCU = 16;
 // ---- launch variants (tuning knobs; the defaults are what bench/profiles were measured with) ----
 struct Variant {
     int unroll;         // 16-byte packets in flight per lane per stream
-    bool nt;            // non-temporal loads/stores (stream past the caches)
+    bool nt_load;       // non-temporal loads  (global_load ... nt)
+    bool nt_store;      // non-temporal stores (global_store ... nt)
     int blocks_per_cu;  // persistent-grid size = CUs * blocks_per_cu
+    bool chunked;       // tile -> workgroup map: false = strided (tile t -> wg t % grid), true = contiguous chunks
 };
-// encoded as unroll | nt << 8 | blocks_per_cu << 16 ; 0 = "use the default"
-constexpr int encode_variant(int unroll, bool nt, int bpc) { return unroll | (nt ? 1 << 8 : 0) | (bpc << 16); }
-constexpr int kDefaultFwdVariant = encode_variant(4, true, 8);
-constexpr int kDefaultBwdVariant = encode_variant(4, true, 8);
-constexpr int kDefaultPcVariant = encode_variant(4, true, 8);
+// encoded as unroll | nt_load << 8 | nt_store << 9 | chunked << 10 | blocks_per_cu << 16 ; 0 = "use the default"
+constexpr int encode_variant(int unroll, bool ntl, bool nts, int bpc) {
+    return unroll | (ntl ? 1 << 8 : 0) | (nts ? 1 << 9 : 0) | (bpc << 16);
+}
+// Tuned on MI355X at BASELINE config 2 (tools/tune_stream.py, profiles/r01_tune_*.log): the forward
+// (1 read : 1 write) is flat within ~2 % from 2 to 16 workgroups per CU, best at 16; the fused backward
+// (2 reads : 1 write) is best with a SMALL persistent grid, 2 workgroups per CU -- the same optimum a
+// no-arithmetic 2R:1W probe kernel shows, i.e. an HBM access-pattern effect, not a compute one.
+constexpr int kDefaultFwdVariant = encode_variant(4, true, true, 16);
+constexpr int kDefaultBwdVariant = encode_variant(4, true, true, 2);
+constexpr int kDefaultPcVariant = encode_variant(4, true, true, 8);
 
 inline Variant decode_variant(int code, int dflt) {
     if (code == 0) code = dflt;
     Variant v;
     v.unroll = code & 0xff;
-    v.nt = ((code >> 8) & 1) != 0;
+    v.nt_load = ((code >> 8) & 1) != 0;
+    v.nt_store = ((code >> 9) & 1) != 0;
     v.blocks_per_cu = (code >> 16) & 0xff;
+    v.chunked = ((code >> 10) & 1) != 0;
     if (v.unroll != 1 && v.unroll != 2 && v.unroll != 4 && v.unroll != 8) v.unroll = 4;
     if (v.blocks_per_cu < 1) v.blocks_per_cu = 1;
     if (v.blocks_per_cu > kMaxBlocksPerCU) v.blocks_per_cu = kMaxBlocksPerCU;
     return v;
 }
 
-// LAUNCH(U, NT) is a macro taking the compile-time unroll and non-temporal flag.
+// LAUNCH(U, NTL, NTS) is a macro taking the compile-time unroll and non-temporal flags.
+// Production builds compile ONE code path per kernel (the tuned default); -DLSQ_TUNING compiles the
+// whole table for the kernels that pass FULL = true (fp32 per-tensor), for tools/tune_stream.py.
+#define LSQ_VARIANT_DEFAULT(LAUNCH) LAUNCH(4, true, true)
 #ifdef LSQ_TUNING
-#define LSQ_DISPATCH_VARIANT(v, LAUNCH)                                   \
-    do {                                                                  \
-        if ((v).nt) {                                                     \
-            switch ((v).unroll) {                                         \
-                case 1: LAUNCH(1, true); break;                           \
-                case 2: LAUNCH(2, true); break;                           \
-                case 8: LAUNCH(8, true); break;                           \
-                default: LAUNCH(4, true); break;                          \
-            }                                                             \
-        } else {                                                          \
-            switch ((v).unroll) {                                         \
-                case 1: LAUNCH(1, false); break;                          \
-                case 2: LAUNCH(2, false); break;                          \
-                case 8: LAUNCH(8, false); break;                          \
-                default: LAUNCH(4, false); break;                         \
-            }                                                             \
-        }                                                                 \
+#define LSQ_VARIANT_ROW(v, LAUNCH, NTL, NTS)                 \
+    switch ((v).unroll) {                                    \
+        case 1: LAUNCH(1, NTL, NTS); break;                  \
+        case 2: LAUNCH(2, NTL, NTS); break;                  \
+        case 8: LAUNCH(8, NTL, NTS); break;                  \
+        default: LAUNCH(4, NTL, NTS); break;                 \
+    }
+#define LSQ_DISPATCH_VARIANT(FULL, v, LAUNCH)                                         \
+    do {                                                                              \
+        if constexpr (FULL) {                                                         \
+            if ((v).nt_load && (v).nt_store) { LSQ_VARIANT_ROW(v, LAUNCH, true, true) }        \
+            else if ((v).nt_load) { LSQ_VARIANT_ROW(v, LAUNCH, true, false) }          \
+            else if ((v).nt_store) { LSQ_VARIANT_ROW(v, LAUNCH, false, true) }         \
+            else { LSQ_VARIANT_ROW(v, LAUNCH, false, false) }                          \
+        } else {                                                                      \
+            LSQ_VARIANT_DEFAULT(LAUNCH);                                              \
+        }                                                                             \
     } while (0)
 #else
-// production build: one code path per kernel (the tuned one) to keep the code object small
-#define LSQ_DISPATCH_VARIANT(v, LAUNCH) \
-    do {                                \
-        (void)(v);                      \
-        LAUNCH(4, true);                \
+#define LSQ_DISPATCH_VARIANT(FULL, v, LAUNCH) \
+    do {                                      \
+        (void)(v);                            \
+        LSQ_VARIANT_DEFAULT(LAUNCH);          \
     } while (0)
 #endif
 

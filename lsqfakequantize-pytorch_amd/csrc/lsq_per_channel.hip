@@ -163,7 +163,7 @@ struct LaneChannels {
 // ------------------------------------------------------------------------------------------------
 // K3: forward
 // ------------------------------------------------------------------------------------------------
-template <typename IO, int V, int CPL, bool INIT, bool LEVELS, int UNROLL, bool NT>
+template <typename IO, int V, int CPL, bool INIT, bool LEVELS, int UNROLL, bool NTL, bool NTS>
 __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                         int8_t* __restrict__ levels, int level_bias, PcGeom g,
                                                         const typename IO::arith* __restrict__ scale,
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
         if constexpr (V == 1) {
             in[0] = static_cast<const typename IO::elem*>(x)[e];
         } else {
-            const Packet<IO> pk = NT ? load_packet_nt<IO>(x, e) : load_packet<IO>(x, e);
+            const Packet<IO> pk = NTL ? load_packet_nt<IO>(x, e) : load_packet<IO>(x, e);
 #pragma unroll
             for (int j = 0; j < V; ++j) in[j] = pk.v[j];
         }
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
             Packet<IO> pk;
 #pragma unroll
             for (int j = 0; j < V; ++j) pk.v[j] = out[j];
-            if (NT) store_packet_nt<IO>(y, e, pk); else store_packet<IO>(y, e, pk);
+            if (NTS) store_packet_nt<IO>(y, e, pk); else store_packet<IO>(y, e, pk);
         }
         if (LEVELS) lv.store(levels + e);
     };
@@ -237,31 +237,35 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
 // ------------------------------------------------------------------------------------------------
 // K4: backward
 // ------------------------------------------------------------------------------------------------
-// Segmented wave64 reduction: lanes hold (key, s, b); equal keys form contiguous runs of lanes.
-// After log2(64) shuffle steps the first lane of every run owns the run total and adds it to the
-// window's LDS slot with an LDS fp64 atomic.
+// Segmented wave64 reduction: lanes hold (key, s, b).  A RUN is a maximal group of ADJACENT lanes
+// with the same key (equal keys may re-appear further away -- folded rows, inner < V -- so runs are
+// numbered with a ballot + popcount and the scan is keyed by run id, not by channel).  After
+// log2(64) shuffle steps the first lane of every run owns the run total and adds it to the
+// window's LDS slot with an LDS fp64 atomic (ds_add_f64).
 template <bool SYM>
 __device__ __forceinline__ void segmented_wave_accumulate(int key, double s, double b, double* lds_s, double* lds_b) {
     const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(key, 1, 64);
+    const bool head = (lane == 0) || (prev != key);
+    const unsigned long long heads = __ballot(head);
+    const int run = __popcll(heads & (~0ull >> (63 - lane)));  // heads at or below this lane: unique per run
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const int ok = __shfl_down(key, d, 64);
+        const int orun = __shfl_down(run, d, 64);
         const double os = shfl_down_f64(s, d);
         const double ob = SYM ? 0.0 : shfl_down_f64(b, d);
-        if (lane + d < 64 && ok == key) {
+        if (lane + d < 64 && orun == run) {
             s += os;
             if (!SYM) b += ob;
         }
     }
-    const int prev = __shfl_up(key, 1, 64);
-    const bool head = (lane == 0) || (prev != key);
     if (head && key >= 0) {
         __hip_atomic_fetch_add(&lds_s[key], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (!SYM) __hip_atomic_fetch_add(&lds_b[key], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
-template <typename IO, int V, int CPL, bool SYM, bool INIT, bool EVAL, int UNROLL, bool NT>
+template <typename IO, int V, int CPL, bool SYM, bool INIT, bool EVAL, int UNROLL, bool NTL, bool NTS>
 __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__ grad, const void* __restrict__ x,
                                                         void* __restrict__ dx, PcGeom g,
                                                         const typename IO::arith* __restrict__ scale,
@@ -301,8 +305,8 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
                 gi[0] = static_cast<const typename IO::elem*>(grad)[e];
                 xi[0] = static_cast<const typename IO::elem*>(x)[e];
             } else {
-                const Packet<IO> pg = NT ? load_packet_nt<IO>(grad, e) : load_packet<IO>(grad, e);
-                const Packet<IO> px = NT ? load_packet_nt<IO>(x, e) : load_packet<IO>(x, e);
+                const Packet<IO> pg = NTL ? load_packet_nt<IO>(grad, e) : load_packet<IO>(grad, e);
+                const Packet<IO> px = NTL ? load_packet_nt<IO>(x, e) : load_packet<IO>(x, e);
 #pragma unroll
                 for (int j = 0; j < V; ++j) { gi[j] = pg.v[j]; xi[j] = px.v[j]; }
             }
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
                 Packet<IO> pk;
 #pragma unroll
                 for (int j = 0; j < V; ++j) pk.v[j] = out[j];
-                if (NT) store_packet_nt<IO>(dx, e, pk); else store_packet<IO>(dx, e, pk);
+                if (NTS) store_packet_nt<IO>(dx, e, pk); else store_packet<IO>(dx, e, pk);
             }
         };
 
@@ -440,10 +444,10 @@ static hipError_t launch_fwd_pc(const void* x, void* y, int8_t* levels, int bias
     const Range<T> r = make_range<T>(p);
     const dim3 grid(static_cast<unsigned>(g.n_windows), static_cast<unsigned>(g.splits));
     const size_t lds = static_cast<size_t>(g.k_slots) * sizeof(QSlot<T>);
-#define LSQ_LAUNCH(U, NTF)                                                                                       \
-    hipLaunchKernelGGL((fwd_pc_kernel<IO, V, CPL, INIT, LEVELS, U, NTF>), grid, dim3(kBlock), lds, stream, x, y, levels, \
+#define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                       \
+    hipLaunchKernelGGL((fwd_pc_kernel<IO, V, CPL, INIT, LEVELS, U, NTLF, NTSF>), grid, dim3(kBlock), lds, stream, x, y, levels, \
                        bias, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r)
-    LSQ_DISPATCH_VARIANT(v, LSQ_LAUNCH);
+    LSQ_DISPATCH_VARIANT(false, v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH
     return hipGetLastError();
 }
@@ -488,10 +492,10 @@ static hipError_t launch_bwd_pc(const void* grad, const void* x, void* dx, const
     const Range<T> r = make_range<T>(p);
     const dim3 grid(static_cast<unsigned>(g.n_windows), static_cast<unsigned>(g.splits));
     const size_t lds = static_cast<size_t>(g.k_slots) * (sizeof(QSlot<T>) + 2 * sizeof(double));
-#define LSQ_LAUNCH(U, NTF)                                                                                          \
-    hipLaunchKernelGGL((bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, U, NTF>), grid, dim3(kBlock), lds, stream, grad, x, dx, \
+#define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                          \
+    hipLaunchKernelGGL((bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, U, NTLF, NTSF>), grid, dim3(kBlock), lds, stream, grad, x, dx, \
                        g, static_cast<const T*>(scale), static_cast<const T*>(shift), r, gs, partials)
-    LSQ_DISPATCH_VARIANT(v, LSQ_LAUNCH);
+    LSQ_DISPATCH_VARIANT(false, v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH
     return hipGetLastError();
 }

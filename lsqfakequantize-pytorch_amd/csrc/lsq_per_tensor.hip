@@ -22,15 +22,34 @@
 
 namespace lsq {
 
+// Which full tiles a workgroup visits.  strided: tile t belongs to workgroup t % grid, so at any moment the
+// whole chip works inside one moving window of grid*tile bytes per stream; chunked: each workgroup owns
+// one contiguous run of tiles.
+struct TileWalk {
+    int64_t first, last, step;
+    __device__ __forceinline__ TileWalk(int64_t n_full, bool chunked) {
+        if (chunked) {
+            const int64_t per = (n_full + gridDim.x - 1) / gridDim.x;
+            first = static_cast<int64_t>(blockIdx.x) * per;
+            last = first + per < n_full ? first + per : n_full;
+            step = 1;
+        } else {
+            first = blockIdx.x;
+            last = n_full;
+            step = gridDim.x;
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // K1: forward
 // ------------------------------------------------------------------------------------------------
-template <typename IO, bool INIT, bool LEVELS, int UNROLL, bool NT>
+template <typename IO, bool INIT, bool LEVELS, int UNROLL, bool NTL, bool NTS>
 __global__ __launch_bounds__(kBlock) void fwd_pt_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                         int8_t* __restrict__ levels, int level_bias,
                                                         int64_t n, const typename IO::arith* __restrict__ scale,
                                                         const typename IO::arith* __restrict__ shift,
-                                                        Range<typename IO::arith> r) {
+                                                        Range<typename IO::arith> r, int chunked) {
     using T = typename IO::arith;
     constexpr int VEC = IO::VEC;
     const QParams<T> q = make_qparams<T>(sanitize_scale_per_tensor<T>(scale[0]), shift[0], r);  // lsq_cpu.cpp:44-47
@@ -50,18 +69,19 @@ __global__ __launch_bounds__(kBlock) void fwd_pt_kernel(const void* __restrict__
             out.v[j] = static_cast<typename IO::elem>(INIT ? xv : dequant<T>(l, q));  // lsq_kernel.h:13
             if (LEVELS) lv.b[j] = static_cast<int8_t>(static_cast<int>(l - bias));
         }
-        if (NT) store_packet_nt<IO>(y, p * VEC, out); else store_packet<IO>(y, p * VEC, out);
+        if (NTS) store_packet_nt<IO>(y, p * VEC, out); else store_packet<IO>(y, p * VEC, out);
         if (LEVELS) lv.store(levels + p * VEC);
     };
 
     // full tiles: no predicates, UNROLL independent 16-byte loads per lane in flight
-    for (int64_t tile = blockIdx.x; tile < n_full; tile += gridDim.x) {
+    const TileWalk walk(n_full, chunked != 0);
+    for (int64_t tile = walk.first; tile < walk.last; tile += walk.step) {
         const int64_t p0 = tile * kTile + threadIdx.x;
         Packet<IO> in[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int64_t p = p0 + static_cast<int64_t>(u) * kBlock;
-            in[u] = NT ? load_packet_nt<IO>(x, p * VEC) : load_packet<IO>(x, p * VEC);
+            in[u] = NTL ? load_packet_nt<IO>(x, p * VEC) : load_packet<IO>(x, p * VEC);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) emit(in[u], p0 + static_cast<int64_t>(u) * kBlock);
@@ -139,13 +159,13 @@ __device__ __forceinline__ void block_reduce_store(double s, double b, double2* 
     }
 }
 
-template <typename IO, bool SYM, bool INIT, bool EVAL, int UNROLL, bool NT>
+template <typename IO, bool SYM, bool INIT, bool EVAL, int UNROLL, bool NTL, bool NTS>
 __global__ __launch_bounds__(kBlock) void bwd_pt_kernel(const void* __restrict__ grad, const void* __restrict__ x,
                                                         void* __restrict__ dx, int64_t n,
                                                         const typename IO::arith* __restrict__ scale,
                                                         const typename IO::arith* __restrict__ shift,
                                                         Range<typename IO::arith> r, typename IO::arith grad_scaler,
-                                                        double2* __restrict__ partials) {
+                                                        double2* __restrict__ partials, int chunked) {
     using T = typename IO::arith;
     constexpr int VEC = IO::VEC;
     const QParams<T> q = make_qparams<T>(sanitize_scale_per_tensor<T>(scale[0]), shift[0], r);  // lsq_cpu.cpp:99-102
@@ -161,18 +181,19 @@ __global__ __launch_bounds__(kBlock) void bwd_pt_kernel(const void* __restrict__
         for (int j = 0; j < VEC; ++j)
             out.v[j] = static_cast<typename IO::elem>(
                 acc.step(static_cast<T>(gi.v[j]), static_cast<T>(xi.v[j]), q, r, grad_scaler));
-        if (NT) store_packet_nt<IO>(dx, p * VEC, out); else store_packet<IO>(dx, p * VEC, out);
+        if (NTS) store_packet_nt<IO>(dx, p * VEC, out); else store_packet<IO>(dx, p * VEC, out);
     };
 
     // full tiles: no predicates, 2*UNROLL independent 16-byte loads per lane in flight
-    for (int64_t tile = blockIdx.x; tile < n_full; tile += gridDim.x) {
+    const TileWalk walk(n_full, chunked != 0);
+    for (int64_t tile = walk.first; tile < walk.last; tile += walk.step) {
         const int64_t p0 = tile * kTile + threadIdx.x;
         Packet<IO> gi[UNROLL], xi[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int64_t p = p0 + static_cast<int64_t>(u) * kBlock;
-            gi[u] = NT ? load_packet_nt<IO>(grad, p * VEC) : load_packet<IO>(grad, p * VEC);
-            xi[u] = NT ? load_packet_nt<IO>(x, p * VEC) : load_packet<IO>(x, p * VEC);
+            gi[u] = NTL ? load_packet_nt<IO>(grad, p * VEC) : load_packet<IO>(grad, p * VEC);
+            xi[u] = NTL ? load_packet_nt<IO>(x, p * VEC) : load_packet<IO>(x, p * VEC);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) emit(gi[u], xi[u], p0 + static_cast<int64_t>(u) * kBlock);
@@ -272,10 +293,11 @@ static hipError_t launch_fwd_pt(const void* x, void* y, int8_t* levels, int leve
     const int64_t n_tiles = std::max<int64_t>(1, (n_packets + tile - 1) / tile);
     const int grid = static_cast<int>(std::min<int64_t>(n_tiles, static_cast<int64_t>(dev.cu_count) * v.blocks_per_cu));
     // (the partial tile is owned by workgroup n_full % grid, which exists because grid <= n_tiles)
-#define LSQ_LAUNCH_FWD(U, NTF)                                                                                   \
-    hipLaunchKernelGGL((fwd_pt_kernel<IO, INIT, LEVELS, U, NTF>), dim3(grid), dim3(kBlock), 0, stream, x, y, levels, \
-                       level_bias, n, sc, sh, r)
-    LSQ_DISPATCH_VARIANT(v, LSQ_LAUNCH_FWD);
+#define LSQ_LAUNCH_FWD(U, NTLF, NTSF)                                                                                   \
+    hipLaunchKernelGGL((fwd_pt_kernel<IO, INIT, LEVELS, U, NTLF, NTSF>), dim3(grid), dim3(kBlock), 0, stream, x, y, levels, \
+                       level_bias, n, sc, sh, r, v.chunked ? 1 : 0)
+    constexpr bool kFull = std::is_same<IO, io_f32>::value && !INIT && !LEVELS;
+    LSQ_DISPATCH_VARIANT(kFull, v, LSQ_LAUNCH_FWD);
 #undef LSQ_LAUNCH_FWD
     return hipGetLastError();
 }
@@ -328,10 +350,11 @@ static hipError_t launch_bwd_pt(const void* grad, const void* x, void* dx, void*
         hipLaunchKernelGGL((bwd_pt_scalar_kernel<IO, SYM, INIT, EVAL>), dim3(grid), dim3(kBlock), 0, stream, grad, x,
                            dx, n, sc, sh, r, gs, partials);
     } else {
-#define LSQ_LAUNCH_BWD(U, NTF)                                                                                    \
-    hipLaunchKernelGGL((bwd_pt_kernel<IO, SYM, INIT, EVAL, U, NTF>), dim3(grid), dim3(kBlock), 0, stream, grad, x, dx, \
-                       n, sc, sh, r, gs, partials)
-        LSQ_DISPATCH_VARIANT(v, LSQ_LAUNCH_BWD);
+#define LSQ_LAUNCH_BWD(U, NTLF, NTSF)                                                                                    \
+    hipLaunchKernelGGL((bwd_pt_kernel<IO, SYM, INIT, EVAL, U, NTLF, NTSF>), dim3(grid), dim3(kBlock), 0, stream, grad, x, dx, \
+                       n, sc, sh, r, gs, partials, v.chunked ? 1 : 0)
+        constexpr bool kFull = std::is_same<IO, io_f32>::value && !SYM && !INIT && !EVAL;
+        LSQ_DISPATCH_VARIANT(kFull, v, LSQ_LAUNCH_BWD);
 #undef LSQ_LAUNCH_BWD
     }
     hipError_t e = hipGetLastError();

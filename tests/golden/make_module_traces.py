@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Capture behaviour traces of the REFERENCE's LSQFakeQuantizer module (build container only).
+
+    python oracle/build_ref.py && python tests/golden/make_module_traces.py
+
+The reference's Python sources are imported IN PLACE from /root/reference (nothing is copied): a
+package object named `torchlsq` is created with __path__ pointing at the reference's directory, its
+`extension` submodule is replaced by a stub that loads the reference op library built by
+oracle/build_ref.py, and `torchlsq.functional` / `torchlsq.quantized.modules.observers` are then the
+reference's own files.  For every scenario below the module is driven through a sequence of calls
+(with backward) and the observable state after each call is written to
+tests/golden/module_traces.json -- data only.  tests/test_host_logic.py replays the same scenarios
+on this repository's module.
+"""
+import hashlib
+import importlib
+import importlib.util
+import json
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+warnings.filterwarnings("ignore")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF_PKG = "/root/reference/torchlsq"
+
+
+def load_synth():
+    p = os.path.join(ROOT, "lsqfakequantize-pytorch_amd", "torchlsq", "synth.py")
+    spec = importlib.util.spec_from_file_location("_synth_by_path", p)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+S = load_synth()
+
+SCENARIOS = [
+    dict(name="act_observer_pt", observer="MovingAverageMinMaxObserver", ctor=dict(otype="activation", init_batches=2),
+         shape=[4, 8, 6, 6], x_mean=0.8, x_std=1.0, calls=6),
+    dict(name="act_learnable_pt", observer=None, ctor=dict(otype="activation", init_batches=2, init_mode="learnable",
+                                                            init_scale=0.05, init_shift=0.1),
+         shape=[4, 8, 6, 6], x_mean=0.8, x_std=1.0, calls=6),
+    dict(name="act_observer_pc", observer="MovingAveragePerChannelMinMaxObserver",
+         ctor=dict(otype="activation", init_batches=1, qscheme="per_channel_affine", ch_axis=1),
+         shape=[4, 8, 6, 6], x_mean=0.5, x_std=1.0, calls=5),
+    dict(name="act_fakequant_only", observer="MovingAverageMinMaxObserver",
+         ctor=dict(otype="activation", init_batches=2, learn_params=False),
+         shape=[4, 8, 6, 6], x_mean=0.8, x_std=1.0, calls=4),
+    dict(name="act_8bit_custom_range", observer="MovingAverageMinMaxObserver",
+         ctor=dict(otype="activation", init_batches=0, quant_min=0, quant_max=15, avoid_torch_overflow=False),
+         shape=[3, 5, 7], x_mean=0.8, x_std=1.0, calls=4),
+    dict(name="act_symmetric_pt", observer="MovingAverageMinMaxObserver",
+         ctor=dict(otype="activation", init_batches=1, qscheme="per_tensor_symmetric", avoid_torch_overflow=False),
+         shape=[4, 8, 6, 6], x_mean=0.8, x_std=1.0, calls=4),
+    dict(name="weight_pc_sym", observer="MovingAveragePerChannelMinMaxObserver",
+         ctor=dict(otype="weight", dtype="qint8", qscheme="per_channel_symmetric"),
+         shape=[16, 8, 3, 3], x_mean=0.0, x_std=0.05, calls=4),
+    dict(name="weight_pt_sym_8bit", observer="MovingAverageMinMaxObserver",
+         ctor=dict(otype="weight", dtype="qint8", qscheme="per_tensor_symmetric", avoid_torch_overflow=False),
+         shape=[16, 8, 3, 3], x_mean=0.01, x_std=0.05, calls=3),
+    dict(name="weight_learn_off", observer="MovingAveragePerChannelMinMaxObserver",
+         ctor=dict(otype="weight", dtype="qint8", qscheme="per_channel_symmetric", learn_params=False, ch_axis=0),
+         shape=[16, 8, 3, 3], x_mean=0.0, x_std=0.05, calls=3),
+    dict(name="act_eval_midway", observer="MovingAverageMinMaxObserver", ctor=dict(otype="activation", init_batches=3),
+         shape=[4, 8, 6, 6], x_mean=0.8, x_std=1.0, calls=6, eval_from=2),
+    dict(name="act_toggle_learning", observer="MovingAverageMinMaxObserver", ctor=dict(otype="activation", init_batches=5),
+         shape=[4, 8, 6, 6], x_mean=0.8, x_std=1.0, calls=6, actions={"2": "enable_param_learning", "4": "enable_static_estimate"}),
+    dict(name="act_disable_fake_quant", observer="MovingAverageMinMaxObserver", ctor=dict(otype="activation", init_batches=1),
+         shape=[4, 8, 6, 6], x_mean=0.8, x_std=1.0, calls=4, actions={"2": "disable_fake_quant", "3": "enable_fake_quant"}),
+    dict(name="act_debug_mode", observer="MovingAverageMinMaxObserver", ctor=dict(otype="activation", debug_mode=True),
+         shape=[2, 3], x_mean=0.0, x_std=1.0, calls=2),
+]
+
+
+def build_kwargs(ctor):
+    kw = dict(ctor)
+    if "dtype" in kw:
+        kw["dtype"] = getattr(torch, kw["dtype"])
+    if "qscheme" in kw:
+        kw["qscheme"] = getattr(torch, kw["qscheme"])
+    return kw
+
+
+def sha(t):
+    return hashlib.sha256(np.ascontiguousarray(t.detach().numpy()).tobytes()).hexdigest()
+
+
+def tolist(t):
+    return None if t is None else [float(v) for v in t.detach().reshape(-1).tolist()]
+
+
+def drive(module_cls, sc):
+    """Run one scenario on `module_cls`; shared by the generator (reference class) and the test."""
+    from torch.ao.quantization import observer as obs_mod
+    observer = getattr(obs_mod, sc["observer"]) if sc["observer"] else None
+    m = module_cls(observer, **build_kwargs(sc["ctor"]))
+    m.train()
+    n = int(np.prod(sc["shape"]))
+    out = []
+    for i in range(sc["calls"]):
+        act = sc.get("actions", {}).get(str(i))
+        if act:
+            getattr(m, act)()
+        if sc.get("eval_from") is not None and i >= sc["eval_from"]:
+            m.eval()
+        x = S.normal_like(n, 100 + i, sc["x_mean"], sc["x_std"]).view(sc["shape"]).requires_grad_(True)
+        w = S.normal_like(n, 200 + i, 0.0, 1.0).view(sc["shape"])
+        y = m(x)
+        rec = dict(call=i, y_is_x=bool(y is x), y_sha=sha(y), y_head=tolist(y.reshape(-1)[:6]))
+        if y.requires_grad:
+            for prm in (m.scale, m.shift):
+                if prm is not None:
+                    prm.grad = None
+            (y * w).sum().backward()
+            rec["dx_sha"] = sha(x.grad) if x.grad is not None else None
+        rec.update(scale=tolist(m.scale), shift=tolist(m.shift),
+                   scale_requires_grad=bool(m.scale.requires_grad) if m.scale is not None else None,
+                   shift_requires_grad=bool(m.shift.requires_grad) if m.shift is not None else None,
+                   scale_grad=tolist(m.scale.grad) if m.scale is not None else None,
+                   shift_grad=tolist(m.shift.grad) if m.shift is not None else None,
+                   current_batch=int(m.current_batch[0]), observer_enabled=int(m.observer_enabled[0]),
+                   fake_quant_enabled=int(m.fake_quant_enabled[0]), learning_enabled=int(m.learning_enabled[0]),
+                   n_batches=int(m.n_batches), initialized=bool(m._initialized))
+        out.append(rec)
+    qp = m.calculate_qparams(verbose=False, need_shift=True)
+    final = dict(qparams=[tolist(torch.as_tensor(v, dtype=torch.float64)) for v in qp],
+                 state_dict_keys=list(m.state_dict().keys()), quant_min=m.quant_min, quant_max=m.quant_max,
+                 ch_axis=m.ch_axis, is_perchannel=bool(m.is_perchannel), is_affine=bool(m.is_affine),
+                 init_shift=float(m.init_shift), repr=m.extra_repr())
+    return out, final
+
+
+def import_reference_module():
+    from oracle import build_ref
+    build_ref.build_all(verbose=False)
+    torch.ops.load_library(build_ref.OPS_SO)
+    pkg = types.ModuleType("torchlsq")
+    pkg.__path__ = [REF_PKG]
+    sys.modules["torchlsq"] = pkg
+    ext = types.ModuleType("torchlsq.extension")
+    ext._HAS_OPS = True
+    ext._assert_has_ops = lambda: None
+    sys.modules["torchlsq.extension"] = ext
+    qpkg = types.ModuleType("torchlsq.quantized")
+    qpkg.__path__ = [os.path.join(REF_PKG, "quantized")]
+    sys.modules["torchlsq.quantized"] = qpkg
+    mpkg = types.ModuleType("torchlsq.quantized.modules")
+    mpkg.__path__ = [os.path.join(REF_PKG, "quantized", "modules")]
+    sys.modules["torchlsq.quantized.modules"] = mpkg
+    return importlib.import_module("torchlsq.quantized.modules.observers")
+
+
+if __name__ == "__main__":
+    ref = import_reference_module()
+    assert ref.__file__.startswith(REF_PKG)
+    traces = {}
+    for sc in SCENARIOS:
+        calls, final = drive(ref.LSQFakeQuantizer, sc)
+        traces[sc["name"]] = dict(scenario=sc, calls=calls, final=final)
+        print("%-24s %d calls  cur=%s obs=%s rg=%s" % (sc["name"], len(calls), [c["current_batch"] for c in calls],
+                                                      [c["observer_enabled"] for c in calls],
+                                                      [c["scale_requires_grad"] for c in calls]))
+    # free-standing helpers
+    extras = dict(
+        convert_shift_to_zp=[[float(s), float(sc), dt, int(ref.LSQFakeQuantizer.convert_shift_to_zp(
+            torch.tensor(float(s)), torch.tensor(float(sc)), getattr(torch, dt)))]
+            for s in (-3.0, -0.26, 0.0, 0.24, 1.5, 40.0) for sc in (0.01, 0.5) for dt in ("quint8", "qint8")],
+        default_ranges=[[ot, dt, bool(lb), list(ref.LSQFakeQuantizer(None, ot, dtype=getattr(torch, dt),
+                         qscheme=torch.per_tensor_symmetric if ot == "weight" else torch.per_tensor_affine,
+                         init_mode="learnable", avoid_torch_overflow=lb).__dict__[k] for k in ("quant_min", "quant_max"))]
+                        for ot, dt in (("weight", "qint8"), ("activation", "quint8")) for lb in (True, False)],
+    )
+    with open(os.path.join(HERE, "module_traces.json"), "w") as f:
+        json.dump(dict(generator="tests/golden/make_module_traces.py", torch=torch.__version__,
+                       reference="DeadAt0m/LSQFakeQuantize-PyTorch torchlsq/quantized/modules/observers.py (imported in place)",
+                       traces=traces, extras=extras), f, indent=1)
+    print("wrote module_traces.json")

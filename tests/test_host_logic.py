@@ -1,0 +1,230 @@
+"""CPU: the host side of the drop-in surface (functional.lsq, the op layer, LSQFakeQuantizer).
+
+The product has no CPU kernels; conftest plugs the CPU ORACLE in under the CPU dispatch key so that
+the product's Python layer runs here exactly as it does over the HIP kernels on the GPU box.
+Expected behaviour comes from traces captured from the reference's own module
+(tests/golden/module_traces.json, made by tests/golden/make_module_traces.py).
+"""
+import importlib.util
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _load_driver():
+    spec = importlib.util.spec_from_file_location("_trace_driver", os.path.join(GOLDEN, "make_module_traces.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.fixture(scope="module")
+def traces():
+    with open(os.path.join(GOLDEN, "module_traces.json")) as f:
+        return json.load(f)
+
+
+def _close(a, b, what):
+    if a is None or b is None:
+        assert a is None and b is None, what
+        return
+    # wiring check on small mixed-sign sums: the reference's fp32 at::sum and the oracle's fp64 sum differ
+    # by cancellation error; the arithmetic bar (1e-6 of sum|terms|) is enforced in test_oracle_pinned.py
+    np.testing.assert_allclose(np.array(a, dtype=np.float64), np.array(b, dtype=np.float64), rtol=1e-4, atol=1e-8,
+                               err_msg=what)
+
+
+def test_module_state_machine_matches_reference_traces(oracle_cpu_backend, traces):
+    from torchlsq.quantized import LSQFakeQuantizer
+    drv = _load_driver()
+    assert len(traces["traces"]) >= 13
+    for name, t in traces["traces"].items():
+        calls, final = drv.drive(LSQFakeQuantizer, t["scenario"])
+        for got, want in zip(calls, t["calls"]):
+            tag = "%s call %d" % (name, want["call"])
+            for k in ("y_is_x", "y_sha", "dx_sha", "scale_requires_grad", "shift_requires_grad", "current_batch",
+                      "observer_enabled", "fake_quant_enabled", "learning_enabled", "n_batches", "initialized"):
+                assert got.get(k) == want.get(k), "%s: %s got %r want %r" % (tag, k, got.get(k), want.get(k))
+            assert got["scale"] == want["scale"] and got["shift"] == want["shift"], tag + " parameters"
+            _close(got["scale_grad"], want["scale_grad"], tag + " scale.grad")
+            _close(got["shift_grad"], want["shift_grad"], tag + " shift.grad")
+        for k in ("state_dict_keys", "quant_min", "quant_max", "ch_axis", "is_perchannel", "is_affine", "init_shift", "qparams"):
+            assert final[k] == t["final"][k], "%s final %s: %r vs %r" % (name, k, final[k], t["final"][k])
+        assert final["repr"] == t["final"]["repr"], name
+
+
+def test_helpers_match_reference(traces):
+    from torchlsq.quantized import LSQFakeQuantizer
+    for shift, scale, dt, want in traces["extras"]["convert_shift_to_zp"]:
+        got = int(LSQFakeQuantizer.convert_shift_to_zp(torch.tensor(shift), torch.tensor(scale), getattr(torch, dt)))
+        assert got == want
+    for ot, dt, lowbit, want in traces["extras"]["default_ranges"]:
+        m = LSQFakeQuantizer(None, ot, dtype=getattr(torch, dt), init_mode="learnable", avoid_torch_overflow=lowbit,
+                             qscheme=torch.per_tensor_symmetric if ot == "weight" else torch.per_tensor_affine)
+        assert [m.quant_min, m.quant_max] == want
+
+
+def test_constructor_assertions():
+    from torch.ao.quantization.observer import MovingAverageMinMaxObserver as Obs
+    from torchlsq.quantized import LSQFakeQuantizer as Q
+    with pytest.raises(AssertionError, match="only following modes available"):
+        Q(Obs, "activation", init_mode="bogus")
+    with pytest.raises(AssertionError, match="awaited Observer class"):
+        Q(Obs(), "activation")
+    with pytest.raises(AssertionError, match="otype must be on of"):
+        Q(Obs, "bias")
+    with pytest.raises(AssertionError, match="only symmetric scheme for weight"):
+        Q(Obs, "weight", dtype=torch.qint8)
+    with pytest.raises(AssertionError, match="requires `qint8` type for weights"):
+        Q(None, "weight", qscheme=torch.per_tensor_symmetric, init_mode="learnable")
+    with pytest.raises(AssertionError, match="requires `quint8` type for activation"):
+        Q(Obs, "activation", dtype=torch.qint8)
+    with pytest.raises(AssertionError, match="must include 0"):
+        Q(Obs, "activation", quant_min=1, quant_max=5)
+    with pytest.raises(AssertionError, match="not exceed the maximum bit range"):
+        Q(Obs, "activation", quant_min=0, quant_max=255)        # 7-bit cap with avoid_torch_overflow
+    assert Q(Obs, "activation", quant_min=0, quant_max=255, avoid_torch_overflow=False).quant_max == 255
+
+
+def test_with_args_factory_and_qconfig(oracle_cpu_backend):
+    """`with_args` raises NameError in the reference (missing `partial` import, observers.py:64); here it
+    builds a picklable factory that QConfig / prepare_qat can instantiate per module."""
+    from torch.ao.quantization import QConfig
+    from torch.ao.quantization.observer import MovingAverageMinMaxObserver, MovingAveragePerChannelMinMaxObserver
+    from torchlsq.quantized import LSQFakeQuantizer
+    act = LSQFakeQuantizer.with_args(observer=MovingAverageMinMaxObserver, otype="activation", init_batches=1)
+    wgt = LSQFakeQuantizer.with_args(observer=MovingAveragePerChannelMinMaxObserver, otype="weight", dtype=torch.qint8,
+                                     qscheme=torch.per_channel_symmetric).with_args(grad_scaler=0.5)
+    a1, a2, w = act(), act(), wgt()
+    assert a1 is not a2 and isinstance(w, LSQFakeQuantizer) and w.grad_scaler == 0.5 and w.ch_axis == 0
+    qc = QConfig(activation=act, weight=wgt)
+    assert isinstance(qc.activation(), LSQFakeQuantizer)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.ReLU())
+    model.qconfig = qc
+    torch.ao.quantization.prepare_qat(model.train(), inplace=True)
+    assert isinstance(model[0].weight_fake_quant, LSQFakeQuantizer)
+    x = torch.randn(2, 3, 8, 8)
+    model(x)                      # creates the parameters (passes through)
+    out = model(x)
+    out.sum().backward()
+    assert model[0].weight_fake_quant.scale.grad is not None and model[0].weight_fake_quant.scale.shape == (8,)
+
+
+def test_state_dict_roundtrip(oracle_cpu_backend):
+    from torch.ao.quantization.observer import MovingAverageMinMaxObserver as Obs
+    from torchlsq.quantized import LSQFakeQuantizer as Q
+    a = Q(Obs, "activation", init_batches=1)
+    x = torch.rand(4, 8) + 0.5
+    for _ in range(3):
+        a(x)
+    sd = a.state_dict()
+    assert list(sd.keys()) == ['scale', 'shift', 'fake_quant_enabled', 'observer_enabled', 'learning_enabled',
+                               'current_batch', 'activation_post_process.eps', 'activation_post_process.min_val',
+                               'activation_post_process.max_val']
+    b = Q(Obs, "activation", init_batches=1)
+    b(x)                                   # parameters exist only after the first call (reference behaviour)
+    b.load_state_dict(sd)
+    assert torch.equal(b.scale, a.scale) and int(b.current_batch[0]) == int(a.current_batch[0])
+    assert torch.equal(a(x), b(x))
+
+
+def test_apply_helpers():
+    import torchlsq.quantized as TQ
+    from torch.ao.quantization import FakeQuantize
+    from torch.ao.quantization.observer import MovingAverageMinMaxObserver as Obs
+    act = TQ.LSQFakeQuantizer(Obs, "activation")
+    wgt = TQ.LSQFakeQuantizer(Obs, "weight", dtype=torch.qint8, qscheme=torch.per_tensor_symmetric)
+    fq = FakeQuantize()
+    net = torch.nn.ModuleList([act, wgt, fq])
+    net.apply(TQ.disable_fake_quant_on_act)
+    assert int(act.fake_quant_enabled[0]) == 0 and int(wgt.fake_quant_enabled[0]) == 1 and int(fq.fake_quant_enabled[0]) == 0
+    net.apply(TQ.enable_fake_quant)
+    assert int(act.fake_quant_enabled[0]) == 1 and int(fq.fake_quant_enabled[0]) == 1
+    wgt.learning_enabled[0] = 0
+    net.apply(TQ.disable_observer_on_weights)
+    assert int(wgt.observer_enabled[0]) == 0 and int(act.observer_enabled[0]) == 1 and int(fq.observer_enabled[0]) == 0
+    net.apply(TQ.enable_observer_on_weights)
+    assert int(wgt.observer_enabled[0]) == 1
+    net.apply(TQ.disable_observer)
+    assert int(act.observer_enabled[0]) == 0
+
+
+def test_functional_and_front_op(oracle_cpu_backend, small_cases):
+    from torchlsq.functional import lsq
+    manifest, arrays = small_cases
+    x = torch.randn(4, 8)
+    s, b = torch.ones(1), torch.zeros(1)
+    with pytest.raises(RuntimeError, match="scale should be a 1-D tensor"):
+        lsq(x, torch.tensor(1.0), b)
+    with pytest.raises(RuntimeError, match="shift should be a 1-D tensor"):
+        lsq(x, s, torch.zeros(1, 1))
+    with pytest.raises(AssertionError, match="must be covered 0"):
+        lsq(x, s, b, quant_min=1, quant_max=5, is_affine=False)
+    with pytest.raises(RuntimeError, match="same floating-point type"):
+        lsq(x, s.double(), b)
+    with pytest.raises(RuntimeError, match="between 0 and number of dimensions"):
+        lsq(x, torch.ones(8), torch.zeros(8), axis=2, is_perchannel=True)
+    with pytest.raises(RuntimeError, match="not consistent with input tensor"):
+        lsq(x, torch.ones(3), torch.zeros(3), is_perchannel=True)
+    # defaults: type range falls back to the quant range (functional.py:92-93)
+    y = lsq(x * 100, s, b)
+    assert float(y.max()) <= 255.0 and float(y.min()) >= 0.0
+    # autograd wiring incl. the size-1 `repeat` path, against the reference goldens
+    for case in manifest["cases"]:
+        if not case["name"].startswith(("pc_repeat", "pt_affine7", "pc_axis0_sym_float32")):
+            continue
+        k, p = case["key"], case["params"]
+        xs = torch.from_numpy(arrays[k + "x"]).requires_grad_(True)
+        sc = torch.from_numpy(arrays[k + "scale"]).requires_grad_(True)
+        sh = torch.from_numpy(arrays[k + "shift"]).requires_grad_(True)
+        y = lsq(xs, sc, sh, p["quant_min"], p["quant_max"], p["type_min"], p["type_max"], p["axis"], p["use_grad_scaling"],
+                p["grad_scaler"], p["is_affine"], p["is_perchannel"], p["eval_mode"], p["init_mode"])
+        y.backward(torch.from_numpy(arrays[k + "g"]))
+        assert y.detach().numpy().tobytes() == arrays[k + "y"].tobytes(), case["name"]
+        assert xs.grad.numpy().tobytes() == arrays[k + "dx"].tobytes(), case["name"]
+        assert sc.grad.shape == sc.shape and sh.grad.shape == sh.shape
+        np.testing.assert_allclose(sc.grad.numpy(), arrays[k + "ds"], rtol=2e-6, atol=1e-6 * float(arrays[k + "abs_ds"].max()))
+        np.testing.assert_allclose(sh.grad.numpy(), arrays[k + "db"], rtol=2e-6, atol=1e-6 * float(arrays[k + "abs_db"].max()) + 1e-30)
+    # double backward is refused like the reference (lsq_autograd.cpp:106)
+    xs = torch.randn(8, requires_grad=True)
+    g = torch.ones(8, requires_grad=True)
+    dx, ds, db = torch.ops.torchlsq.lsq_backward_per_tensor(g, xs, s, b, 0, 127, 0, 255, True, 1.0, False, False, False)
+    with pytest.raises(RuntimeError, match="double backwards on lsq_per_tensor not supported"):
+        dx.sum().backward()
+
+
+def test_layout_helpers():
+    from torchlsq import extension as E
+    x = torch.empty(4, 16, 6, 10)
+    xd, order = E._dense(x)
+    assert xd is x and E._ocl(x, order, 1) == (4, 16, 60) and E._ocl(x, order, 0) == (1, 4, 960)
+    cl = x.contiguous(memory_format=torch.channels_last)
+    xd, order = E._dense(cl)
+    assert xd is cl and E._ocl(cl, order, 1) == (4 * 6 * 10, 16, 1)
+    t = x.permute(1, 0, 2, 3)                     # dense, permuted
+    xd, order = E._dense(t)
+    assert xd is t and E._ocl(t, order, 0) == (4, 16, 60)
+    sl = x[:, ::2]                                # not dense -> contiguous copy
+    xd, order = E._dense(sl)
+    assert xd is not sl and xd.is_contiguous() and E._ocl(xd, order, 1) == (4, 8, 60)
+    one = torch.empty(6, 1, 9)
+    xd, order = E._dense(one)
+    assert E._ocl(one, order, 1) == (1, 1, 54)
+    g = torch.empty(4, 16, 6, 10)
+    assert E._like_layout(g, cl).stride() == cl.stride()
+
+
+def test_picklable_factory():
+    from torch.ao.quantization.observer import MovingAverageMinMaxObserver
+    from torchlsq.quantized import LSQFakeQuantizer
+    f = LSQFakeQuantizer.with_args(observer=MovingAverageMinMaxObserver, otype="activation")
+    m = f()
+    m2 = pickle.loads(pickle.dumps(m))
+    assert isinstance(m2, LSQFakeQuantizer) and m2.quant_max == 127

@@ -108,7 +108,7 @@ def test_baseline_configs_match_reference_digests(dev, config_digests, name):
     assert_reduction_close(scale.grad.cpu().numpy(), d["ds"], d["oracle_abs_ds"], name + " ds")
     sg = shift.grad.cpu().numpy() if shift.grad is not None else np.zeros(len(d["db"]))
     assert_reduction_close(sg, d["db"], d["oracle_abs_db"], name + " db")
-    if name.endswith("absgrad"):  # no cancellation: plain 1e-6 relative to the reference value
+    if name in ("cfg1_absgrad", "cfg2_absgrad"):  # border terms dominate, no cancellation: plain 1e-6 relative
         np.testing.assert_allclose(scale.grad.cpu().numpy().astype(np.float64), np.array(d["ds"]), rtol=TOL, atol=0)
 
 
