@@ -211,6 +211,13 @@ __device__ __forceinline__ double shfl_down_f64(double v, int delta) {
     return __hiloint2double(hi, lo);
 }
 
+__device__ __forceinline__ double shfl_up_f64(double v, int delta) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_up(lo, delta, 64);
+    hi = __shfl_up(hi, delta, 64);
+    return __hiloint2double(hi, lo);
+}
+
 // butterfly sum over the 64 lanes of a wavefront; every lane ends with the total
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -4,27 +4,72 @@
 // TensorIterator-broadcast scale/shift with a division per element (lsq_kernel.h:157-158), three
 // elementwise backward kernels, three N-sized temporaries and two `sum(axes != axis)`.
 //
-// Data view: dense memory as [outer][L], L = C*inner; position p in a row belongs to channel p/inner.
+// Data view: dense memory as [outer][C][inner]; a "row" is the L = C*inner elements of one outer
+// index, position p of a row belongs to channel p / inner.
 //
-// CDNA4 design: "channel-stationary lanes".
-//  * A workgroup owns a WINDOW of positions [w*W, (w+1)*W) of the row (W = 256 lanes x V elements,
-//    V = one 16-byte packet) and walks down a slab of rows o = o0, o0+R, ... .  A lane keeps the same
-//    positions -- hence the same channel(s) -- for its whole life: the per-channel constants
-//    {s, 1/s, zp} live in registers, no per-element index arithmetic or division is left in the
-//    loop, and every wave instruction still moves 1 KiB of contiguous HBM.
-//    Short rows (L < W, e.g. [batch, features] activations) fold R = W/L rows into one tile.
-//  * The window's channel table {s, 1/s, zp} is computed ONCE per workgroup into LDS (one IEEE
-//    division per channel per workgroup instead of one per element) and fanned out to the lanes.
-//  * d_scale / d_shift: fp64 lane accumulators (one per channel the lane touches) ->
-//    segmented wave64 shuffle reduction keyed by channel (lanes of a wave hold runs of equal
-//    channels) -> LDS fp64 atomics on the window's channel slots (ds_add_f64) -> one 16-byte partial
-//    per (workgroup, channel slot) in the workspace -> fixed-order finalize per channel.
-//    No global atomics, no zero-initialised buffers.
+// CDNA4 design: CHANNEL-STATIONARY LANES.  A lane keeps the same channel(s) for its whole life, so
+// the per-channel constants {s, 1/s, zp} sit in registers, no per-element index arithmetic or
+// division is left in the loop (the reference divides per element), and every wave instruction still
+// moves 1 KiB of contiguous HBM.  Two work decompositions, chosen on the host:
+//
+//  * WINDOW mode (many rows: activations, [batch, features], channels-last).  A workgroup owns a
+//    window of W = 256 lanes x V positions of the row and walks down a slab of rows; short rows
+//    (L < W) fold R = W/L rows into one tile.  The window's channel table is computed ONCE per
+//    workgroup into LDS and fanned out to the lanes (1 lane = 1, 2 or V channels, template CPL).
+//    d_scale/d_shift: fp64 lane accumulators -> segmented wave64 shuffle reduction keyed by runs of
+//    equal channel -> LDS fp64 atomics (ds_add_f64) on the window's channel slots -> one partial per
+//    (workgroup, slot) -> fixed-order finalize.
+//  * SEGMENT mode (few rows, long channels: conv/linear weights on axis 0).  A workgroup owns a
+//    segment of ONE channel row (sub-rows of W positions) for a range of outer indices: one channel
+//    per workgroup, its constants computed in registers, reduction = wave64 butterfly + 4 partials
+//    through LDS -> one partial per workgroup -> fixed-order finalize.
+//
+// Loads are never predicated (a predicated version serialised them behind s_waitcnt): the ragged end
+// of a walk re-reads the last valid packet (clamped address, served by L2) and masks its effects.
+// No global atomics, no zero-initialised buffers.
 #include "lsq_kernels.hpp"
 
 namespace lsq {
 
-// Launch geometry, computed on the host and passed by value.
+// =================================================================================================
+// shared pieces
+// =================================================================================================
+template <typename T>
+struct alignas(16) QSlot {  // LDS image of one channel's constants
+    T s, inv_s, zp, pad;
+};
+
+// floor(a / b) for non-negative operands; 32-bit path when the whole row index space fits
+__device__ __forceinline__ int64_t udiv(int64_t a, int64_t b, bool fits32) {
+    return fits32 ? static_cast<int64_t>(static_cast<uint32_t>(a) / static_cast<uint32_t>(b)) : a / b;
+}
+
+template <typename IO, int V, bool NTL>
+__device__ __forceinline__ void load_elems(const void* base, int64_t e, typename IO::elem (&out)[V]) {
+    if constexpr (V == 1) {
+        out[0] = static_cast<const typename IO::elem*>(base)[e];
+    } else {
+        const Packet<IO> pk = NTL ? load_packet_nt<IO>(base, e) : load_packet<IO>(base, e);
+#pragma unroll
+        for (int j = 0; j < V; ++j) out[j] = pk.v[j];
+    }
+}
+
+template <typename IO, int V, bool NTS>
+__device__ __forceinline__ void store_elems(void* base, int64_t e, const typename IO::elem (&in)[V]) {
+    if constexpr (V == 1) {
+        static_cast<typename IO::elem*>(base)[e] = in[0];
+    } else {
+        Packet<IO> pk;
+#pragma unroll
+        for (int j = 0; j < V; ++j) pk.v[j] = in[j];
+        if (NTS) store_packet_nt<IO>(base, e, pk); else store_packet<IO>(base, e, pk);
+    }
+}
+
+// =================================================================================================
+// WINDOW mode
+// =================================================================================================
 struct PcGeom {
     int64_t outer, C, inner, L;
     int64_t wpos;            // positions per window (R == 1) or L (R > 1)
@@ -34,11 +79,13 @@ struct PcGeom {
     int32_t R;               // rows folded into one tile
     int32_t k_slots;         // channel slots per window (LDS table / partial row length)
     int32_t vec;             // elements per lane per row (IO::VEC or 1)
+    int32_t fits32;          // L < 2^31: index divisions in 32 bits
 };
 
 static PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec, int target_blocks) {
     PcGeom g;
     g.outer = outer; g.C = C; g.inner = inner; g.L = C * inner; g.vec = vec;
+    g.fits32 = (g.L + static_cast<int64_t>(kBlock) * vec) < 0x7fffffffLL ? 1 : 0;
     const int64_t W = static_cast<int64_t>(kBlock) * vec;
     if (g.L >= W) {
         g.R = 1;
@@ -61,11 +108,6 @@ static PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec, int ta
     g.splits = static_cast<int32_t>((outer + rows - 1) / rows);
     return g;
 }
-
-template <typename T>
-struct alignas(16) QSlot {  // LDS image of one channel's constants
-    T s, inv_s, zp, pad;
-};
 
 // Build the window's channel table in LDS (lsq_kernel.h:157-158 + :12, once per channel).
 template <typename T>
@@ -95,14 +137,15 @@ struct LaneSite {
 __device__ __forceinline__ LaneSite lane_site(const PcGeom& g, int V) {
     LaneSite s;
     const int64_t idx = static_cast<int64_t>(threadIdx.x) * V;
+    const bool f32 = g.fits32 != 0;
     if (g.R == 1) {
         const int64_t base = static_cast<int64_t>(blockIdx.x) * g.wpos;
         s.p0 = base + idx;
         s.row_in_tile = 0;
         s.live = s.p0 < g.L;
-        s.c_lo = base / g.inner;
+        s.c_lo = udiv(base, g.inner, f32);
     } else {
-        s.row_in_tile = static_cast<int32_t>(idx / g.L);
+        s.row_in_tile = static_cast<int32_t>(udiv(idx, g.L, f32));
         s.p0 = idx - static_cast<int64_t>(s.row_in_tile) * g.L;
         s.live = s.row_in_tile < g.R;
         s.c_lo = 0;
@@ -120,8 +163,9 @@ struct LaneChannels {
     __device__ __forceinline__ void init(const QSlot<T>* table, const LaneSite& s, const PcGeom& g) {
         // dead lanes (past the row end / beyond the tile rows) point at slot 0 and never accumulate.
         // Everything is computed into scalars first so the struct stays in registers.
+        const bool f32 = g.fits32 != 0;
         const int64_t p0 = s.live ? s.p0 : s.c_lo * g.inner;
-        const int64_t c0 = p0 / g.inner;
+        const int64_t c0 = udiv(p0, g.inner, f32);
         int32_t sp = V;
         if (CPL == 2) {
             const int64_t left = (c0 + 1) * g.inner - p0;  // elements of channel c0 from p0 on
@@ -133,17 +177,11 @@ struct LaneChannels {
             int32_t k;
             if (N == 1 || j == 0) k = static_cast<int32_t>(c0 - s.c_lo);
             else if (CPL == 2) k = static_cast<int32_t>(c0 - s.c_lo) + (sp < V ? 1 : 0);
-            else k = s.live ? static_cast<int32_t>((p0 + j) / g.inner - s.c_lo) : 0;
+            else k = s.live ? static_cast<int32_t>(udiv(p0 + j, g.inner, f32) - s.c_lo) : 0;
             key[j] = k;
             const QSlot<T> e = table[k];
             q[j].s = e.s; q[j].inv_s = e.inv_s; q[j].zp = e.zp;
         }
-    }
-    // 0/1/.. = which of the lane's channels component j belongs to (compile-time for CPL != 2)
-    __device__ __forceinline__ int which(int j) const {
-        if (N == 1) return 0;
-        if (CPL == 2) return j >= split ? 1 : 0;
-        return j;
     }
     // constants of component j, by select (never a runtime-indexed register array -> no scratch)
     __device__ __forceinline__ QParams<T> params(int j) const {
@@ -160,8 +198,20 @@ struct LaneChannels {
     }
 };
 
+// The rows a lane walks: o_begin, o_begin + step, ... (n_rows of them)
+struct RowWalk {
+    int64_t o_begin, step, n_rows;
+    __device__ __forceinline__ RowWalk(const PcGeom& g, const LaneSite& site) {
+        o_begin = static_cast<int64_t>(blockIdx.y) * g.rows_per_split + site.row_in_tile;
+        const int64_t o_end = std::min<int64_t>(g.outer, static_cast<int64_t>(blockIdx.y + 1) * g.rows_per_split);
+        step = g.R;
+        n_rows = (site.live && o_begin < o_end) ? (o_end - o_begin + step - 1) / step : 0;
+    }
+    __device__ __forceinline__ int64_t row(int64_t i) const { return o_begin + i * step; }
+};
+
 // ------------------------------------------------------------------------------------------------
-// K3: forward
+// K3 (window mode): forward
 // ------------------------------------------------------------------------------------------------
 template <typename IO, int V, int CPL, bool INIT, bool LEVELS, int UNROLL, bool NTL, bool NTS>
 __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__ x, void* __restrict__ y,
@@ -170,72 +220,70 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
                                                         const typename IO::arith* __restrict__ shift,
                                                         Range<typename IO::arith> r) {
     using T = typename IO::arith;
+    using E = typename IO::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     QSlot<T>* table = reinterpret_cast<QSlot<T>*>(smem);
 
     const LaneSite site = lane_site(g, V);
+    const RowWalk walk(g, site);
+    // the first group of loads does not depend on the channel constants: put it in flight before the
+    // table build (global loads of scale/shift + a division + a barrier) so the two latencies overlap
+    E first[UNROLL][V];
+    const bool first_full = walk.n_rows >= UNROLL;
+    if (first_full) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) load_elems<IO, V, NTL>(x, walk.row(u) * g.L + site.p0, first[u]);
+    }
     build_channel_table<T>(table, g.k_slots, site.c_lo, g.C, scale, shift, r);
     __syncthreads();
     LaneChannels<T, V, CPL> ch;
     ch.init(table, site, g);
-    if (!site.live) return;
     const T bias = static_cast<T>(level_bias);
 
-    const int64_t o_begin = static_cast<int64_t>(blockIdx.y) * g.rows_per_split + site.row_in_tile;
-    const int64_t o_end = std::min<int64_t>(g.outer, static_cast<int64_t>(blockIdx.y + 1) * g.rows_per_split);
-    const int64_t step = g.R;
-
-    auto load_row = [&](int64_t oo, typename IO::elem (&in)[V]) {
+    auto emit_row = [&](int64_t oo, const E (&in)[V], bool valid) {
         const int64_t e = oo * g.L + site.p0;
-        if constexpr (V == 1) {
-            in[0] = static_cast<const typename IO::elem*>(x)[e];
-        } else {
-            const Packet<IO> pk = NTL ? load_packet_nt<IO>(x, e) : load_packet<IO>(x, e);
-#pragma unroll
-            for (int j = 0; j < V; ++j) in[j] = pk.v[j];
-        }
-    };
-    auto emit_row = [&](int64_t oo, const typename IO::elem (&in)[V]) {
-        const int64_t e = oo * g.L + site.p0;
-        typename IO::elem out[V];
+        E out[V];
         LevelPack<V> lv;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             const QParams<T> q = ch.params(j);
             const T xv = static_cast<T>(in[j]);
             const T l = level<T>(xv, q, r);
-            out[j] = static_cast<typename IO::elem>(INIT ? xv : dequant<T>(l, q));
+            out[j] = static_cast<E>(INIT ? xv : dequant<T>(l, q));
             if (LEVELS) lv.b[j] = static_cast<int8_t>(static_cast<int>(l - bias));
         }
-        if constexpr (V == 1) {
-            static_cast<typename IO::elem*>(y)[e] = out[0];
-        } else {
-            Packet<IO> pk;
-#pragma unroll
-            for (int j = 0; j < V; ++j) pk.v[j] = out[j];
-            if (NTS) store_packet_nt<IO>(y, e, pk); else store_packet<IO>(y, e, pk);
+        if (valid) {
+            store_elems<IO, V, NTS>(y, e, out);
+            if (LEVELS) lv.store(levels + e);
         }
-        if (LEVELS) lv.store(levels + e);
     };
 
-    int64_t o = o_begin;
-    // full groups of UNROLL rows: unpredicated, all loads issued before the first use
-    for (; o + step * (UNROLL - 1) < o_end; o += step * UNROLL) {
-        typename IO::elem in[UNROLL][V];
+    int64_t i = 0;
+    if (first_full) {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) load_row(o + u * step, in[u]);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) emit_row(o + u * step, in[u]);
+        for (int u = 0; u < UNROLL; ++u) emit_row(walk.row(u), first[u], true);
+        i = UNROLL;
     }
-    for (; o < o_end; o += step) {
-        typename IO::elem in[V];
-        load_row(o, in);
-        emit_row(o, in);
+    for (; i + UNROLL <= walk.n_rows; i += UNROLL) {   // full groups: every load issued before the first use
+        E in[UNROLL][V];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) load_elems<IO, V, NTL>(x, walk.row(i + u) * g.L + site.p0, in[u]);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) emit_row(walk.row(i + u), in[u], true);
+    }
+    if (i < walk.n_rows) {                             // ragged end: clamped (re-read) addresses, masked effects
+        E in[UNROLL][V];
+        const int64_t last = walk.n_rows - 1;
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+            load_elems<IO, V, NTL>(x, walk.row(i + u < last ? i + u : last) * g.L + site.p0, in[u]);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) emit_row(walk.row(i + u < last ? i + u : last), in[u], i + u <= last);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: backward
+// K4 (window mode): backward
 // ------------------------------------------------------------------------------------------------
 // Segmented wave64 reduction: lanes hold (key, s, b).  A RUN is a maximal group of ADJACENT lanes
 // with the same key (equal keys may re-appear further away -- folded rows, inner < V -- so runs are
@@ -273,6 +321,7 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
                                                         Range<typename IO::arith> r, typename IO::arith grad_scaler,
                                                         double2* __restrict__ partials) {
     using T = typename IO::arith;
+    using E = typename IO::elem;
     using LC = LaneChannels<T, V, CPL>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     QSlot<T>* table = reinterpret_cast<QSlot<T>*>(smem);
@@ -280,6 +329,17 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
     double* lds_b = lds_s + g.k_slots;
 
     const LaneSite site = lane_site(g, V);
+    const RowWalk walk(g, site);
+    E first_g[UNROLL][V], first_x[UNROLL][V];   // first group in flight before the table build (see K3)
+    const bool first_full = walk.n_rows >= UNROLL;
+    if (first_full) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t e = walk.row(u) * g.L + site.p0;
+            load_elems<IO, V, NTL>(grad, e, first_g[u]);
+            load_elems<IO, V, NTL>(x, e, first_x[u]);
+        }
+    }
     build_channel_table<T>(table, g.k_slots, site.c_lo, g.C, scale, shift, r);
     if (!EVAL) {
         for (int k = threadIdx.x; k < g.k_slots; k += kBlock) {
@@ -291,90 +351,102 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
     LC ch;
     ch.init(table, site, g);
 
+    // CPL == 1 / V: one accumulator pair per channel of the lane.  CPL == 2: [0] = ALL components,
+    // [1] = the components of the lane's second channel (first channel = [0] - [1] at the end).
     double acc_s[LC::N], acc_b[LC::N];
 #pragma unroll
     for (int j = 0; j < LC::N; ++j) { acc_s[j] = 0.0; acc_b[j] = 0.0; }
 
-    if (site.live) {
-        const int64_t o_begin = static_cast<int64_t>(blockIdx.y) * g.rows_per_split + site.row_in_tile;
-        const int64_t o_end = std::min<int64_t>(g.outer, static_cast<int64_t>(blockIdx.y + 1) * g.rows_per_split);
-        const int64_t step = g.R;
-        auto load_row = [&](int64_t oo, typename IO::elem (&gi)[V], typename IO::elem (&xi)[V]) {
-            const int64_t e = oo * g.L + site.p0;
-            if constexpr (V == 1) {
-                gi[0] = static_cast<const typename IO::elem*>(grad)[e];
-                xi[0] = static_cast<const typename IO::elem*>(x)[e];
+    auto emit_row = [&](int64_t oo, const E (&gi)[V], const E (&xi)[V], bool valid) {
+        const int64_t e = oo * g.L + site.p0;
+        E out[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const QParams<T> q = ch.params(j);
+            const T gv = static_cast<T>(gi[j]), xv = static_cast<T>(xi[j]);
+            if (EVAL) {
+                out[j] = static_cast<E>(backward_elem_eval<T, INIT>(gv, xv, q, r));
             } else {
-                const Packet<IO> pg = NTL ? load_packet_nt<IO>(grad, e) : load_packet<IO>(grad, e);
-                const Packet<IO> px = NTL ? load_packet_nt<IO>(x, e) : load_packet<IO>(x, e);
-#pragma unroll
-                for (int j = 0; j < V; ++j) { gi[j] = pg.v[j]; xi[j] = px.v[j]; }
-            }
-        };
-        auto emit_row = [&](int64_t oo, const typename IO::elem (&gi)[V], const typename IO::elem (&xi)[V]) {
-            const int64_t e = oo * g.L + site.p0;
-            typename IO::elem out[V];
-#pragma unroll
-            for (int j = 0; j < V; ++j) {
-                const QParams<T> q = ch.params(j);
-                const T gv = static_cast<T>(gi[j]), xv = static_cast<T>(xi[j]);
-                if (EVAL) {
-                    out[j] = static_cast<typename IO::elem>(backward_elem_eval<T, INIT>(gv, xv, q, r));
-                } else {
-                    T ds_t, db_t;
-                    out[j] = static_cast<typename IO::elem>(
-                        backward_elem<T, SYM, INIT>(gv, xv, q, r, grad_scaler, ds_t, db_t));
-                    const double a = static_cast<double>(ds_t), c = static_cast<double>(db_t);
-                    if (LC::N == 1) {
-                        acc_s[0] += a;
-                        if (!SYM) acc_b[0] += c;
-                    } else if (CPL == 2) {
-                        // branch-free routing between the lane's two channels
-                        const bool hi = ch.which(j) != 0;
-                        acc_s[0] += hi ? 0.0 : a;
-                        acc_s[LC::N - 1] += hi ? a : 0.0;
-                        if (!SYM) {
-                            acc_b[0] += hi ? 0.0 : c;
-                            acc_b[LC::N - 1] += hi ? c : 0.0;
-                        }
-                    } else {
-                        acc_s[j < LC::N ? j : 0] += a;
-                        if (!SYM) acc_b[j < LC::N ? j : 0] += c;
+                T ds_t, db_t;
+                out[j] = static_cast<E>(backward_elem<T, SYM, INIT>(gv, xv, q, r, grad_scaler, ds_t, db_t));
+                if (!valid) { ds_t = static_cast<T>(0); db_t = static_cast<T>(0); }
+                const double a = static_cast<double>(ds_t), c = static_cast<double>(db_t);
+                if (LC::N == 1) {
+                    acc_s[0] += a;
+                    if (!SYM) acc_b[0] += c;
+                } else if (CPL == 2) {
+                    const bool hi = j >= ch.split;
+                    acc_s[0] += a;
+                    acc_s[LC::N - 1] += hi ? a : 0.0;
+                    if (!SYM) {
+                        acc_b[0] += c;
+                        acc_b[LC::N - 1] += hi ? c : 0.0;
                     }
+                } else {
+                    acc_s[j < LC::N ? j : 0] += a;
+                    if (!SYM) acc_b[j < LC::N ? j : 0] += c;
                 }
             }
-            if constexpr (V == 1) {
-                static_cast<typename IO::elem*>(dx)[e] = out[0];
-            } else {
-                Packet<IO> pk;
-#pragma unroll
-                for (int j = 0; j < V; ++j) pk.v[j] = out[j];
-                if (NTS) store_packet_nt<IO>(dx, e, pk); else store_packet<IO>(dx, e, pk);
-            }
-        };
+        }
+        if (valid) store_elems<IO, V, NTS>(dx, e, out);
+    };
 
-        int64_t o = o_begin;
-        for (; o + step * (UNROLL - 1) < o_end; o += step * UNROLL) {
-            typename IO::elem gi[UNROLL][V], xi[UNROLL][V];
+    int64_t i = 0;
+    if (first_full) {
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) load_row(o + u * step, gi[u], xi[u]);
+        for (int u = 0; u < UNROLL; ++u) emit_row(walk.row(u), first_g[u], first_x[u], true);
+        i = UNROLL;
+    }
+    for (; i + UNROLL <= walk.n_rows; i += UNROLL) {
+        E gi[UNROLL][V], xi[UNROLL][V];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) emit_row(o + u * step, gi[u], xi[u]);
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t e = walk.row(i + u) * g.L + site.p0;
+            load_elems<IO, V, NTL>(grad, e, gi[u]);
+            load_elems<IO, V, NTL>(x, e, xi[u]);
         }
-        for (; o < o_end; o += step) {
-            typename IO::elem gi[V], xi[V];
-            load_row(o, gi, xi);
-            emit_row(o, gi, xi);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) emit_row(walk.row(i + u), gi[u], xi[u], true);
+    }
+    if (i < walk.n_rows) {
+        E gi[UNROLL][V], xi[UNROLL][V];
+        const int64_t last = walk.n_rows - 1;
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t e = walk.row(i + u < last ? i + u : last) * g.L + site.p0;
+            load_elems<IO, V, NTL>(grad, e, gi[u]);
+            load_elems<IO, V, NTL>(x, e, xi[u]);
         }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) emit_row(walk.row(i + u < last ? i + u : last), gi[u], xi[u], i + u <= last);
     }
     if (EVAL) return;
 
-    // lanes -> window slots.  Dead lanes carry key -1 (never written).
+    if (CPL == 2) {
+        // [0] all, [1] second channel  ->  [0] first channel, [1] second channel.  The second channel of
+        // lane i is the FIRST channel of lane i+1 (their positions are contiguous and inner >= V), so
+        // its sums travel one lane up and join that lane's run: ONE segmented reduction instead of two.
+        // Only the last lane of a wave / of a row has no neighbour and adds its second channel itself.
+        const int lane = threadIdx.x & 63;
+        const bool has_hi = site.live && ch.split < V;
+        acc_s[0] -= acc_s[LC::N - 1];
+        acc_b[0] -= acc_b[LC::N - 1];
+        const int key_hi = has_hi ? ch.key[LC::N - 1] : -1;
+        const int next_key0 = __shfl_down(site.live ? ch.key[0] : -2, 1, 64);
+        const bool handoff = has_hi && lane < 63 && next_key0 == key_hi;
+        const double give_s = handoff ? acc_s[LC::N - 1] : 0.0, give_b = handoff ? acc_b[LC::N - 1] : 0.0;
+        const double got_s = shfl_up_f64(give_s, 1), got_b = shfl_up_f64(give_b, 1);
+        if (lane > 0) { acc_s[0] += got_s; acc_b[0] += got_b; }
+        if (has_hi && !handoff) {
+            __hip_atomic_fetch_add(&lds_s[key_hi], acc_s[LC::N - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!SYM) __hip_atomic_fetch_add(&lds_b[key_hi], acc_b[LC::N - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        segmented_wave_accumulate<SYM>(site.live ? ch.key[0] : -1, acc_s[0], acc_b[0], lds_s, lds_b);
+    } else {
+        // lanes -> window slots.  Dead lanes carry key -1 (never written).
 #pragma unroll
-    for (int j = 0; j < LC::N; ++j) {
-        int key = site.live ? ch.key[j] : -1;
-        if (CPL == 2 && j == 1 && ch.split >= V) key = -1;  // lane touches one channel only
-        segmented_wave_accumulate<SYM>(key, acc_s[j], acc_b[j], lds_s, lds_b);
+        for (int j = 0; j < LC::N; ++j)
+            segmented_wave_accumulate<SYM>(site.live ? ch.key[j] : -1, acc_s[j], acc_b[j], lds_s, lds_b);
     }
     __syncthreads();
     const int64_t block_linear = static_cast<int64_t>(blockIdx.y) * g.n_windows + blockIdx.x;
@@ -382,8 +454,8 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
     for (int k = threadIdx.x; k < g.k_slots; k += kBlock) out[k] = make_double2(lds_s[k], lds_b[k]);
 }
 
-// Finalize: one lane per channel folds, in a fixed order, every (split, window) partial that can
-// hold a piece of that channel (the reference's `ds_buffer.sum(axes != axis)`, lsq_cpu.cpp:287-292).
+// Finalize (window mode): one lane per channel folds, in a fixed order, every (split, window) partial
+// that can hold a piece of that channel (the reference's `ds_buffer.sum(axes != axis)`, lsq_cpu.cpp:287-292).
 template <typename T>
 __global__ __launch_bounds__(kBlock) void finalize_pc_kernel(const double2* __restrict__ partials, PcGeom g,
                                                              int eval_mode, int sym, T sym_term, T* __restrict__ ds,
@@ -415,13 +487,211 @@ __global__ __launch_bounds__(kBlock) void finalize_pc_kernel(const double2* __re
     }
 }
 
-// ------------------------------------------------------------------------------------------------
+// =================================================================================================
+// SEGMENT mode: one channel per workgroup
+// =================================================================================================
+struct SegGeom {
+    int64_t outer, C, inner;
+    int64_t n_sub;        // sub-rows (of W positions) per channel row
+    int64_t sub_per_seg;  // sub-rows one workgroup owns
+    int64_t o_per_split;  // outer indices one workgroup owns
+    int32_t segs;         // workgroups per channel row
+    int32_t osplits;      // workgroups along outer
+};
+
+static SegGeom make_seg_geom(int64_t outer, int64_t C, int64_t inner, int vec, int target_blocks) {
+    SegGeom g;
+    g.outer = outer; g.C = C; g.inner = inner;
+    const int64_t W = static_cast<int64_t>(kBlock) * vec;
+    g.n_sub = (inner + W - 1) / W;
+    const int64_t per_channel = std::max<int64_t>(1, target_blocks / C);       // workgroups we would like per channel
+    const int64_t iters = g.n_sub * outer;                                    // lane iterations per channel
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(per_channel, iters / 4));  // >= 4 packets per lane
+    int64_t segs = std::min<int64_t>(g.n_sub, blocks);
+    g.sub_per_seg = (g.n_sub + segs - 1) / segs;
+    g.segs = static_cast<int32_t>((g.n_sub + g.sub_per_seg - 1) / g.sub_per_seg);
+    int64_t osplits = std::max<int64_t>(1, std::min<int64_t>(outer, blocks / g.segs));
+    g.o_per_split = (outer + osplits - 1) / osplits;
+    g.osplits = static_cast<int32_t>((outer + g.o_per_split - 1) / g.o_per_split);
+    return g;
+}
+
+// The (o, sub-row) pairs a workgroup walks, flattened: it -> (o_begin + it / n_r, r_begin + it % n_r)
+struct SegWalk {
+    int64_t c, o_begin, r_begin, n_r, n_it;
+    __device__ __forceinline__ SegWalk(const SegGeom& g) {
+        c = blockIdx.x / g.segs;
+        const int64_t seg = blockIdx.x - c * g.segs;
+        r_begin = seg * g.sub_per_seg;
+        const int64_t r_end = std::min<int64_t>(g.n_sub, r_begin + g.sub_per_seg);
+        o_begin = static_cast<int64_t>(blockIdx.y) * g.o_per_split;
+        const int64_t o_end = std::min<int64_t>(g.outer, o_begin + g.o_per_split);
+        n_r = r_end - r_begin;
+        n_it = n_r * (o_end - o_begin);
+    }
+};
+
+template <typename IO, int V, bool INIT, bool LEVELS, int UNROLL, bool NTL, bool NTS>
+__global__ __launch_bounds__(kBlock) void fwd_seg_kernel(const void* __restrict__ x, void* __restrict__ y,
+                                                         int8_t* __restrict__ levels, int level_bias, SegGeom g,
+                                                         const typename IO::arith* __restrict__ scale,
+                                                         const typename IO::arith* __restrict__ shift,
+                                                         Range<typename IO::arith> r) {
+    using T = typename IO::arith;
+    using E = typename IO::elem;
+    const SegWalk w(g);
+    const QParams<T> q = make_qparams<T>(sanitize_scale_per_channel<T>(scale[w.c]), shift[w.c], r);
+    const T bias = static_cast<T>(level_bias);
+    const int64_t W = static_cast<int64_t>(kBlock) * V;
+    const int64_t q0 = static_cast<int64_t>(threadIdx.x) * V;
+    const int64_t q_last = (g.inner - V);   // last packet of a channel row (inner % V == 0)
+
+    // iteration it -> element index of the lane's packet (clamped into the row) and its validity
+    auto site = [&](int64_t it, bool& valid) {
+        const int64_t oi = static_cast<int64_t>(static_cast<uint32_t>(it) / static_cast<uint32_t>(w.n_r));
+        const int64_t ri = it - oi * w.n_r;
+        const int64_t pos = (w.r_begin + ri) * W + q0;
+        valid = pos < g.inner;
+        return ((w.o_begin + oi) * g.C + w.c) * g.inner + (valid ? pos : q_last);
+    };
+    auto emit = [&](int64_t e, const E (&in)[V], bool valid) {
+        E out[V];
+        LevelPack<V> lv;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const T xv = static_cast<T>(in[j]);
+            const T l = level<T>(xv, q, r);
+            out[j] = static_cast<E>(INIT ? xv : dequant<T>(l, q));
+            if (LEVELS) lv.b[j] = static_cast<int8_t>(static_cast<int>(l - bias));
+        }
+        if (valid) {
+            store_elems<IO, V, NTS>(y, e, out);
+            if (LEVELS) lv.store(levels + e);
+        }
+    };
+    for (int64_t it = 0; it < w.n_it; it += UNROLL) {
+        E in[UNROLL][V];
+        int64_t e[UNROLL];
+        bool ok[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t k = it + u < w.n_it ? it + u : w.n_it - 1;
+            e[u] = site(k, ok[u]);
+            ok[u] = ok[u] && (it + u < w.n_it);
+            load_elems<IO, V, NTL>(x, e[u], in[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) emit(e[u], in[u], ok[u]);
+    }
+}
+
+template <typename IO, int V, bool SYM, bool INIT, bool EVAL, int UNROLL, bool NTL, bool NTS>
+__global__ __launch_bounds__(kBlock) void bwd_seg_kernel(const void* __restrict__ grad, const void* __restrict__ x,
+                                                         void* __restrict__ dx, SegGeom g,
+                                                         const typename IO::arith* __restrict__ scale,
+                                                         const typename IO::arith* __restrict__ shift,
+                                                         Range<typename IO::arith> r, typename IO::arith grad_scaler,
+                                                         double2* __restrict__ partials) {
+    using T = typename IO::arith;
+    using E = typename IO::elem;
+    __shared__ double2 wave_tot[kBlock / 64];
+    const SegWalk w(g);
+    const QParams<T> q = make_qparams<T>(sanitize_scale_per_channel<T>(scale[w.c]), shift[w.c], r);
+    const int64_t W = static_cast<int64_t>(kBlock) * V;
+    const int64_t q0 = static_cast<int64_t>(threadIdx.x) * V;
+    const int64_t q_last = (g.inner - V);
+    double acc_s = 0.0, acc_b = 0.0;
+
+    auto site = [&](int64_t it, bool& valid) {
+        const int64_t oi = static_cast<int64_t>(static_cast<uint32_t>(it) / static_cast<uint32_t>(w.n_r));
+        const int64_t ri = it - oi * w.n_r;
+        const int64_t pos = (w.r_begin + ri) * W + q0;
+        valid = pos < g.inner;
+        return ((w.o_begin + oi) * g.C + w.c) * g.inner + (valid ? pos : q_last);
+    };
+    auto emit = [&](int64_t e, const E (&gi)[V], const E (&xi)[V], bool valid) {
+        E out[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const T gv = static_cast<T>(gi[j]), xv = static_cast<T>(xi[j]);
+            if (EVAL) {
+                out[j] = static_cast<E>(backward_elem_eval<T, INIT>(gv, xv, q, r));
+            } else {
+                T ds_t, db_t;
+                out[j] = static_cast<E>(backward_elem<T, SYM, INIT>(gv, xv, q, r, grad_scaler, ds_t, db_t));
+                if (!valid) { ds_t = static_cast<T>(0); db_t = static_cast<T>(0); }
+                acc_s += static_cast<double>(ds_t);
+                if (!SYM) acc_b += static_cast<double>(db_t);
+            }
+        }
+        if (valid) store_elems<IO, V, NTS>(dx, e, out);
+    };
+    for (int64_t it = 0; it < w.n_it; it += UNROLL) {
+        E gi[UNROLL][V], xi[UNROLL][V];
+        int64_t e[UNROLL];
+        bool ok[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t k = it + u < w.n_it ? it + u : w.n_it - 1;
+            e[u] = site(k, ok[u]);
+            ok[u] = ok[u] && (it + u < w.n_it);
+            load_elems<IO, V, NTL>(grad, e[u], gi[u]);
+            load_elems<IO, V, NTL>(x, e[u], xi[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) emit(e[u], gi[u], xi[u], ok[u]);
+    }
+    if (EVAL) return;
+    acc_s = wave_sum(acc_s);
+    acc_b = wave_sum(acc_b);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = make_double2(acc_s, acc_b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ts = 0.0, tb = 0.0;
+#pragma unroll
+        for (int k = 0; k < kBlock / 64; ++k) { ts += wave_tot[k].x; tb += wave_tot[k].y; }
+        partials[static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = make_double2(ts, tb);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void finalize_seg_kernel(const double2* __restrict__ partials, SegGeom g,
+                                                              int eval_mode, int sym, T sym_term, T* __restrict__ ds,
+                                                              T* __restrict__ db, double* __restrict__ wide) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (c >= g.C) return;
+    double s = 0.0, b = 0.0;
+    if (!eval_mode) {
+        const int64_t gx = g.C * g.segs;
+        for (int32_t oy = 0; oy < g.osplits; ++oy)
+            for (int32_t sg = 0; sg < g.segs; ++sg) {
+                const double2 v = partials[static_cast<int64_t>(oy) * gx + c * g.segs + sg];
+                s += v.x;
+                b += v.y;
+            }
+        if (sym) b = 0.0 + static_cast<double>(sym_term);
+    }
+    ds[c] = static_cast<T>(s);
+    db[c] = static_cast<T>(b);
+    if (wide) {
+        wide[c] = s;
+        wide[g.C + c] = b;
+    }
+}
+
+// =================================================================================================
 // host-side launchers
-// ------------------------------------------------------------------------------------------------
+// =================================================================================================
 static inline int pick_vec(int io_vec, int64_t L, bool aligned) { return (aligned && (L % io_vec) == 0) ? io_vec : 1; }
 static inline int pick_cpl(int vec, int64_t inner) {
     if (vec == 1 || inner % vec == 0) return 1;
     return inner >= vec ? 2 : vec;
+}
+// few rows + long, packet-aligned channel rows -> one channel per workgroup
+static inline bool pick_segment_mode(int vec, int64_t outer, int64_t C, int64_t inner) {
+    if (vec == 1 || inner % vec != 0) return false;
+    const int64_t W = static_cast<int64_t>(kBlock) * vec;
+    return outer < 8 && inner >= W && C * ((inner + W - 1) / W) <= 0x7fffffffLL;
 }
 
 size_t bwd_pc_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64_t inner) {
@@ -429,14 +699,22 @@ size_t bwd_pc_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64
     size_t need = 0;
     const int vecs[2] = {io_vec, 1};
     for (int vi = 0; vi < 2; ++vi) {
-        for (int bpc = 1; bpc <= kMaxBlocksPerCU; bpc <<= 1) {
+        for (int bpc = 1; bpc <= kMaxBlocksPerCU; ++bpc) {
             const PcGeom g = make_geom(outer, channels, inner, vecs[vi], dev.cu_count * bpc);
             need = std::max(need, static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2));
+            if (pick_segment_mode(vecs[vi], outer, channels, inner)) {
+                const SegGeom sgm = make_seg_geom(outer, channels, inner, vecs[vi], dev.cu_count * bpc);
+                need = std::max(need, static_cast<size_t>(channels) * sgm.segs * sgm.osplits * sizeof(double2));
+            }
         }
     }
     return need + 256;
 }
 
+static inline bool grid_fits(const PcGeom& g) { return g.n_windows <= 0x7fffffffLL && g.splits <= 65535; }
+static inline bool grid_fits(const SegGeom& g) { return g.C * g.segs <= 0x7fffffffLL && g.osplits <= 65535; }
+
+// ---- forward --------------------------------------------------------------------------------------
 template <typename IO, int V, int CPL, bool INIT, bool LEVELS>
 static hipError_t launch_fwd_pc(const void* x, void* y, int8_t* levels, int bias, const PcGeom& g, const void* scale,
                                 const void* shift, const lsq_params& p, const Variant& v, hipStream_t stream) {
@@ -446,6 +724,20 @@ static hipError_t launch_fwd_pc(const void* x, void* y, int8_t* levels, int bias
     const size_t lds = static_cast<size_t>(g.k_slots) * sizeof(QSlot<T>);
 #define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                       \
     hipLaunchKernelGGL((fwd_pc_kernel<IO, V, CPL, INIT, LEVELS, U, NTLF, NTSF>), grid, dim3(kBlock), lds, stream, x, y, levels, \
+                       bias, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r)
+    LSQ_DISPATCH_VARIANT(false, v, LSQ_LAUNCH);
+#undef LSQ_LAUNCH
+    return hipGetLastError();
+}
+
+template <typename IO, bool INIT, bool LEVELS>
+static hipError_t launch_fwd_seg(const void* x, void* y, int8_t* levels, int bias, const SegGeom& g, const void* scale,
+                                 const void* shift, const lsq_params& p, const Variant& v, hipStream_t stream) {
+    using T = typename IO::arith;
+    const Range<T> r = make_range<T>(p);
+    const dim3 grid(static_cast<unsigned>(g.C * g.segs), static_cast<unsigned>(g.osplits));
+#define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                      \
+    hipLaunchKernelGGL((fwd_seg_kernel<IO, IO::VEC, INIT, LEVELS, U, NTLF, NTSF>), grid, dim3(kBlock), 0, stream, x, y, levels, \
                        bias, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r)
     LSQ_DISPATCH_VARIANT(false, v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH
@@ -463,8 +755,6 @@ static hipError_t fwd_pc_modes(const void* x, void* y, int8_t* levels, int bias,
                   : launch_fwd_pc<IO, V, CPL, false, false>(x, y, levels, bias, g, scale, shift, p, v, stream);
 }
 
-static inline bool grid_fits(const PcGeom& g) { return g.n_windows <= 0x7fffffffLL && g.splits <= 65535; }
-
 template <typename IO>
 hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t channels, int64_t inner,
                                const void* scale, const void* shift, const lsq_params& p,
@@ -475,8 +765,19 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
     const DeviceInfo& dev = device_info();
     const bool aligned = is_aligned16(x) && is_aligned16(y) && (!levels || (reinterpret_cast<uintptr_t>(levels) & 7u) == 0);
     const int vec = pick_vec(IO::VEC, channels * inner, aligned);
+    const int target = dev.cu_count * v.blocks_per_cu;
+    if (pick_segment_mode(vec, outer, channels, inner)) {
+        const SegGeom sg = make_seg_geom(outer, channels, inner, vec, target);
+        if (!grid_fits(sg)) return hipErrorInvalidConfiguration;
+        if (p.init_mode) {
+            return levels ? launch_fwd_seg<IO, true, true>(x, y, levels, bias, sg, scale, shift, p, v, stream)
+                          : launch_fwd_seg<IO, true, false>(x, y, levels, bias, sg, scale, shift, p, v, stream);
+        }
+        return levels ? launch_fwd_seg<IO, false, true>(x, y, levels, bias, sg, scale, shift, p, v, stream)
+                      : launch_fwd_seg<IO, false, false>(x, y, levels, bias, sg, scale, shift, p, v, stream);
+    }
     const int cpl = pick_cpl(vec, inner);
-    const PcGeom g = make_geom(outer, channels, inner, vec, dev.cu_count * v.blocks_per_cu);
+    const PcGeom g = make_geom(outer, channels, inner, vec, target);
     if (!grid_fits(g)) return hipErrorInvalidConfiguration;
     if (vec == 1) return fwd_pc_modes<IO, 1, 1>(x, y, levels, bias, g, scale, shift, p, v, stream);
     if (cpl == 1) return fwd_pc_modes<IO, IO::VEC, 1>(x, y, levels, bias, g, scale, shift, p, v, stream);
@@ -484,6 +785,7 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
     return fwd_pc_modes<IO, IO::VEC, IO::VEC>(x, y, levels, bias, g, scale, shift, p, v, stream);
 }
 
+// ---- backward -------------------------------------------------------------------------------------
 template <typename IO, int V, int CPL, bool SYM, bool INIT, bool EVAL>
 static hipError_t launch_bwd_pc(const void* grad, const void* x, void* dx, const PcGeom& g, const void* scale,
                                 const void* shift, const lsq_params& p, typename IO::arith gs, double2* partials,
@@ -500,23 +802,51 @@ static hipError_t launch_bwd_pc(const void* grad, const void* x, void* dx, const
     return hipGetLastError();
 }
 
+template <typename IO, bool SYM, bool INIT, bool EVAL>
+static hipError_t launch_bwd_seg(const void* grad, const void* x, void* dx, const SegGeom& g, const void* scale,
+                                 const void* shift, const lsq_params& p, typename IO::arith gs, double2* partials,
+                                 const Variant& v, hipStream_t stream) {
+    using T = typename IO::arith;
+    const Range<T> r = make_range<T>(p);
+    const dim3 grid(static_cast<unsigned>(g.C * g.segs), static_cast<unsigned>(g.osplits));
+#define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                         \
+    hipLaunchKernelGGL((bwd_seg_kernel<IO, IO::VEC, SYM, INIT, EVAL, U, NTLF, NTSF>), grid, dim3(kBlock), 0, stream, grad, x, dx, \
+                       g, static_cast<const T*>(scale), static_cast<const T*>(shift), r, gs, partials)
+    LSQ_DISPATCH_VARIANT(false, v, LSQ_LAUNCH);
+#undef LSQ_LAUNCH
+    return hipGetLastError();
+}
+
+#define LSQ_MODE_SWITCH(CALL)                                  \
+    do {                                                       \
+        const bool sym = p.sym != 0, init = p.init_mode != 0;  \
+        if (p.eval_mode) {                                     \
+            if (init) return CALL(false, true, true);          \
+            return CALL(false, false, true);                   \
+        }                                                      \
+        if (sym) {                                             \
+            if (init) return CALL(true, true, false);          \
+            return CALL(true, false, false);                   \
+        }                                                      \
+        if (init) return CALL(false, true, false);             \
+        return CALL(false, false, false);                      \
+    } while (0)
+
 template <typename IO, int V, int CPL>
 static hipError_t bwd_pc_modes(const void* grad, const void* x, void* dx, const PcGeom& g, const void* scale,
                                const void* shift, const lsq_params& p, typename IO::arith gs, double2* partials,
                                const Variant& v, hipStream_t stream) {
-#define LSQ_CASE(S, I, E) \
-    return launch_bwd_pc<IO, V, CPL, S, I, E>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream)
-    const bool sym = p.sym != 0, init = p.init_mode != 0;
-    if (p.eval_mode) {
-        if (init) LSQ_CASE(false, true, true);
-        LSQ_CASE(false, false, true);
-    }
-    if (sym) {
-        if (init) LSQ_CASE(true, true, false);
-        LSQ_CASE(true, false, false);
-    }
-    if (init) LSQ_CASE(false, true, false);
-    LSQ_CASE(false, false, false);
+#define LSQ_CASE(S, I, E) launch_bwd_pc<IO, V, CPL, S, I, E>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream)
+    LSQ_MODE_SWITCH(LSQ_CASE);
+#undef LSQ_CASE
+}
+
+template <typename IO>
+static hipError_t bwd_seg_modes(const void* grad, const void* x, void* dx, const SegGeom& g, const void* scale,
+                                const void* shift, const lsq_params& p, typename IO::arith gs, double2* partials,
+                                const Variant& v, hipStream_t stream) {
+#define LSQ_CASE(S, I, E) launch_bwd_seg<IO, S, I, E>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream)
+    LSQ_MODE_SWITCH(LSQ_CASE);
 #undef LSQ_CASE
 }
 
@@ -530,23 +860,37 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
     const DeviceInfo& dev = device_info();
     const bool aligned = is_aligned16(grad) && is_aligned16(x) && is_aligned16(dx);
     const int vec = pick_vec(IO::VEC, channels * inner, aligned);
-    const int cpl = pick_cpl(vec, inner);
-    const PcGeom g = make_geom(outer, channels, inner, vec, dev.cu_count * v.blocks_per_cu);
-    if (!grid_fits(g)) return hipErrorInvalidConfiguration;
-    const size_t need = static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2);
-    if (!p.eval_mode && workspace_bytes < need) return hipErrorInvalidValue;
+    const int target = dev.cu_count * v.blocks_per_cu;
     const int64_t numel = outer * channels * inner;
     const int64_t n4s = p.numel_for_scaler > 0 ? p.numel_for_scaler : numel;
     const T gs = grad_scaler_per_channel<T>(n4s, p.quant_max, channels, p.use_grad_scaling != 0, p.grad_scaler);
+    const T sym_term = static_cast<T>(0) * gs;
     double2* partials = static_cast<double2*>(workspace);
+    const unsigned fgrid = static_cast<unsigned>((channels + kBlock - 1) / kBlock);
+
+    if (pick_segment_mode(vec, outer, channels, inner)) {
+        const SegGeom sg = make_seg_geom(outer, channels, inner, vec, target);
+        if (!grid_fits(sg)) return hipErrorInvalidConfiguration;
+        const size_t need = static_cast<size_t>(channels) * sg.segs * sg.osplits * sizeof(double2);
+        if (!p.eval_mode && workspace_bytes < need) return hipErrorInvalidValue;
+        hipError_t e = bwd_seg_modes<IO>(grad, x, dx, sg, scale, shift, p, gs, partials, v, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((finalize_seg_kernel<T>), dim3(fgrid), dim3(kBlock), 0, stream, partials, sg,
+                           p.eval_mode ? 1 : 0, p.sym ? 1 : 0, sym_term, static_cast<T*>(ds), static_cast<T*>(db), wide);
+        return hipGetLastError();
+    }
+
+    const int cpl = pick_cpl(vec, inner);
+    const PcGeom g = make_geom(outer, channels, inner, vec, target);
+    if (!grid_fits(g)) return hipErrorInvalidConfiguration;
+    const size_t need = static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2);
+    if (!p.eval_mode && workspace_bytes < need) return hipErrorInvalidValue;
     hipError_t e;
     if (vec == 1) e = bwd_pc_modes<IO, 1, 1>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
     else if (cpl == 1) e = bwd_pc_modes<IO, IO::VEC, 1>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
     else if (cpl == 2) e = bwd_pc_modes<IO, IO::VEC, 2>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
     else e = bwd_pc_modes<IO, IO::VEC, IO::VEC>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
     if (e != hipSuccess) return e;
-    const T sym_term = static_cast<T>(0) * gs;
-    const unsigned fgrid = static_cast<unsigned>((channels + kBlock - 1) / kBlock);
     hipLaunchKernelGGL((finalize_pc_kernel<T>), dim3(fgrid), dim3(kBlock), 0, stream, partials, g, p.eval_mode ? 1 : 0,
                        p.sym ? 1 : 0, sym_term, static_cast<T*>(ds), static_cast<T*>(db), wide);
     return hipGetLastError();

@@ -17,7 +17,6 @@ machine without a GPU).
 """
 import ctypes
 import os
-import threading
 
 import torch
 
@@ -215,12 +214,16 @@ def _physical_order(t):
     return dims
 
 
+_ROW_MAJOR = "row-major"   # marker: plain contiguous tensor, physical order == logical order
+
+
 def _dense(t):
     """(tensor, physical order) with the tensor dense in memory (a contiguous copy if it was not)."""
+    if t.is_contiguous():                      # the common case, one C call
+        return t, _ROW_MAJOR
     order = _physical_order(t)
     if order is None:
-        t = t.contiguous()
-        order = _physical_order(t)
+        return t.contiguous(), _ROW_MAJOR
     return t, order
 
 
@@ -235,26 +238,49 @@ def _like_layout(g, x):
 
 def _ocl(x, order, axis):
     """[outer, C, inner] of dense x for channel `axis`, in memory order."""
+    shape = x.shape
+    if order is _ROW_MAJOR:
+        outer = 1
+        for d in shape[:axis]:
+            outer *= d
+        inner = 1
+        for d in shape[axis + 1:]:
+            inner *= d
+        return outer, shape[axis], inner
     if axis not in order:  # a size-1 channel dimension: one channel covering the whole tensor
         return 1, 1, x.numel()
     k = order.index(axis)
     outer = 1
     for d in order[:k]:
-        outer *= x.size(d)
+        outer *= shape[d]
     inner = 1
     for d in order[k + 1:]:
-        inner *= x.size(d)
-    return outer, x.size(axis), inner
+        inner *= shape[d]
+    return outer, shape[axis], inner
 
 
 # -------------------------------------------------------------------------------------------------
-# the HIP backend ("CUDA" dispatch key on ROCm)
+# the HIP backend ("CUDA" dispatch key on ROCm).  Host cost per call matters for small layers, so the
+# steady-state path is: a few C-level tensor queries, one cached lsq_params struct, two or three
+# allocator calls, one ctypes call -- no context managers, no per-call struct construction.
 # -------------------------------------------------------------------------------------------------
+_PARAMS_CACHE = {}
+
+
 def _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode, numel_for_scaler=0):
+    """(struct, byref) for the scalar arguments; immutable, cached per distinct argument tuple."""
+    key = (qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode, numel_for_scaler)
+    hit = _PARAMS_CACHE.get(key)
+    if hit is not None:
+        return hit
     for name, v in (("quant_min", qmin), ("quant_max", qmax), ("type_min", tmin), ("type_max", tmax)):
         _check(-2 ** 31 <= int(v) < 2 ** 31, "%s=%d does not fit a 32-bit integer" % (name, v))
-    return LsqParams(int(qmin), int(qmax), int(tmin), int(tmax), int(bool(use_gs)), int(bool(sym)),
-                     int(bool(eval_mode)), int(bool(init_mode)), float(gs), int(numel_for_scaler))
+    p = LsqParams(int(qmin), int(qmax), int(tmin), int(tmax), int(bool(use_gs)), int(bool(sym)),
+                  int(bool(eval_mode)), int(bool(init_mode)), float(gs), int(numel_for_scaler))
+    hit = (p, ctypes.byref(p))
+    if len(_PARAMS_CACHE) < 4096:
+        _PARAMS_CACHE[key] = hit
+    return hit
 
 
 def _status(rc, what):
@@ -262,12 +288,24 @@ def _status(rc, what):
         raise RuntimeError("%s failed (%d): %s" % (what, rc, _LIB.lsq_hip_last_error().decode("utf-8", "replace")))
 
 
-def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
-_ws_lock = threading.Lock()
-_ws_size_pt = {}
+def _stream_of(index):
+    if _raw_stream is not None:
+        return _raw_stream(index)
+    return torch.cuda.current_stream(index).cuda_stream
+
+
+def _on_device(index, fn, *args):
+    """Call the C entry point with `index` as the current HIP device (kernels launch on the current device)."""
+    if torch.cuda.current_device() == index:
+        return fn(*args)
+    with torch.cuda.device(index):
+        return fn(*args)
+
+
+_WS_BYTES_PT = [0]
 
 
 def _workspace(device, nbytes):
@@ -276,32 +314,33 @@ def _workspace(device, nbytes):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
-def _require_gpu(t, what):
-    _check(t.is_cuda, "%s: expected a tensor on the GPU (HIP device) but got device %s" % (what, t.device))
+def _require_gpu(what, *tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError("%s: expected a tensor on the GPU (HIP device) but got device %s" % (what, t.device))
 
 
 def hip_forward_per_tensor(x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode,
                            levels_bias=None, variant=0):
     _assert_has_ops()
     check_forward_dtypes(x, scale, shift)
-    for t in (x, scale, shift):
-        _require_gpu(t, "lsq_forward_per_tensor")
+    _require_gpu("lsq_forward_per_tensor", x, scale, shift)
     xd, _ = _dense(x)
     y = torch.empty_like(xd)
-    lv = None
-    if x.numel() == 0:
+    n = xd.numel()
+    if n == 0:
         return (y, torch.empty(x.shape, dtype=torch.int8, device=x.device)) if levels_bias is not None else y
-    ex = None
+    lv, ex = None, None
     if levels_bias is not None:
         lv = torch.empty_strided(xd.shape, xd.stride(), dtype=torch.int8, device=x.device)
         ex = ctypes.byref(LsqFwdExtras(lv.data_ptr(), int(levels_bias), 0))
-    p = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
+    _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
     scale_c, shift_c = scale.contiguous(), shift.contiguous()
-    with torch.cuda.device(x.device):
-        rc = _LIB.lsq_hip_forward_per_tensor_ex(_DTYPE_CODE[x.dtype], xd.data_ptr(), y.data_ptr(), xd.numel(),
-                                                scale_c.data_ptr(), shift_c.data_ptr(), ctypes.byref(p), ex,
-                                                _stream(x), int(variant))
-    _status(rc, "lsq_hip_forward_per_tensor")
+    idx = x.device.index
+    rc = _on_device(idx, _LIB.lsq_hip_forward_per_tensor_ex, _DTYPE_CODE[x.dtype], xd.data_ptr(), y.data_ptr(), n,
+                    scale_c.data_ptr(), shift_c.data_ptr(), pref, ex, _stream_of(idx), variant)
+    if rc:
+        _status(rc, "lsq_hip_forward_per_tensor")
     return (y, lv) if levels_bias is not None else y
 
 
@@ -313,26 +352,27 @@ def hip_backward_per_tensor(grad, x, scale, shift, qmin, qmax, tmin, tmax, use_g
         if want_wide:
             return x.clone(), torch.zeros(2, dtype=torch.float64, device=x.device)
         return x.clone(), scale.clone(), shift.clone()
-    for t in (grad, x, scale, shift):
-        _require_gpu(t, "lsq_backward_per_tensor")
+    _require_gpu("lsq_backward_per_tensor", grad, x, scale, shift)
     xd, _ = _dense(x)
     gd = _like_layout(grad, xd)
     dx = torch.empty_like(xd)
     pd = _param_dtype(x)
-    ds = torch.empty(1, dtype=pd, device=x.device)
-    db = torch.empty(1, dtype=pd, device=x.device)
-    wide = torch.empty(2, dtype=torch.float64, device=x.device) if want_wide else None
-    p = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode, numel_for_scaler)
+    dev = x.device
+    ds = torch.empty(1, dtype=pd, device=dev)
+    db = torch.empty(1, dtype=pd, device=dev)
+    wide = torch.empty(2, dtype=torch.float64, device=dev) if want_wide else None
+    _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode, numel_for_scaler)
     code = _DTYPE_CODE[x.dtype]
     scale_c, shift_c = scale.contiguous(), shift.contiguous()
-    with torch.cuda.device(x.device):
-        nbytes = _LIB.lsq_hip_backward_per_tensor_workspace(code, xd.numel())
-        ws = _workspace(x.device, nbytes)
-        rc = _LIB.lsq_hip_backward_per_tensor_ex(code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(), ds.data_ptr(),
-                                                 db.data_ptr(), wide.data_ptr() if want_wide else None, xd.numel(),
-                                                 scale_c.data_ptr(), shift_c.data_ptr(), ctypes.byref(p),
-                                                 ws.data_ptr(), ws.numel(), _stream(x), int(variant))
-    _status(rc, "lsq_hip_backward_per_tensor")
+    if not _WS_BYTES_PT[0]:
+        _WS_BYTES_PT[0] = int(_LIB.lsq_hip_backward_per_tensor_workspace(code, xd.numel()))   # a constant
+    ws = _workspace(dev, _WS_BYTES_PT[0])
+    idx = dev.index
+    rc = _on_device(idx, _LIB.lsq_hip_backward_per_tensor_ex, code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(),
+                    ds.data_ptr(), db.data_ptr(), wide.data_ptr() if want_wide else None, xd.numel(),
+                    scale_c.data_ptr(), shift_c.data_ptr(), pref, ws.data_ptr(), ws.numel(), _stream_of(idx), variant)
+    if rc:
+        _status(rc, "lsq_hip_backward_per_tensor")
     if want_wide:
         return dx, wide
     return dx, ds, db
@@ -343,8 +383,7 @@ def hip_forward_per_channel(x, scale, shift, axis, qmin, qmax, tmin, tmax, use_g
     _assert_has_ops()
     check_forward_dtypes(x, scale, shift)
     check_channel_args(x, scale, shift, axis, backward=False)
-    for t in (x, scale, shift):
-        _require_gpu(t, "lsq_forward_per_channel")
+    _require_gpu("lsq_forward_per_channel", x, scale, shift)
     xd, order = _dense(x)
     y = torch.empty_like(xd)
     if x.numel() == 0:
@@ -354,14 +393,21 @@ def hip_forward_per_channel(x, scale, shift, axis, qmin, qmax, tmin, tmax, use_g
     if levels_bias is not None:
         lv = torch.empty_strided(xd.shape, xd.stride(), dtype=torch.int8, device=x.device)
         ex = ctypes.byref(LsqFwdExtras(lv.data_ptr(), int(levels_bias), 0))
-    p = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
+    _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
     scale_c, shift_c = scale.contiguous(), shift.contiguous()
-    with torch.cuda.device(x.device):
-        rc = _LIB.lsq_hip_forward_per_channel_ex(_DTYPE_CODE[x.dtype], xd.data_ptr(), y.data_ptr(), outer, C, inner,
-                                                 scale_c.data_ptr(), shift_c.data_ptr(), ctypes.byref(p), ex,
-                                                 _stream(x), int(variant))
-    _status(rc, "lsq_hip_forward_per_channel")
+    idx = x.device.index
+    rc = _on_device(idx, _LIB.lsq_hip_forward_per_channel_ex, _DTYPE_CODE[x.dtype], xd.data_ptr(), y.data_ptr(), outer,
+                    C, inner, scale_c.data_ptr(), shift_c.data_ptr(), pref, ex, _stream_of(idx), variant)
+    if rc:
+        _status(rc, "lsq_hip_forward_per_channel")
     return (y, lv) if levels_bias is not None else y
+
+
+def _pc_workspace_bytes(idx, code, outer, C, inner):
+    return int(_on_device(idx, _LIB.lsq_hip_backward_per_channel_workspace, code, outer, C, inner))
+
+
+_WS_BYTES_PC = {}
 
 
 def hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode,
@@ -373,27 +419,32 @@ def hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax
         if want_wide:
             return x.clone(), torch.zeros(2, scale.numel(), dtype=torch.float64, device=x.device)
         return x.clone(), scale.clone(), shift.clone()
-    for t in (grad, x, scale, shift):
-        _require_gpu(t, "lsq_backward_per_channel")
+    _require_gpu("lsq_backward_per_channel", grad, x, scale, shift)
     xd, order = _dense(x)
     gd = _like_layout(grad, xd)
     dx = torch.empty_like(xd)
     outer, C, inner = _ocl(xd, order, axis)
     pd = _param_dtype(x)
-    ds = torch.empty(C, dtype=pd, device=x.device)
-    db = torch.empty(C, dtype=pd, device=x.device)
-    wide = torch.empty(2, C, dtype=torch.float64, device=x.device) if want_wide else None
-    p = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode, numel_for_scaler)
+    dev = x.device
+    idx = dev.index
+    ds = torch.empty(C, dtype=pd, device=dev)
+    db = torch.empty(C, dtype=pd, device=dev)
+    wide = torch.empty(2, C, dtype=torch.float64, device=dev) if want_wide else None
+    _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode, numel_for_scaler)
     code = _DTYPE_CODE[x.dtype]
     scale_c, shift_c = scale.contiguous(), shift.contiguous()
-    with torch.cuda.device(x.device):
-        nbytes = _LIB.lsq_hip_backward_per_channel_workspace(code, outer, C, inner)
-        ws = _workspace(x.device, nbytes)
-        rc = _LIB.lsq_hip_backward_per_channel_ex(code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(), ds.data_ptr(),
-                                                  db.data_ptr(), wide.data_ptr() if want_wide else None, outer, C,
-                                                  inner, scale_c.data_ptr(), shift_c.data_ptr(), ctypes.byref(p),
-                                                  ws.data_ptr(), ws.numel(), _stream(x), int(variant))
-    _status(rc, "lsq_hip_backward_per_channel")
+    wkey = (idx, code, outer, C, inner)
+    nbytes = _WS_BYTES_PC.get(wkey)
+    if nbytes is None:
+        nbytes = _pc_workspace_bytes(idx, code, outer, C, inner)
+        if len(_WS_BYTES_PC) < 4096:
+            _WS_BYTES_PC[wkey] = nbytes
+    ws = _workspace(dev, nbytes)
+    rc = _on_device(idx, _LIB.lsq_hip_backward_per_channel_ex, code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(),
+                    ds.data_ptr(), db.data_ptr(), wide.data_ptr() if want_wide else None, outer, C, inner,
+                    scale_c.data_ptr(), shift_c.data_ptr(), pref, ws.data_ptr(), ws.numel(), _stream_of(idx), variant)
+    if rc:
+        _status(rc, "lsq_hip_backward_per_channel")
     if want_wide:
         return dx, wide
     return dx, ds, db

@@ -5,10 +5,48 @@ assertions; the work is done by `torch.ops.torchlsq.lsq` (registered in torchlsq
 of the gfx950 kernels).
 """
 import torch
+from torch.autograd.function import once_differentiable
 
+from . import extension as _E
 from .extension import _assert_has_ops
 
 Tensor = torch.Tensor
+
+
+class _LSQOnDevice(torch.autograd.Function):
+    """Direct autograd binding of the gfx950 kernels for GPU tensors.
+
+    Same computation as `torch.ops.torchlsq.lsq` (the registered ops stay available and are what the
+    dispatcher-level tests exercise); this class only skips the dispatcher round trips -- two Python
+    re-entries per op -- which dominate the cost of small layers.  Mirrors LSQPer*Function of the
+    reference (csrc/ops/autograd/lsq_autograd.cpp:16-74,111-173): saves {input, scale, shift}, backward
+    returns gradients for those three only, double backward is refused.
+    """
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, cfg):
+        (qmin, qmax, tmin, tmax, axis, use_gs, gs, sym, per_channel, eval_mode, init_mode) = cfg
+        if per_channel:
+            y = _E.hip_forward_per_channel(x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode,
+                                           init_mode)
+        else:
+            y = _E.hip_forward_per_tensor(x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
+        ctx.save_for_backward(x, scale, shift)
+        ctx.cfg = cfg
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        x, scale, shift = ctx.saved_tensors
+        (qmin, qmax, tmin, tmax, axis, use_gs, gs, sym, per_channel, eval_mode, init_mode) = ctx.cfg
+        if per_channel:
+            dx, ds, db = _E.hip_backward_per_channel(grad_out, x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs,
+                                                     sym, eval_mode, init_mode)
+        else:
+            dx, ds, db = _E.hip_backward_per_tensor(grad_out, x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym,
+                                                    eval_mode, init_mode)
+        return dx, ds, db, None
 
 
 def lsq(x: Tensor, scale: Tensor, shift: Tensor,
@@ -65,6 +103,22 @@ def lsq(x: Tensor, scale: Tensor, shift: Tensor,
         type_min = quant_min
     if type_max is None:
         type_max = quant_max
+    if x.is_cuda and scale.is_cuda and shift.is_cuda and not torch.jit.is_tracing() \
+            and not torch.compiler.is_compiling():
+        # front-op checks and routing of quantops::ops::lsq (lsq.cpp:104-134), then straight to the kernels
+        if scale.dim() != 1:
+            raise RuntimeError("scale should be a 1-D tensor, even in per tensor case(please, avoid torch.Scalar too)")
+        if shift.dim() != 1:
+            raise RuntimeError("shift should be a 1-D tensor, even in per tensor case(please, avoid torch.Scalar too)")
+        if is_perchannel:
+            size = max(scale.size(0), shift.size(0))
+            if scale.size(0) != size:
+                scale = scale.repeat(size)      # differentiable: a size-1 leaf receives the summed gradient
+            if shift.size(0) != size:
+                shift = shift.repeat(size)
+        cfg = (quant_min, quant_max, type_min, type_max, axis, bool(use_grad_scaling), float(grad_scaler),
+               not is_affine, bool(is_perchannel), bool(eval_mode), bool(init_mode))
+        return _LSQOnDevice.apply(x, scale, shift, cfg)
     return torch.ops.torchlsq.lsq(x, scale, shift, quant_min, quant_max, type_min, type_max,
                                   axis, use_grad_scaling, grad_scaler, is_affine, is_perchannel,
                                   eval_mode, init_mode)

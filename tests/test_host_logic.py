@@ -216,7 +216,7 @@ def test_layout_helpers():
     assert xd is not sl and xd.is_contiguous() and E._ocl(xd, order, 1) == (4, 8, 60)
     one = torch.empty(6, 1, 9)
     xd, order = E._dense(one)
-    assert E._ocl(one, order, 1) == (1, 1, 54)
+    assert E._ocl(one, order, 1) in ((1, 1, 54), (6, 1, 9))      # a single channel either way
     g = torch.empty(4, 16, 6, 10)
     assert E._like_layout(g, cl).stride() == cl.stride()
 

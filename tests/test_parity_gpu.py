@@ -384,3 +384,58 @@ def test_full_size_properties_cfg2(dev):
     _, w_b = ops.lsq_backward_per_tensor_wide(g[h:], x[h:], scale, shift, *p, True, 1.0, False, False, False, n)
     np.testing.assert_allclose((w_a + w_b).cpu().numpy(), w_all.cpu().numpy(), rtol=1e-12, atol=0)
     assert torch.equal(w_all.to(torch.float32)[0], ds[0])
+
+
+def test_dispatcher_path_equals_direct_path(dev, small_cases):
+    """functional.lsq binds the kernels directly for GPU tensors; torch.ops.torchlsq.lsq goes through the
+    dispatcher (front op -> register_autograd -> CUDA-key kernels).  Both must give identical results,
+    including the size-1 `repeat` route of the per-channel front op (lsq.cpp:124-126)."""
+    from torchlsq.functional import lsq
+    manifest, arrays = small_cases
+    picked = [c for c in manifest["cases"] if c["name"].endswith("float32") and
+              c["name"].startswith(("pt_affine7", "pt_sym7", "pt_init", "pc_axis1_affine", "pc_repeat_scale", "pc_repeat_shift", "pc_axis0_sym_"))]
+    assert len(picked) >= 6
+    for case in picked:
+        k, p = case["key"], case["params"]
+        outs = []
+        for route in ("direct", "dispatcher"):
+            x = torch.from_numpy(arrays[k + "x"]).to(dev).requires_grad_(True)
+            s = torch.from_numpy(arrays[k + "scale"]).to(dev).requires_grad_(True)
+            b = torch.from_numpy(arrays[k + "shift"]).to(dev).requires_grad_(True)
+            args = (p["quant_min"], p["quant_max"], p["type_min"], p["type_max"], p["axis"], p["use_grad_scaling"],
+                    p["grad_scaler"], p["is_affine"], p["is_perchannel"], p["eval_mode"], p["init_mode"])
+            y = lsq(x, s, b, *args) if route == "direct" else torch.ops.torchlsq.lsq(x, s, b, *args)
+            y.backward(torch.from_numpy(arrays[k + "g"]).to(dev))
+            outs.append((y.detach(), x.grad, s.grad, b.grad))
+        for a, c in zip(*outs):
+            assert (a is None and c is None) or torch.equal(a, c), case["name"]
+        assert_bits_equal(outs[1][0].cpu().numpy(), arrays[k + "y"], case["name"] + " y (dispatcher)")
+        assert_bits_equal(outs[1][1].cpu().numpy(), arrays[k + "dx"], case["name"] + " dx (dispatcher)")
+    # double backward is refused on both routes
+    x = torch.randn(64, device=dev, requires_grad=True)
+    s, b = torch.ones(1, device=dev, requires_grad=True), torch.zeros(1, device=dev, requires_grad=True)
+    y = lsq(x, s, b, 0, 127, 0, 255)
+    (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+    with pytest.raises(RuntimeError):
+        gx.sum().backward()
+
+
+def test_module_on_gpu_qat_step(dev):
+    """LSQFakeQuantizer over the HIP kernels: one QAT-style step for an activation and a weight quantizer."""
+    from torch.ao.quantization.observer import MovingAverageMinMaxObserver, MovingAveragePerChannelMinMaxObserver
+    from torchlsq.quantized import LSQFakeQuantizer
+    act = LSQFakeQuantizer(MovingAverageMinMaxObserver, "activation", init_batches=1).to(dev)
+    wq = LSQFakeQuantizer(MovingAveragePerChannelMinMaxObserver, "weight", dtype=torch.qint8,
+                          qscheme=torch.per_channel_symmetric).to(dev)
+    w = torch.nn.Parameter(torch.randn(32, 16, 3, 3, device=dev) * 0.05)
+    x = torch.rand(8, 16, 12, 12, device=dev)
+    for step in range(4):
+        out = torch.nn.functional.conv2d(act(x), wq(w), padding=1)
+        out.square().mean().backward()
+    assert act.scale.is_cuda and act.scale.grad is not None and act.shift.grad is not None
+    assert wq.scale.shape == (32,) and wq.scale.grad is not None and wq.shift.grad is None
+    assert torch.isfinite(w.grad).all()
+    assert int(act.current_batch[0]) == 2 and int(act.observer_enabled[0]) == 0
+    # the quantised weight takes at most 2^7 distinct values per channel (7-bit default range)
+    qw = wq(w).detach()
+    assert all(torch.unique(qw[c]).numel() <= 128 for c in range(0, 32, 8))

@@ -19,11 +19,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--configs", default="cfg1,cfg2,cfg3,cfg4s,cfg5,cfg5_bf16,cfg5_axis0")
+    ap.add_argument("--pc-bpc", type=int, default=0, help="override workgroups-per-CU of the per-channel kernels")
+    ap.add_argument("--graph-only", action="store_true")
     a = ap.parse_args()
     import torch
     import torchlsq  # noqa: F401
     from torchlsq import synth
     ops = torch.ops.torchlsq
+    from torchlsq import extension as E
+    pcv = (4 | (1 << 8) | (1 << 9) | (a.pc_bpc << 16)) if a.pc_bpc else 0
     dev = torch.device("cuda:0")
     out = {}
     for name in a.configs.split(","):
@@ -50,17 +54,21 @@ def main():
         def fwd(s):
             x, g, scale, shift = s
             if c["per_channel"]:
+                if pcv:
+                    return E.hip_forward_per_channel(x, scale, shift, c["axis"], *q, True, 1.0, sym, False, False, variant=pcv)
                 return ops.lsq_forward_per_channel(x, scale, shift, c["axis"], *q, True, 1.0, sym, False, False)
             return ops.lsq_forward_per_tensor(x, scale, shift, *q, True, 1.0, sym, False, False)
 
         def bwd(s):
             x, g, scale, shift = s
             if c["per_channel"]:
+                if pcv:
+                    return E.hip_backward_per_channel(g, x, scale, shift, c["axis"], *q, True, 1.0, sym, False, False, variant=pcv)
                 return ops.lsq_backward_per_channel(g, x, scale, shift, c["axis"], *q, True, 1.0, sym, False, False)
             return ops.lsq_backward_per_tensor(g, x, scale, shift, *q, True, 1.0, sym, False, False)
 
         res = {"shape": shape, "n": n, "dtype": str(dt), "ring": ring}
-        for mode in (("hot", "cold") if ring > 1 else ("hot",)):
+        for mode in (() if a.graph_only else (("hot", "cold") if ring > 1 else ("hot",))):
             for kind, fn, nb in (("fwd", fwd, 2 * esz * n), ("bwd", bwd, 3 * esz * n)):
                 for i in range(5):
                     fn(sets[i % ring])
