@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--workload", default="cfg2", help="cfg2 (default, weak-scaled per GPU) | cfg4 (strong: "
                     "[1024,1024,14,14] split over the ranks) | cfg1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)            # "gloo" + --single-device: smoke-test
+    ap.add_argument("--single-device", action="store_true", help=argparse.SUPPRESS)  # the N>1 control flow on a 1-GPU box
     ap.add_argument("--variant-fwd", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--variant-bwd", type=int, default=0, help=argparse.SUPPRESS)
     a = ap.parse_args()
@@ -77,11 +79,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if a.single_device else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" == RCCL on ROCm
+        if a.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" == RCCL on ROCm
+        else:
+            dist.init_process_group(backend=a.backend)
 
     c = synth.CONFIGS[a.workload]
     shape = list(c["shape"])
@@ -102,18 +107,35 @@ def main():
             return ops.lsq_forward_per_tensor(x, scale, shift, *q, True, 1.0, sym, False, False)
         return extension.hip_forward_per_tensor(x, scale, shift, *q, True, 1.0, sym, False, False, variant=a.variant_fwd)
 
+    pending = []   # N > 1: the previous step's in-flight all-reduce (RCCL runs it on its own stream)
+
     def bwd():
         if world == 1:
             if a.variant_bwd == 0:
                 return ops.lsq_backward_per_tensor(g, x, scale, shift, *q, True, 1.0, sym, False, False)
             return extension.hip_backward_per_tensor(g, x, scale, shift, *q, True, 1.0, sym, False, False,
                                                      variant=a.variant_bwd)
-        return sharded_backward(g, x, scale, shift, *q, 1, True, 1.0, c["affine"], False, False, False,
-                                None, n_global)
+        # batch-sharded: local fused backward with the GLOBAL numel in the gradient scaler, then ONE
+        # all-reduce of the packed fp64 [d_scale, d_shift] pair.  The collective is issued async and
+        # consumed one step later (d_scale/d_shift are only needed by the optimizer), so its latency
+        # hides behind the next step's kernels; every reduction is completed inside the timed region.
+        dx, wide, work = sharded_backward(g, x, scale, shift, *q, 1, True, 1.0, c["affine"], False, False, False,
+                                          None, n_global, async_op=True)
+        drain()
+        pending.append((wide, work))
+        return dx
+
+    def drain():
+        while pending:
+            wide, work = pending.pop()
+            work.wait()                                   # stream-level wait, the host does not block
+            ds_db = wide.to(torch.float32)                # the rounding to the parameter type
+        return None
 
     for _ in range(a.warmup):
         y = fwd()
         r = bwd()
+    drain()
     torch.cuda.synchronize()
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
@@ -127,6 +149,7 @@ def main():
         ev[i][1].record()
         r = bwd()
         ev[i][2].record()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -725,7 +725,9 @@ static hipError_t launch_fwd_pc(const void* x, void* y, int8_t* levels, int bias
 #define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                       \
     hipLaunchKernelGGL((fwd_pc_kernel<IO, V, CPL, INIT, LEVELS, U, NTLF, NTSF>), grid, dim3(kBlock), lds, stream, x, y, levels, \
                        bias, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r)
-    LSQ_DISPATCH_VARIANT(false, v, LSQ_LAUNCH);
+    [[maybe_unused]] constexpr bool kFull = !INIT && !LEVELS && V > 1 && CPL <= 2 && !std::is_same<IO, io_f64>::value &&
+                                            !std::is_same<IO, io_f16>::value;
+    LSQ_DISPATCH_VARIANT(kFull, v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH
     return hipGetLastError();
 }
@@ -797,7 +799,9 @@ static hipError_t launch_bwd_pc(const void* grad, const void* x, void* dx, const
 #define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                          \
     hipLaunchKernelGGL((bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, U, NTLF, NTSF>), grid, dim3(kBlock), lds, stream, grad, x, dx, \
                        g, static_cast<const T*>(scale), static_cast<const T*>(shift), r, gs, partials)
-    LSQ_DISPATCH_VARIANT(false, v, LSQ_LAUNCH);
+    [[maybe_unused]] constexpr bool kFull = !SYM && !INIT && !EVAL && V > 1 && CPL <= 2 && !std::is_same<IO, io_f64>::value &&
+                                            !std::is_same<IO, io_f16>::value;
+    LSQ_DISPATCH_VARIANT(kFull, v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH
     return hipGetLastError();
 }

@@ -439,3 +439,52 @@ def test_module_on_gpu_qat_step(dev):
     # the quantised weight takes at most 2^7 distinct values per channel (7-bit default range)
     qw = wq(w).detach()
     assert all(torch.unique(qw[c]).numel() <= 128 for c in range(0, 32, 8))
+
+
+@pytest.mark.slow
+def test_more_than_2_pow_31_elements(dev):
+    """64-bit indexing: a tensor with more than 2^31 elements must equal its two halves processed separately
+    (each half < 2^31), bit-for-bit for y/dx and additively for the un-rounded reductions."""
+    from torchlsq import synth
+    ops = torch.ops.torchlsq
+    half = (1 << 30) + 2048
+    n = 2 * half + 5                       # > 2^31, ragged tail
+    x = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    g = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    chunk = 1 << 27
+    for lo in range(0, n, chunk):          # fill in pieces to keep temporaries small
+        m = min(chunk, n - lo)
+        x[lo:lo + m] = synth.normal_like(m, 900 + lo // chunk, 1.5, 1.0, device=dev, dtype=torch.bfloat16)
+        g[lo:lo + m] = synth.normal_like(m, 950 + lo // chunk, 0.0, 1e-3, device=dev, dtype=torch.bfloat16)
+    s, b = torch.tensor([0.03], device=dev), torch.tensor([0.01], device=dev)
+    p = (0, 127, 0, 255)
+    y = ops.lsq_forward_per_tensor(x, s, b, *p, True, 1.0, False, False, False)
+    dx, wide = ops.lsq_backward_per_tensor_wide(g, x, s, b, *p, True, 1.0, False, False, False, n)
+    parts = [(0, half), (half, n)]
+    acc = torch.zeros(2, dtype=torch.float64, device=dev)
+    for lo, hi in parts:
+        yp = ops.lsq_forward_per_tensor(x[lo:hi], s, b, *p, True, 1.0, False, False, False)
+        dxp, wp = ops.lsq_backward_per_tensor_wide(g[lo:hi], x[lo:hi], s, b, *p, True, 1.0, False, False, False, n)
+        assert torch.equal(y[lo:hi], yp) and torch.equal(dx[lo:hi], dxp), "mismatch in [%d, %d)" % (lo, hi)
+        acc += wp
+        del yp, dxp
+    np.testing.assert_allclose(acc.cpu().numpy(), wide.cpu().numpy(), rtol=1e-12)
+    del y, dx
+    # per-channel, window mode with > 2^31 elements: [outer, 64, 32] split along outer
+    C, inner = 64, 32
+    outer = n // (C * inner)
+    m = outer * C * inner
+    xv, gv = x[:m].view(outer, C, inner), g[:m].view(outer, C, inner)
+    sc = synth.uniform_like(C, 17, 0.02, 0.05, device=dev)
+    sh = synth.normal_like(C, 18, 0.0, 0.01, device=dev)
+    y = ops.lsq_forward_per_channel(xv, sc, sh, 1, *p, True, 1.0, False, False, False)
+    dx, wide = ops.lsq_backward_per_channel_wide(gv, xv, sc, sh, 1, *p, True, 1.0, False, False, False, m)
+    ho = outer // 2
+    acc = torch.zeros(2, C, dtype=torch.float64, device=dev)
+    for lo, hi in ((0, ho), (ho, outer)):
+        yp = ops.lsq_forward_per_channel(xv[lo:hi], sc, sh, 1, *p, True, 1.0, False, False, False)
+        dxp, wp = ops.lsq_backward_per_channel_wide(gv[lo:hi], xv[lo:hi], sc, sh, 1, *p, True, 1.0, False, False, False, m)
+        assert torch.equal(y[lo:hi], yp) and torch.equal(dx[lo:hi], dxp)
+        acc += wp
+        del yp, dxp
+    np.testing.assert_allclose(acc.cpu().numpy(), wide.cpu().numpy(), rtol=1e-11)
