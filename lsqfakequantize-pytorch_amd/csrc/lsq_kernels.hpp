@@ -36,7 +36,14 @@ constexpr int encode_variant(int unroll, bool ntl, bool nts, int bpc) {
 // no-arithmetic 2R:1W probe kernel shows, i.e. an HBM access-pattern effect, not a compute one.
 constexpr int kDefaultFwdVariant = encode_variant(4, true, true, 16);
 constexpr int kDefaultBwdVariant = encode_variant(4, true, true, 2);
-constexpr int kDefaultPcVariant = encode_variant(4, true, true, 8);
+// Per-channel (profiles/r01_pc_variant_sweep.txt, BASELINE config 5): forward best at 16 workgroups/CU;
+// the window-mode backward at 2/CU with SHALLOW unrolling (1 packet pair in flight per lane for 4/8-byte
+// elements, 2 for 16-bit ones): its register footprint, not memory-level parallelism, is what limits it.
+// Segment mode (one channel per workgroup) likes many workgroups in both directions.
+constexpr int kDefaultPcFwdVariant = encode_variant(4, true, true, 16);
+constexpr int kDefaultPcBwdWideVariant = encode_variant(1, true, true, 2);    // fp32 / fp64 storage
+constexpr int kDefaultPcBwdNarrowVariant = encode_variant(2, true, true, 2);  // bf16 / fp16 storage
+constexpr int kDefaultPcSegVariant = encode_variant(4, true, true, 16);
 
 inline Variant decode_variant(int code, int dflt) {
     if (code == 0) code = dflt;
@@ -55,7 +62,7 @@ inline Variant decode_variant(int code, int dflt) {
 // LAUNCH(U, NTL, NTS) is a macro taking the compile-time unroll and non-temporal flags.
 // Production builds compile ONE code path per kernel (the tuned default); -DLSQ_TUNING compiles the
 // whole table for the kernels that pass FULL = true (fp32 per-tensor), for tools/tune_stream.py.
-#define LSQ_VARIANT_DEFAULT(LAUNCH) LAUNCH(4, true, true)
+// DEFU = the compile-time unroll of the kernel's tuned default.
 #ifdef LSQ_TUNING
 #define LSQ_VARIANT_ROW(v, LAUNCH, NTL, NTS)                 \
     switch ((v).unroll) {                                    \
@@ -64,7 +71,7 @@ inline Variant decode_variant(int code, int dflt) {
         case 8: LAUNCH(8, NTL, NTS); break;                  \
         default: LAUNCH(4, NTL, NTS); break;                 \
     }
-#define LSQ_DISPATCH_VARIANT(FULL, v, LAUNCH)                                         \
+#define LSQ_DISPATCH_VARIANT(FULL, DEFU, v, LAUNCH)                                   \
     do {                                                                              \
         if constexpr (FULL) {                                                         \
             if ((v).nt_load && (v).nt_store) { LSQ_VARIANT_ROW(v, LAUNCH, true, true) }        \
@@ -72,14 +79,14 @@ inline Variant decode_variant(int code, int dflt) {
             else if ((v).nt_store) { LSQ_VARIANT_ROW(v, LAUNCH, false, true) }         \
             else { LSQ_VARIANT_ROW(v, LAUNCH, false, false) }                          \
         } else {                                                                      \
-            LSQ_VARIANT_DEFAULT(LAUNCH);                                              \
+            LAUNCH(DEFU, true, true);                                                 \
         }                                                                             \
     } while (0)
 #else
-#define LSQ_DISPATCH_VARIANT(FULL, v, LAUNCH) \
-    do {                                      \
-        (void)(v);                            \
-        LSQ_VARIANT_DEFAULT(LAUNCH);          \
+#define LSQ_DISPATCH_VARIANT(FULL, DEFU, v, LAUNCH) \
+    do {                                            \
+        (void)(v);                                  \
+        LAUNCH(DEFU, true, true);                   \
     } while (0)
 #endif
 

@@ -727,7 +727,7 @@ static hipError_t launch_fwd_pc(const void* x, void* y, int8_t* levels, int bias
                        bias, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r)
     [[maybe_unused]] constexpr bool kFull = !INIT && !LEVELS && V > 1 && CPL <= 2 && !std::is_same<IO, io_f64>::value &&
                                             !std::is_same<IO, io_f16>::value;
-    LSQ_DISPATCH_VARIANT(kFull, v, LSQ_LAUNCH);
+    LSQ_DISPATCH_VARIANT(kFull, 4, v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH
     return hipGetLastError();
 }
@@ -741,7 +741,7 @@ static hipError_t launch_fwd_seg(const void* x, void* y, int8_t* levels, int bia
 #define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                      \
     hipLaunchKernelGGL((fwd_seg_kernel<IO, IO::VEC, INIT, LEVELS, U, NTLF, NTSF>), grid, dim3(kBlock), 0, stream, x, y, levels, \
                        bias, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r)
-    LSQ_DISPATCH_VARIANT(false, v, LSQ_LAUNCH);
+    LSQ_DISPATCH_VARIANT(false, 4, v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH
     return hipGetLastError();
 }
@@ -763,12 +763,13 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
                                const lsq_fwd_extras* ex, int variant, hipStream_t stream) {
     int8_t* levels = ex ? static_cast<int8_t*>(ex->levels) : nullptr;
     const int bias = ex ? ex->level_bias : 0;
-    const Variant v = decode_variant(variant, kDefaultPcVariant);
     const DeviceInfo& dev = device_info();
     const bool aligned = is_aligned16(x) && is_aligned16(y) && (!levels || (reinterpret_cast<uintptr_t>(levels) & 7u) == 0);
     const int vec = pick_vec(IO::VEC, channels * inner, aligned);
+    const bool seg = pick_segment_mode(vec, outer, channels, inner);
+    const Variant v = decode_variant(variant, seg ? kDefaultPcSegVariant : kDefaultPcFwdVariant);
     const int target = dev.cu_count * v.blocks_per_cu;
-    if (pick_segment_mode(vec, outer, channels, inner)) {
+    if (seg) {
         const SegGeom sg = make_seg_geom(outer, channels, inner, vec, target);
         if (!grid_fits(sg)) return hipErrorInvalidConfiguration;
         if (p.init_mode) {
@@ -801,7 +802,8 @@ static hipError_t launch_bwd_pc(const void* grad, const void* x, void* dx, const
                        g, static_cast<const T*>(scale), static_cast<const T*>(shift), r, gs, partials)
     [[maybe_unused]] constexpr bool kFull = !SYM && !INIT && !EVAL && V > 1 && CPL <= 2 && !std::is_same<IO, io_f64>::value &&
                                             !std::is_same<IO, io_f16>::value;
-    LSQ_DISPATCH_VARIANT(kFull, v, LSQ_LAUNCH);
+    constexpr int kDefU = sizeof(typename IO::elem) >= 4 ? 1 : 2;
+    LSQ_DISPATCH_VARIANT(kFull, kDefU, v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH
     return hipGetLastError();
 }
@@ -816,7 +818,7 @@ static hipError_t launch_bwd_seg(const void* grad, const void* x, void* dx, cons
 #define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                         \
     hipLaunchKernelGGL((bwd_seg_kernel<IO, IO::VEC, SYM, INIT, EVAL, U, NTLF, NTSF>), grid, dim3(kBlock), 0, stream, grad, x, dx, \
                        g, static_cast<const T*>(scale), static_cast<const T*>(shift), r, gs, partials)
-    LSQ_DISPATCH_VARIANT(false, v, LSQ_LAUNCH);
+    LSQ_DISPATCH_VARIANT(false, 4, v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH
     return hipGetLastError();
 }
@@ -860,10 +862,13 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
                                 const void* shift, const lsq_params& p, void* workspace, size_t workspace_bytes,
                                 int variant, hipStream_t stream) {
     using T = typename IO::arith;
-    const Variant v = decode_variant(variant, kDefaultPcVariant);
     const DeviceInfo& dev = device_info();
     const bool aligned = is_aligned16(grad) && is_aligned16(x) && is_aligned16(dx);
     const int vec = pick_vec(IO::VEC, channels * inner, aligned);
+    const bool seg = pick_segment_mode(vec, outer, channels, inner);
+    const Variant v = decode_variant(variant, seg ? kDefaultPcSegVariant
+                                                  : (sizeof(typename IO::elem) >= 4 ? kDefaultPcBwdWideVariant
+                                                                                    : kDefaultPcBwdNarrowVariant));
     const int target = dev.cu_count * v.blocks_per_cu;
     const int64_t numel = outer * channels * inner;
     const int64_t n4s = p.numel_for_scaler > 0 ? p.numel_for_scaler : numel;
@@ -872,7 +877,7 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
     double2* partials = static_cast<double2*>(workspace);
     const unsigned fgrid = static_cast<unsigned>((channels + kBlock - 1) / kBlock);
 
-    if (pick_segment_mode(vec, outer, channels, inner)) {
+    if (seg) {
         const SegGeom sg = make_seg_geom(outer, channels, inner, vec, target);
         if (!grid_fits(sg)) return hipErrorInvalidConfiguration;
         const size_t need = static_cast<size_t>(channels) * sg.segs * sg.osplits * sizeof(double2);

@@ -297,7 +297,7 @@ static hipError_t launch_fwd_pt(const void* x, void* y, int8_t* levels, int leve
     hipLaunchKernelGGL((fwd_pt_kernel<IO, INIT, LEVELS, U, NTLF, NTSF>), dim3(grid), dim3(kBlock), 0, stream, x, y, levels, \
                        level_bias, n, sc, sh, r, v.chunked ? 1 : 0)
     [[maybe_unused]] constexpr bool kFull = std::is_same<IO, io_f32>::value && !INIT && !LEVELS;
-    LSQ_DISPATCH_VARIANT(kFull, v, LSQ_LAUNCH_FWD);
+    LSQ_DISPATCH_VARIANT(kFull, 4, v, LSQ_LAUNCH_FWD);
 #undef LSQ_LAUNCH_FWD
     return hipGetLastError();
 }
@@ -354,7 +354,7 @@ static hipError_t launch_bwd_pt(const void* grad, const void* x, void* dx, void*
     hipLaunchKernelGGL((bwd_pt_kernel<IO, SYM, INIT, EVAL, U, NTLF, NTSF>), dim3(grid), dim3(kBlock), 0, stream, grad, x, dx, \
                        n, sc, sh, r, gs, partials, v.chunked ? 1 : 0)
         [[maybe_unused]] constexpr bool kFull = std::is_same<IO, io_f32>::value && !SYM && !INIT && !EVAL;
-        LSQ_DISPATCH_VARIANT(kFull, v, LSQ_LAUNCH_BWD);
+        LSQ_DISPATCH_VARIANT(kFull, 4, v, LSQ_LAUNCH_BWD);
 #undef LSQ_LAUNCH_BWD
     }
     hipError_t e = hipGetLastError();

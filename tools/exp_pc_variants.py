@@ -51,3 +51,4 @@ for dt, code in ((torch.float32, 0), (torch.bfloat16, 2)):
             rows.append((unroll, bpc, round(tf, 2), round(2 * esz * n / tf / 1e3), round(tb, 2), round(3 * esz * n / tb / 1e3)))
     print(str(dt), "best fwd:", sorted(rows, key=lambda r: r[2])[:4])
     print(str(dt), "best bwd:", sorted(rows, key=lambda r: r[4])[:6])
+    print(str(dt), "bwd @bpc 2/3:", [(r[0], r[1], r[4]) for r in rows if r[1] in (2, 3)])
