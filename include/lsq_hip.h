@@ -143,6 +143,22 @@ int lsq_hip_backward_per_channel(int dtype, const void* grad, const void* x, voi
                                  const lsq_params* p, void* workspace, size_t workspace_bytes,
                                  void* stream);
 
+/* ---- observer statistics (init phase) ------------------------------------------------------ */
+
+/* Running min / max of a tensor in ONE read-only pass: what the torch MinMax observers that the
+ * reference module runs before the fake-quantize op during its initialisation batches compute with
+ * torch.aminmax (reference quantized/modules/observers.py:446-449).  Semantics of torch.aminmax: exact
+ * min and max; a NaN anywhere (in the channel) makes both results NaN.
+ * min_out / max_out: 1 element (per-tensor) or `channels` elements, float for F32|BF16|F16 storage,
+ * double for F64.  The workspace size comes from lsq_hip_minmax_workspace (per-tensor: channels = 1,
+ * outer = 1, inner = n). */
+size_t lsq_hip_minmax_workspace(int dtype, int64_t outer, int64_t channels, int64_t inner);
+int lsq_hip_minmax_per_tensor(int dtype, const void* x, int64_t n, void* min_out, void* max_out,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int lsq_hip_minmax_per_channel(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
+                               void* min_out, void* max_out, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

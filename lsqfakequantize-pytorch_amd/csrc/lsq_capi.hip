@@ -189,4 +189,40 @@ int lsq_hip_backward_per_channel(int dtype, const void* grad, const void* x, voi
                                            p, workspace, workspace_bytes, stream, 0);
 }
 
+void lsq_hip_debug_set_observe_wg_per_cu(int v) { lsq::set_observe_wg_per_cu(v); }
+
+size_t lsq_hip_minmax_workspace(int dtype, int64_t outer, int64_t channels, int64_t inner) {
+    if (!dtype_ok(dtype) || outer <= 0 || channels <= 0 || inner <= 0) return 256;
+    return lsq::minmax_workspace_bytes(io_vec(dtype), dtype == LSQ_F64 ? 8 : 4, outer, channels, inner);
+}
+
+int lsq_hip_minmax_per_tensor(int dtype, const void* x, int64_t n, void* min_out, void* max_out, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    if (!dtype_ok(dtype)) return fail(LSQ_EINVAL, "unknown dtype code %d", dtype);
+    if (n <= 0) return fail(LSQ_EINVAL, "minmax_per_tensor: element count must be positive");
+    if (!x || !min_out || !max_out) return fail(LSQ_EINVAL, "minmax_per_tensor: NULL buffer");
+    if (!workspace || workspace_bytes < lsq::minmax_workspace_bytes(io_vec(dtype), dtype == LSQ_F64 ? 8 : 4, 1, 1, 1) - 256 ||
+        (reinterpret_cast<uintptr_t>(workspace) & 15u))
+        return fail(LSQ_EWORKSPACE, "minmax_per_tensor: workspace too small or misaligned (%zu bytes)", workspace_bytes);
+    hipError_t e = hipSuccess;
+    LSQ_DISPATCH_IO(dtype, e = lsq::minmax_per_tensor<IO>(x, n, min_out, max_out, workspace, static_cast<hipStream_t>(stream)));
+    return hip_status(e, "lsq_hip_minmax_per_tensor");
+}
+
+int lsq_hip_minmax_per_channel(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner, void* min_out,
+                               void* max_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dtype_ok(dtype)) return fail(LSQ_EINVAL, "unknown dtype code %d", dtype);
+    if (int rc = check_ocl(outer, channels, inner)) return rc;
+    if (outer == 0 || inner == 0) return fail(LSQ_EINVAL, "minmax_per_channel: empty tensor");
+    if (!x || !min_out || !max_out) return fail(LSQ_EINVAL, "minmax_per_channel: NULL buffer");
+    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15u))
+        return fail(LSQ_EWORKSPACE, "minmax_per_channel: NULL or misaligned workspace");
+    hipError_t e = hipSuccess;
+    LSQ_DISPATCH_IO(dtype, e = lsq::minmax_per_channel<IO>(x, outer, channels, inner, min_out, max_out, workspace,
+                                                            workspace_bytes, static_cast<hipStream_t>(stream)));
+    if (e == hipErrorInvalidValue)
+        return fail(LSQ_EWORKSPACE, "minmax_per_channel: workspace of %zu bytes is too small", workspace_bytes);
+    return hip_status(e, "lsq_hip_minmax_per_channel");
+}
+
 }  // extern "C"

@@ -22,6 +22,8 @@ int lsq_hip_backward_per_channel_ex(int dtype, const void* grad, const void* x, 
                                     double* dsdb_wide, int64_t outer, int64_t channels, int64_t inner,
                                     const void* scale, const void* shift, const lsq_params* p, void* workspace,
                                     size_t workspace_bytes, void* stream, int variant);
+/* tuning only: override the workgroups-per-CU of the observer-statistics kernels (0 = defaults) */
+void lsq_hip_debug_set_observe_wg_per_cu(int v);
 #ifdef __cplusplus
 }
 #endif

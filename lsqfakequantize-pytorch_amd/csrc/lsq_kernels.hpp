@@ -36,13 +36,13 @@ constexpr int encode_variant(int unroll, bool ntl, bool nts, int bpc) {
 // no-arithmetic 2R:1W probe kernel shows, i.e. an HBM access-pattern effect, not a compute one.
 constexpr int kDefaultFwdVariant = encode_variant(4, true, true, 16);
 constexpr int kDefaultBwdVariant = encode_variant(4, true, true, 2);
-// Per-channel (profiles/r01_pc_variant_sweep.txt, BASELINE config 5): forward best at 16 workgroups/CU;
-// the window-mode backward at 2/CU with SHALLOW unrolling (1 packet pair in flight per lane for 4/8-byte
-// elements, 2 for 16-bit ones): its register footprint, not memory-level parallelism, is what limits it.
-// Segment mode (one channel per workgroup) likes many workgroups in both directions.
+// Per-channel (profiles/r01_pc_variant_sweep2.txt, BASELINE config 5, measured AFTER the finalize kernels
+// were parallelised -- before that their serial chain of `splits` dependent loads made few workgroups look
+// best): 16 workgroups/CU in both directions for 4/8-byte elements; the 16-bit backward, which is VALU-
+// rather than HBM-limited, prefers unroll 2 at 8/CU.
 constexpr int kDefaultPcFwdVariant = encode_variant(4, true, true, 16);
-constexpr int kDefaultPcBwdWideVariant = encode_variant(1, true, true, 2);    // fp32 / fp64 storage
-constexpr int kDefaultPcBwdNarrowVariant = encode_variant(2, true, true, 2);  // bf16 / fp16 storage
+constexpr int kDefaultPcBwdWideVariant = encode_variant(4, true, true, 16);   // fp32 / fp64 storage
+constexpr int kDefaultPcBwdNarrowVariant = encode_variant(2, true, true, 8);  // bf16 / fp16 storage
 constexpr int kDefaultPcSegVariant = encode_variant(4, true, true, 16);
 
 inline Variant decode_variant(int code, int dflt) {
@@ -187,5 +187,15 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
                                 int64_t outer, int64_t channels, int64_t inner, const void* scale,
                                 const void* shift, const lsq_params& p, void* workspace, size_t workspace_bytes,
                                 int variant, hipStream_t stream);
+
+// observer statistics (lsq_observe.hip)
+void set_observe_wg_per_cu(int v);
+size_t minmax_workspace_bytes(int io_vec, int elem_arith_bytes, int64_t outer, int64_t channels, int64_t inner);
+template <typename IO>
+hipError_t minmax_per_tensor(const void* x, int64_t n, void* out_min, void* out_max, void* workspace,
+                             hipStream_t stream);
+template <typename IO>
+hipError_t minmax_per_channel(const void* x, int64_t outer, int64_t channels, int64_t inner, void* out_min,
+                              void* out_max, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 }  // namespace lsq

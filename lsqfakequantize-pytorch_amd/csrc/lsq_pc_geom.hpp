@@ -1,0 +1,171 @@
+// lsq_pc_geom.hpp -- the window-mode work decomposition of the per-channel kernels, shared by the
+// fake-quantize kernels (lsq_per_channel.hip) and the observer-statistics kernels (lsq_observe.hip).
+//
+// Data view: dense memory as [outer][L], L = C*inner; a workgroup owns a window of 256 x V positions of
+// the row and walks down a slab of rows, so a lane keeps the same positions -- hence the same
+// channel(s) -- for its whole life.  Short rows (L < 256*V) fold R rows into one tile.
+#pragma once
+
+#include "lsq_kernels.hpp"
+
+namespace lsq {
+
+// floor(a / b) for non-negative operands; 32-bit path when the whole row index space fits
+__device__ __forceinline__ int64_t udiv(int64_t a, int64_t b, bool fits32) {
+    return fits32 ? static_cast<int64_t>(static_cast<uint32_t>(a) / static_cast<uint32_t>(b)) : a / b;
+}
+
+template <typename IO, int V, bool NTL>
+__device__ __forceinline__ void load_elems(const void* base, int64_t e, typename IO::elem (&out)[V]) {
+    if constexpr (V == 1) {
+        out[0] = static_cast<const typename IO::elem*>(base)[e];
+    } else {
+        const Packet<IO> pk = NTL ? load_packet_nt<IO>(base, e) : load_packet<IO>(base, e);
+#pragma unroll
+        for (int j = 0; j < V; ++j) out[j] = pk.v[j];
+    }
+}
+
+template <typename IO, int V, bool NTS>
+__device__ __forceinline__ void store_elems(void* base, int64_t e, const typename IO::elem (&in)[V]) {
+    if constexpr (V == 1) {
+        static_cast<typename IO::elem*>(base)[e] = in[0];
+    } else {
+        Packet<IO> pk;
+#pragma unroll
+        for (int j = 0; j < V; ++j) pk.v[j] = in[j];
+        if (NTS) store_packet_nt<IO>(base, e, pk); else store_packet<IO>(base, e, pk);
+    }
+}
+
+struct PcGeom {
+    int64_t outer, C, inner, L;
+    int64_t wpos;            // positions per window (R == 1) or L (R > 1)
+    int64_t n_windows;       // windows per row
+    int64_t rows_per_split;  // rows walked by one workgroup (multiple of R)
+    int32_t splits;          // workgroups along the row axis
+    int32_t R;               // rows folded into one tile
+    int32_t k_slots;         // channel slots per window (LDS table / partial row length)
+    int32_t vec;             // elements per lane per row (IO::VEC or 1)
+    int32_t fits32;          // L < 2^31: index divisions in 32 bits
+};
+
+static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec, int target_blocks) {
+    PcGeom g;
+    g.outer = outer; g.C = C; g.inner = inner; g.L = C * inner; g.vec = vec;
+    g.fits32 = (g.L + static_cast<int64_t>(kBlock) * vec) < 0x7fffffffLL ? 1 : 0;
+    const int64_t W = static_cast<int64_t>(kBlock) * vec;
+    if (g.L >= W) {
+        g.R = 1;
+        g.wpos = W;
+        g.n_windows = (g.L + W - 1) / W;
+        g.k_slots = static_cast<int32_t>(std::min<int64_t>(C, (W - 1) / inner + 2));
+    } else {
+        g.R = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(W / g.L, outer)));
+        g.wpos = g.L;
+        g.n_windows = 1;
+        g.k_slots = static_cast<int32_t>(C);
+    }
+    // keep the partial-sum traffic (16 B per slot per workgroup) below ~5 % of the streamed bytes
+    const int64_t min_rows = std::max<int64_t>(g.R, (27 * static_cast<int64_t>(g.k_slots) + W - 1) / W * g.R);
+    int64_t want_splits = std::max<int64_t>(1, (target_blocks + g.n_windows - 1) / g.n_windows);
+    int64_t rows = (outer + want_splits - 1) / want_splits;
+    rows = std::max<int64_t>(rows, min_rows);
+    rows = (rows + g.R - 1) / g.R * g.R;
+    g.rows_per_split = rows;
+    g.splits = static_cast<int32_t>((outer + rows - 1) / rows);
+    return g;
+}
+
+// Where a lane sits: position p0 of its first element, its row inside the tile, and whether it is live.
+struct LaneSite {
+    int64_t p0;
+    int32_t row_in_tile;
+    bool live;
+    int64_t c_lo;  // first channel of the window
+};
+__device__ __forceinline__ LaneSite lane_site(const PcGeom& g, int V) {
+    LaneSite s;
+    const int64_t idx = static_cast<int64_t>(threadIdx.x) * V;
+    const bool f32 = g.fits32 != 0;
+    if (g.R == 1) {
+        const int64_t base = static_cast<int64_t>(blockIdx.x) * g.wpos;
+        s.p0 = base + idx;
+        s.row_in_tile = 0;
+        s.live = s.p0 < g.L;
+        s.c_lo = udiv(base, g.inner, f32);
+    } else {
+        s.row_in_tile = static_cast<int32_t>(udiv(idx, g.L, f32));
+        s.p0 = idx - static_cast<int64_t>(s.row_in_tile) * g.L;
+        s.live = s.row_in_tile < g.R;
+        s.c_lo = 0;
+    }
+    return s;
+}
+
+// The rows a lane walks: o_begin, o_begin + step, ... (n_rows of them)
+struct RowWalk {
+    int64_t o_begin, step, n_rows;
+    __device__ __forceinline__ RowWalk(const PcGeom& g, const LaneSite& site) {
+        o_begin = static_cast<int64_t>(blockIdx.y) * g.rows_per_split + site.row_in_tile;
+        const int64_t o_end = std::min<int64_t>(g.outer, static_cast<int64_t>(blockIdx.y + 1) * g.rows_per_split);
+        step = g.R;
+        n_rows = (site.live && o_begin < o_end) ? (o_end - o_begin + step - 1) / step : 0;
+    }
+    __device__ __forceinline__ int64_t row(int64_t i) const { return o_begin + i * step; }
+};
+
+// ---- SEGMENT mode: one channel per workgroup (few rows, long packet-aligned channel rows) ----------
+struct SegGeom {
+    int64_t outer, C, inner;
+    int64_t n_sub;        // sub-rows (of W positions) per channel row
+    int64_t sub_per_seg;  // sub-rows one workgroup owns
+    int64_t o_per_split;  // outer indices one workgroup owns
+    int32_t segs;         // workgroups per channel row
+    int32_t osplits;      // workgroups along outer
+};
+
+static inline SegGeom make_seg_geom(int64_t outer, int64_t C, int64_t inner, int vec, int target_blocks) {
+    SegGeom g;
+    g.outer = outer; g.C = C; g.inner = inner;
+    const int64_t W = static_cast<int64_t>(kBlock) * vec;
+    g.n_sub = (inner + W - 1) / W;
+    const int64_t per_channel = std::max<int64_t>(1, target_blocks / C);       // workgroups we would like per channel
+    const int64_t iters = g.n_sub * outer;                                    // lane iterations per channel
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(per_channel, iters / 4));  // >= 4 packets per lane
+    int64_t segs = std::min<int64_t>(g.n_sub, blocks);
+    g.sub_per_seg = (g.n_sub + segs - 1) / segs;
+    g.segs = static_cast<int32_t>((g.n_sub + g.sub_per_seg - 1) / g.sub_per_seg);
+    int64_t osplits = std::max<int64_t>(1, std::min<int64_t>(outer, blocks / g.segs));
+    g.o_per_split = (outer + osplits - 1) / osplits;
+    g.osplits = static_cast<int32_t>((outer + g.o_per_split - 1) / g.o_per_split);
+    return g;
+}
+
+// The (o, sub-row) pairs a workgroup walks, flattened: it -> (o_begin + it / n_r, r_begin + it % n_r)
+struct SegWalk {
+    int64_t c, o_begin, r_begin, n_r, n_it;
+    __device__ __forceinline__ SegWalk(const SegGeom& g) {
+        c = blockIdx.x / g.segs;
+        const int64_t seg = blockIdx.x - c * g.segs;
+        r_begin = seg * g.sub_per_seg;
+        const int64_t r_end = std::min<int64_t>(g.n_sub, r_begin + g.sub_per_seg);
+        o_begin = static_cast<int64_t>(blockIdx.y) * g.o_per_split;
+        const int64_t o_end = std::min<int64_t>(g.outer, o_begin + g.o_per_split);
+        n_r = r_end - r_begin;
+        n_it = n_r * (o_end - o_begin);
+    }
+};
+
+// few rows + long, packet-aligned channel rows -> one channel per workgroup
+static inline bool pick_segment_mode(int vec, int64_t outer, int64_t C, int64_t inner) {
+    if (vec == 1 || inner % vec != 0) return false;
+    const int64_t W = static_cast<int64_t>(kBlock) * vec;
+    return outer < 8 && inner >= W && C * ((inner + W - 1) / W) <= 0x7fffffffLL;
+}
+
+static inline bool grid_fits(const SegGeom& g) { return g.C * g.segs <= 0x7fffffffLL && g.osplits <= 65535; }
+static inline int pick_vec(int io_vec, int64_t L, bool aligned) { return (aligned && (L % io_vec) == 0) ? io_vec : 1; }
+static inline bool grid_fits(const PcGeom& g) { return g.n_windows <= 0x7fffffffLL && g.splits <= 65535; }
+
+}  // namespace lsq

@@ -28,6 +28,7 @@
 // of a walk re-reads the last valid packet (clamped address, served by L2) and masks its effects.
 // No global atomics, no zero-initialised buffers.
 #include "lsq_kernels.hpp"
+#include "lsq_pc_geom.hpp"
 
 namespace lsq {
 
@@ -39,76 +40,9 @@ struct alignas(16) QSlot {  // LDS image of one channel's constants
     T s, inv_s, zp, pad;
 };
 
-// floor(a / b) for non-negative operands; 32-bit path when the whole row index space fits
-__device__ __forceinline__ int64_t udiv(int64_t a, int64_t b, bool fits32) {
-    return fits32 ? static_cast<int64_t>(static_cast<uint32_t>(a) / static_cast<uint32_t>(b)) : a / b;
-}
-
-template <typename IO, int V, bool NTL>
-__device__ __forceinline__ void load_elems(const void* base, int64_t e, typename IO::elem (&out)[V]) {
-    if constexpr (V == 1) {
-        out[0] = static_cast<const typename IO::elem*>(base)[e];
-    } else {
-        const Packet<IO> pk = NTL ? load_packet_nt<IO>(base, e) : load_packet<IO>(base, e);
-#pragma unroll
-        for (int j = 0; j < V; ++j) out[j] = pk.v[j];
-    }
-}
-
-template <typename IO, int V, bool NTS>
-__device__ __forceinline__ void store_elems(void* base, int64_t e, const typename IO::elem (&in)[V]) {
-    if constexpr (V == 1) {
-        static_cast<typename IO::elem*>(base)[e] = in[0];
-    } else {
-        Packet<IO> pk;
-#pragma unroll
-        for (int j = 0; j < V; ++j) pk.v[j] = in[j];
-        if (NTS) store_packet_nt<IO>(base, e, pk); else store_packet<IO>(base, e, pk);
-    }
-}
-
 // =================================================================================================
 // WINDOW mode
 // =================================================================================================
-struct PcGeom {
-    int64_t outer, C, inner, L;
-    int64_t wpos;            // positions per window (R == 1) or L (R > 1)
-    int64_t n_windows;       // windows per row
-    int64_t rows_per_split;  // rows walked by one workgroup (multiple of R)
-    int32_t splits;          // workgroups along the row axis
-    int32_t R;               // rows folded into one tile
-    int32_t k_slots;         // channel slots per window (LDS table / partial row length)
-    int32_t vec;             // elements per lane per row (IO::VEC or 1)
-    int32_t fits32;          // L < 2^31: index divisions in 32 bits
-};
-
-static PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec, int target_blocks) {
-    PcGeom g;
-    g.outer = outer; g.C = C; g.inner = inner; g.L = C * inner; g.vec = vec;
-    g.fits32 = (g.L + static_cast<int64_t>(kBlock) * vec) < 0x7fffffffLL ? 1 : 0;
-    const int64_t W = static_cast<int64_t>(kBlock) * vec;
-    if (g.L >= W) {
-        g.R = 1;
-        g.wpos = W;
-        g.n_windows = (g.L + W - 1) / W;
-        g.k_slots = static_cast<int32_t>(std::min<int64_t>(C, (W - 1) / inner + 2));
-    } else {
-        g.R = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(W / g.L, outer)));
-        g.wpos = g.L;
-        g.n_windows = 1;
-        g.k_slots = static_cast<int32_t>(C);
-    }
-    // keep the partial-sum traffic (16 B per slot per workgroup) below ~5 % of the streamed bytes
-    const int64_t min_rows = std::max<int64_t>(g.R, (27 * static_cast<int64_t>(g.k_slots) + W - 1) / W * g.R);
-    int64_t want_splits = std::max<int64_t>(1, (target_blocks + g.n_windows - 1) / g.n_windows);
-    int64_t rows = (outer + want_splits - 1) / want_splits;
-    rows = std::max<int64_t>(rows, min_rows);
-    rows = (rows + g.R - 1) / g.R * g.R;
-    g.rows_per_split = rows;
-    g.splits = static_cast<int32_t>((outer + rows - 1) / rows);
-    return g;
-}
-
 // Build the window's channel table in LDS (lsq_kernel.h:157-158 + :12, once per channel).
 template <typename T>
 __device__ __forceinline__ void build_channel_table(QSlot<T>* table, int k_count, int64_t c_lo, int64_t C,
@@ -125,32 +59,6 @@ __device__ __forceinline__ void build_channel_table(QSlot<T>* table, int k_count
         }
         table[k] = e;
     }
-}
-
-// Where a lane sits: position p0 of its first element, its row inside the tile, and whether it is live.
-struct LaneSite {
-    int64_t p0;
-    int32_t row_in_tile;
-    bool live;
-    int64_t c_lo;  // first channel of the window
-};
-__device__ __forceinline__ LaneSite lane_site(const PcGeom& g, int V) {
-    LaneSite s;
-    const int64_t idx = static_cast<int64_t>(threadIdx.x) * V;
-    const bool f32 = g.fits32 != 0;
-    if (g.R == 1) {
-        const int64_t base = static_cast<int64_t>(blockIdx.x) * g.wpos;
-        s.p0 = base + idx;
-        s.row_in_tile = 0;
-        s.live = s.p0 < g.L;
-        s.c_lo = udiv(base, g.inner, f32);
-    } else {
-        s.row_in_tile = static_cast<int32_t>(udiv(idx, g.L, f32));
-        s.p0 = idx - static_cast<int64_t>(s.row_in_tile) * g.L;
-        s.live = s.row_in_tile < g.R;
-        s.c_lo = 0;
-    }
-    return s;
 }
 
 // CPL = channels a lane can touch: 1 (inner % V == 0), 2 (inner >= V), V (anything).
@@ -196,18 +104,6 @@ struct LaneChannels {
         }
         return q[j < N ? j : 0];
     }
-};
-
-// The rows a lane walks: o_begin, o_begin + step, ... (n_rows of them)
-struct RowWalk {
-    int64_t o_begin, step, n_rows;
-    __device__ __forceinline__ RowWalk(const PcGeom& g, const LaneSite& site) {
-        o_begin = static_cast<int64_t>(blockIdx.y) * g.rows_per_split + site.row_in_tile;
-        const int64_t o_end = std::min<int64_t>(g.outer, static_cast<int64_t>(blockIdx.y + 1) * g.rows_per_split);
-        step = g.R;
-        n_rows = (site.live && o_begin < o_end) ? (o_end - o_begin + step - 1) / step : 0;
-    }
-    __device__ __forceinline__ int64_t row(int64_t i) const { return o_begin + i * step; }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -454,83 +350,59 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
     for (int k = threadIdx.x; k < g.k_slots; k += kBlock) out[k] = make_double2(lds_s[k], lds_b[k]);
 }
 
-// Finalize (window mode): one lane per channel folds, in a fixed order, every (split, window) partial
-// that can hold a piece of that channel (the reference's `ds_buffer.sum(axes != axis)`, lsq_cpu.cpp:287-292).
+// Finalize (window mode): folds, in a fixed order, every (split, window) partial that can hold a piece
+// of a channel (the reference's `ds_buffer.sum(axes != axis)`, lsq_cpu.cpp:287-292).  A workgroup
+// handles kFinCh channels x kFinParts interleaved slices of the split axis, so each lane issues only
+// splits/kFinParts INDEPENDENT loads (a one-lane-per-channel loop serialised `splits` dependent
+// HBM latencies); the kFinParts slices are then combined through LDS, again in a fixed order.
+constexpr int kFinCh = 32;
+constexpr int kFinParts = kBlock / kFinCh;
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void finalize_pc_kernel(const double2* __restrict__ partials, PcGeom g,
                                                              int eval_mode, int sym, T sym_term, T* __restrict__ ds,
                                                              T* __restrict__ db, double* __restrict__ wide) {
-    const int64_t c = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (c >= g.C) return;
+    __shared__ double2 part_sum[kFinParts][kFinCh];
+    const int lane_c = threadIdx.x % kFinCh, part = threadIdx.x / kFinCh;
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * kFinCh + lane_c;
     double s = 0.0, b = 0.0;
-    if (!eval_mode) {
+    if (!eval_mode && c < g.C) {
         int64_t w_lo = 0, w_hi = 0;
         if (g.R == 1) {
             w_lo = (c * g.inner) / g.wpos;
             w_hi = ((c + 1) * g.inner - 1) / g.wpos;
         }
-        for (int32_t sy = 0; sy < g.splits; ++sy) {
-            for (int64_t w = w_lo; w <= w_hi; ++w) {
-                const int64_t c_lo = (g.R == 1) ? (w * g.wpos) / g.inner : 0;
-                const double2 v = partials[(static_cast<int64_t>(sy) * g.n_windows + w) * g.k_slots + (c - c_lo)];
+        for (int64_t w = w_lo; w <= w_hi; ++w) {
+            const int64_t c_lo = (g.R == 1) ? (w * g.wpos) / g.inner : 0;
+            const double2* col = partials + w * g.k_slots + (c - c_lo);
+            const int64_t stride = g.n_windows * g.k_slots;
+#pragma unroll 4
+            for (int32_t sy = part; sy < g.splits; sy += kFinParts) {
+                const double2 v = col[static_cast<int64_t>(sy) * stride];
                 s += v.x;
                 b += v.y;
             }
         }
-        if (sym) b = 0.0 + static_cast<double>(sym_term);
     }
-    ds[c] = static_cast<T>(s);
-    db[c] = static_cast<T>(b);
-    if (wide) {
-        wide[c] = s;
-        wide[g.C + c] = b;
+    part_sum[part][lane_c] = make_double2(s, b);
+    __syncthreads();
+    if (part == 0 && c < g.C) {
+        double ts = 0.0, tb = 0.0;
+#pragma unroll
+        for (int k = 0; k < kFinParts; ++k) { ts += part_sum[k][lane_c].x; tb += part_sum[k][lane_c].y; }
+        if (!eval_mode && sym) tb = 0.0 + static_cast<double>(sym_term);
+        ds[c] = static_cast<T>(ts);
+        db[c] = static_cast<T>(tb);
+        if (wide) {
+            wide[c] = ts;
+            wide[g.C + c] = tb;
+        }
     }
 }
 
 // =================================================================================================
 // SEGMENT mode: one channel per workgroup
 // =================================================================================================
-struct SegGeom {
-    int64_t outer, C, inner;
-    int64_t n_sub;        // sub-rows (of W positions) per channel row
-    int64_t sub_per_seg;  // sub-rows one workgroup owns
-    int64_t o_per_split;  // outer indices one workgroup owns
-    int32_t segs;         // workgroups per channel row
-    int32_t osplits;      // workgroups along outer
-};
-
-static SegGeom make_seg_geom(int64_t outer, int64_t C, int64_t inner, int vec, int target_blocks) {
-    SegGeom g;
-    g.outer = outer; g.C = C; g.inner = inner;
-    const int64_t W = static_cast<int64_t>(kBlock) * vec;
-    g.n_sub = (inner + W - 1) / W;
-    const int64_t per_channel = std::max<int64_t>(1, target_blocks / C);       // workgroups we would like per channel
-    const int64_t iters = g.n_sub * outer;                                    // lane iterations per channel
-    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(per_channel, iters / 4));  // >= 4 packets per lane
-    int64_t segs = std::min<int64_t>(g.n_sub, blocks);
-    g.sub_per_seg = (g.n_sub + segs - 1) / segs;
-    g.segs = static_cast<int32_t>((g.n_sub + g.sub_per_seg - 1) / g.sub_per_seg);
-    int64_t osplits = std::max<int64_t>(1, std::min<int64_t>(outer, blocks / g.segs));
-    g.o_per_split = (outer + osplits - 1) / osplits;
-    g.osplits = static_cast<int32_t>((outer + g.o_per_split - 1) / g.o_per_split);
-    return g;
-}
-
-// The (o, sub-row) pairs a workgroup walks, flattened: it -> (o_begin + it / n_r, r_begin + it % n_r)
-struct SegWalk {
-    int64_t c, o_begin, r_begin, n_r, n_it;
-    __device__ __forceinline__ SegWalk(const SegGeom& g) {
-        c = blockIdx.x / g.segs;
-        const int64_t seg = blockIdx.x - c * g.segs;
-        r_begin = seg * g.sub_per_seg;
-        const int64_t r_end = std::min<int64_t>(g.n_sub, r_begin + g.sub_per_seg);
-        o_begin = static_cast<int64_t>(blockIdx.y) * g.o_per_split;
-        const int64_t o_end = std::min<int64_t>(g.outer, o_begin + g.o_per_split);
-        n_r = r_end - r_begin;
-        n_it = n_r * (o_end - o_begin);
-    }
-};
-
 template <typename IO, int V, bool INIT, bool LEVELS, int UNROLL, bool NTL, bool NTS>
 __global__ __launch_bounds__(kBlock) void fwd_seg_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                          int8_t* __restrict__ levels, int level_bias, SegGeom g,
@@ -654,46 +526,49 @@ __global__ __launch_bounds__(kBlock) void bwd_seg_kernel(const void* __restrict_
     }
 }
 
+// Finalize (segment mode): kFinCh channels x kFinParts interleaved slices of the (osplit, seg) partials.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void finalize_seg_kernel(const double2* __restrict__ partials, SegGeom g,
                                                               int eval_mode, int sym, T sym_term, T* __restrict__ ds,
                                                               T* __restrict__ db, double* __restrict__ wide) {
-    const int64_t c = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (c >= g.C) return;
+    __shared__ double2 part_sum[kFinParts][kFinCh];
+    const int lane_c = threadIdx.x % kFinCh, part = threadIdx.x / kFinCh;
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * kFinCh + lane_c;
     double s = 0.0, b = 0.0;
-    if (!eval_mode) {
+    if (!eval_mode && c < g.C) {
         const int64_t gx = g.C * g.segs;
-        for (int32_t oy = 0; oy < g.osplits; ++oy)
-            for (int32_t sg = 0; sg < g.segs; ++sg) {
-                const double2 v = partials[static_cast<int64_t>(oy) * gx + c * g.segs + sg];
-                s += v.x;
-                b += v.y;
-            }
-        if (sym) b = 0.0 + static_cast<double>(sym_term);
+        const int32_t total = g.osplits * g.segs;
+#pragma unroll 4
+        for (int32_t sl = part; sl < total; sl += kFinParts) {
+            const int32_t oy = sl / g.segs, sg = sl - oy * g.segs;
+            const double2 v = partials[static_cast<int64_t>(oy) * gx + c * g.segs + sg];
+            s += v.x;
+            b += v.y;
+        }
     }
-    ds[c] = static_cast<T>(s);
-    db[c] = static_cast<T>(b);
-    if (wide) {
-        wide[c] = s;
-        wide[g.C + c] = b;
+    part_sum[part][lane_c] = make_double2(s, b);
+    __syncthreads();
+    if (part == 0 && c < g.C) {
+        double ts = 0.0, tb = 0.0;
+#pragma unroll
+        for (int k = 0; k < kFinParts; ++k) { ts += part_sum[k][lane_c].x; tb += part_sum[k][lane_c].y; }
+        if (!eval_mode && sym) tb = 0.0 + static_cast<double>(sym_term);
+        ds[c] = static_cast<T>(ts);
+        db[c] = static_cast<T>(tb);
+        if (wide) {
+            wide[c] = ts;
+            wide[g.C + c] = tb;
+        }
     }
 }
 
 // =================================================================================================
 // host-side launchers
 // =================================================================================================
-static inline int pick_vec(int io_vec, int64_t L, bool aligned) { return (aligned && (L % io_vec) == 0) ? io_vec : 1; }
 static inline int pick_cpl(int vec, int64_t inner) {
     if (vec == 1 || inner % vec == 0) return 1;
     return inner >= vec ? 2 : vec;
 }
-// few rows + long, packet-aligned channel rows -> one channel per workgroup
-static inline bool pick_segment_mode(int vec, int64_t outer, int64_t C, int64_t inner) {
-    if (vec == 1 || inner % vec != 0) return false;
-    const int64_t W = static_cast<int64_t>(kBlock) * vec;
-    return outer < 8 && inner >= W && C * ((inner + W - 1) / W) <= 0x7fffffffLL;
-}
-
 size_t bwd_pc_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64_t inner) {
     const DeviceInfo& dev = device_info();
     size_t need = 0;
@@ -711,8 +586,6 @@ size_t bwd_pc_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64
     return need + 256;
 }
 
-static inline bool grid_fits(const PcGeom& g) { return g.n_windows <= 0x7fffffffLL && g.splits <= 65535; }
-static inline bool grid_fits(const SegGeom& g) { return g.C * g.segs <= 0x7fffffffLL && g.osplits <= 65535; }
 
 // ---- forward --------------------------------------------------------------------------------------
 template <typename IO, int V, int CPL, bool INIT, bool LEVELS>
@@ -802,7 +675,7 @@ static hipError_t launch_bwd_pc(const void* grad, const void* x, void* dx, const
                        g, static_cast<const T*>(scale), static_cast<const T*>(shift), r, gs, partials)
     [[maybe_unused]] constexpr bool kFull = !SYM && !INIT && !EVAL && V > 1 && CPL <= 2 && !std::is_same<IO, io_f64>::value &&
                                             !std::is_same<IO, io_f16>::value;
-    constexpr int kDefU = sizeof(typename IO::elem) >= 4 ? 1 : 2;
+    constexpr int kDefU = sizeof(typename IO::elem) >= 4 ? 4 : 2;
     LSQ_DISPATCH_VARIANT(kFull, kDefU, v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH
     return hipGetLastError();
@@ -875,7 +748,7 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
     const T gs = grad_scaler_per_channel<T>(n4s, p.quant_max, channels, p.use_grad_scaling != 0, p.grad_scaler);
     const T sym_term = static_cast<T>(0) * gs;
     double2* partials = static_cast<double2*>(workspace);
-    const unsigned fgrid = static_cast<unsigned>((channels + kBlock - 1) / kBlock);
+    const unsigned fgrid_w = static_cast<unsigned>((channels + kFinCh - 1) / kFinCh);
 
     if (seg) {
         const SegGeom sg = make_seg_geom(outer, channels, inner, vec, target);
@@ -884,7 +757,7 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
         if (!p.eval_mode && workspace_bytes < need) return hipErrorInvalidValue;
         hipError_t e = bwd_seg_modes<IO>(grad, x, dx, sg, scale, shift, p, gs, partials, v, stream);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((finalize_seg_kernel<T>), dim3(fgrid), dim3(kBlock), 0, stream, partials, sg,
+        hipLaunchKernelGGL((finalize_seg_kernel<T>), dim3(fgrid_w), dim3(kBlock), 0, stream, partials, sg,
                            p.eval_mode ? 1 : 0, p.sym ? 1 : 0, sym_term, static_cast<T*>(ds), static_cast<T*>(db), wide);
         return hipGetLastError();
     }
@@ -900,7 +773,7 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
     else if (cpl == 2) e = bwd_pc_modes<IO, IO::VEC, 2>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
     else e = bwd_pc_modes<IO, IO::VEC, IO::VEC>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((finalize_pc_kernel<T>), dim3(fgrid), dim3(kBlock), 0, stream, partials, g, p.eval_mode ? 1 : 0,
+    hipLaunchKernelGGL((finalize_pc_kernel<T>), dim3(fgrid_w), dim3(kBlock), 0, stream, partials, g, p.eval_mode ? 1 : 0,
                        p.sym ? 1 : 0, sym_term, static_cast<T*>(ds), static_cast<T*>(db), wide);
     return hipGetLastError();
 }

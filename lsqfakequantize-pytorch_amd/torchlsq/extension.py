@@ -61,6 +61,9 @@ C_ABI = {
     "lsq_hip_forward_per_channel": (_int, [_int, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP, _EP, _vp]),
     "lsq_hip_backward_per_channel": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP, _vp,
                                             _sz, _vp]),
+    "lsq_hip_minmax_workspace": (_sz, [_int, _i64, _i64, _i64]),
+    "lsq_hip_minmax_per_tensor": (_int, [_int, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "lsq_hip_minmax_per_channel": (_int, [_int, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
 }
 # tuning twins (csrc/lsq_internal.h): same signatures + a trailing launch-variant code
 C_ABI_INTERNAL = {
@@ -155,6 +158,9 @@ _lib_def.define("lsq_backward_per_tensor_wide(Tensor grad, Tensor x, Tensor scal
                 ", int numel_for_scaler) -> (Tensor, Tensor)")
 _lib_def.define("lsq_backward_per_channel_wide(Tensor grad, Tensor x, Tensor scale, Tensor shift, int axis, " + _TAIL +
                 ", int numel_for_scaler) -> (Tensor, Tensor)")
+#  * `lsq_minmax*`: one-pass running min/max (torch.aminmax semantics) for the observer init phase.
+_lib_def.define("lsq_minmax_per_tensor(Tensor x) -> (Tensor, Tensor)")
+_lib_def.define("lsq_minmax_per_channel(Tensor x, int axis) -> (Tensor, Tensor)")
 _lib_def.define("lsq_quantize_per_tensor(Tensor x, Tensor scale, Tensor shift, int quant_min, int quant_max, "
                 "int type_min, int type_max, int level_bias) -> (Tensor, Tensor)")
 _lib_def.define("lsq_quantize_per_channel(Tensor x, Tensor scale, Tensor shift, int axis, int quant_min, "
@@ -450,6 +456,56 @@ def hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax
     return dx, ds, db
 
 
+_WS_BYTES_MM = {}
+
+
+def hip_minmax(x, axis=None):
+    """(min, max) of x -- over everything (axis None) or per channel along `axis` -- in one read-only pass.
+    torch.aminmax semantics (a NaN makes both results NaN); results are fp32 (fp64 for fp64 input)."""
+    _assert_has_ops()
+    _check(x.dtype in _DTYPE_CODE, '"lsq_minmax" not implemented for \'%s\'' % str(x.dtype).replace("torch.", ""))
+    _check(x.numel() > 0, "lsq_minmax: cannot reduce an empty tensor")
+    _require_gpu("lsq_minmax", x)
+    xd, order = _dense(x.detach())
+    pd = _param_dtype(x)
+    dev = x.device
+    idx = dev.index
+    code = _DTYPE_CODE[x.dtype]
+    if axis is None:
+        outer, C, inner = 1, 1, xd.numel()
+    else:
+        _check(0 <= axis < x.dim(), "`axis` must be between 0 and number of dimensions of input")
+        outer, C, inner = _ocl(xd, order, axis)
+    mn = torch.empty(C, dtype=pd, device=dev)
+    mx = torch.empty(C, dtype=pd, device=dev)
+    wkey = (idx, code, outer, C, inner)
+    nbytes = _WS_BYTES_MM.get(wkey)
+    if nbytes is None:
+        nbytes = int(_on_device(idx, _LIB.lsq_hip_minmax_workspace, code, outer, C, inner))
+        if len(_WS_BYTES_MM) < 4096:
+            _WS_BYTES_MM[wkey] = nbytes
+    ws = _workspace(dev, nbytes)
+    if axis is None:
+        rc = _on_device(idx, _LIB.lsq_hip_minmax_per_tensor, code, xd.data_ptr(), xd.numel(), mn.data_ptr(), mx.data_ptr(),
+                        ws.data_ptr(), ws.numel(), _stream_of(idx))
+    else:
+        rc = _on_device(idx, _LIB.lsq_hip_minmax_per_channel, code, xd.data_ptr(), outer, C, inner, mn.data_ptr(),
+                        mx.data_ptr(), ws.data_ptr(), ws.numel(), _stream_of(idx))
+    if rc:
+        _status(rc, "lsq_hip_minmax")
+    if axis is None:
+        return mn.reshape(()), mx.reshape(())
+    return mn, mx
+
+
+def _impl_minmax_pt(x):
+    return hip_minmax(x, None)
+
+
+def _impl_minmax_pc(x, axis):
+    return hip_minmax(x, axis)
+
+
 def _impl_fwd_pt(x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode):
     return hip_forward_per_tensor(x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
 
@@ -499,6 +555,8 @@ _lib_hip.impl("lsq_backward_per_tensor_wide", _impl_bwd_pt_wide)
 _lib_hip.impl("lsq_backward_per_channel_wide", _impl_bwd_pc_wide)
 _lib_hip.impl("lsq_quantize_per_tensor", _impl_quantize_pt)
 _lib_hip.impl("lsq_quantize_per_channel", _impl_quantize_pc)
+_lib_hip.impl("lsq_minmax_per_tensor", _impl_minmax_pt)
+_lib_hip.impl("lsq_minmax_per_channel", _impl_minmax_pc)
 
 
 # -------------------------------------------------------------------------------------------------

@@ -21,6 +21,7 @@ import torch
 from torch.ao.quantization.observer import ObserverBase as _TorchObserverBase
 
 from torchlsq.functional import lsq
+from .hip_observers import accelerated as _accelerated
 
 Tensor = torch.Tensor
 
@@ -159,6 +160,9 @@ class LSQFakeQuantizer(ObserverBase):
             offered.update(observer_kwargs)
             offered['reduce_range'] = avoid_torch_overflow
             accepted = set(inspect.signature(observer.__init__).parameters) - {'self'}
+            # stock torch MinMax observers are swapped for subclasses whose statistics pass is the gfx950
+            # one-pass min/max kernel (same buffers, update rules and qparams; see hip_observers.py)
+            observer = _accelerated(observer)
             self.activation_post_process = observer(**{k: v for k, v in offered.items() if k in accepted})
 
         self.init_mode = init_mode

@@ -107,7 +107,17 @@ def install_oracle_cpu_backend():
         r = bwd_pc_impl(grad, x, scale, shift, axis, *a)
         return torch.from_numpy(r.dx).view(x.shape), torch.from_numpy(np.stack([r.ds_wide, r.db_wide]))
 
+    def minmax_pt(x):
+        return torch.aminmax(x.detach().to(E._param_dtype(x)))
+
+    def minmax_pc(x, axis):
+        dims = [d for d in range(x.dim()) if d != axis]
+        y = x.detach().to(E._param_dtype(x))
+        return torch.amin(y, dims), torch.amax(y, dims)
+
     lib = torch.library.Library("torchlsq", "IMPL", "CPU")
+    lib.impl("lsq_minmax_per_tensor", minmax_pt)
+    lib.impl("lsq_minmax_per_channel", minmax_pc)
     lib.impl("lsq_forward_per_tensor", fwd_pt)
     lib.impl("lsq_backward_per_tensor", bwd_pt)
     lib.impl("lsq_backward_per_tensor_wide", bwd_pt_wide)

@@ -488,3 +488,64 @@ def test_more_than_2_pow_31_elements(dev):
         acc += wp
         del yp, dxp
     np.testing.assert_allclose(acc.cpu().numpy(), wide.cpu().numpy(), rtol=1e-11)
+
+
+MM_SHAPES = [((7,), None), ((4099,), None), ((3, 1 << 20), None), ((4, 8, 6, 6), 1), ((8, 4, 3, 3), 0), ((5, 16), 1),
+             ((3, 5, 7), 1), ((2, 2048, 7, 7), 1), ((33, 1000), 1), ((1000, 33), 0), ((300, 16), 1), ((129, 4096), 1),
+             ((4, 3, 224, 224), 1), ((64, 64, 3, 3), 0), ((1, 7), 1), ((257, 3), 1), ((9, 2050, 3), 1), ((512, 4608), 0)]
+
+
+@pytest.mark.parametrize("shape,axis", MM_SHAPES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16])
+def test_minmax_matches_torch_aminmax(dev, shape, axis, dtype):
+    """One-pass observer statistics == torch.aminmax (CPU) exactly, incl. NaN propagation per channel."""
+    from torchlsq import synth
+    n = int(np.prod(shape))
+    x = synth.normal_like(n, 61, 0.3, 2.0, dtype=dtype).view(shape)
+    pdt = torch.float64 if dtype == torch.float64 else torch.float32
+    for with_nan in (False, True):
+        if with_nan:
+            x = x.clone()
+            x.view(-1)[n // 3] = float("nan")
+        if axis is None:
+            mn, mx = torch.ops.torchlsq.lsq_minmax_per_tensor(x.to(dev))
+            wmn, wmx = torch.aminmax(x.to(pdt))
+        else:
+            mn, mx = torch.ops.torchlsq.lsq_minmax_per_channel(x.to(dev), axis)
+            y = x.to(pdt).transpose(0, axis).flatten(1)
+            wmn, wmx = torch.aminmax(y, dim=1)
+        assert mn.dtype == pdt and mn.shape == wmn.shape
+        assert torch.equal(mn.cpu().isnan(), wmn.isnan()) and torch.equal(mx.cpu().isnan(), wmx.isnan())
+        ok = ~wmn.isnan()
+        assert torch.equal(mn.cpu()[ok], wmn[ok]) and torch.equal(mx.cpu()[ok], wmx[ok])
+    # a sliced (misaligned) view and a channels-last tensor
+    if axis is None and n > 8:
+        v = x.to(dev).view(-1)[1:]
+        mn, mx = torch.ops.torchlsq.lsq_minmax_per_tensor(v)
+        w = torch.aminmax(x.view(-1)[1:].to(pdt))
+        assert (mn.cpu().isnan() and w[0].isnan()) or (mn.cpu() == w[0] and mx.cpu() == w[1])
+
+
+def test_accelerated_observers_equal_stock_observers(dev):
+    """LSQFakeQuantizer's observers on the GPU (one-pass kernel) track exactly what the stock torch observers
+    compute, batch after batch, and produce the same qparams."""
+    from torch.ao.quantization import observer as O
+    from torchlsq import synth
+    from torchlsq.quantized.modules import hip_observers as H
+    for stock, kw, shape in ((O.MinMaxObserver, {}, (8, 16, 5, 5)), (O.MovingAverageMinMaxObserver, {}, (8, 16, 5, 5)),
+                             (O.PerChannelMinMaxObserver, dict(ch_axis=1), (8, 16, 5, 5)),
+                             (O.MovingAveragePerChannelMinMaxObserver, dict(ch_axis=0), (32, 16, 3, 3)),
+                             (O.MovingAveragePerChannelMinMaxObserver, dict(ch_axis=1), (8, 16, 7, 7))):
+        fast_cls = H.accelerated(stock)
+        assert fast_cls is not stock and issubclass(fast_cls, stock)
+        a, b = stock(**kw), fast_cls(**kw).to(dev)
+        n = int(np.prod(shape))
+        for step in range(4):
+            x = synth.normal_like(n, 70 + step, 0.2 * step, 1.0 + 0.3 * step).view(shape)
+            a(x)
+            b(x.to(dev))
+            assert torch.equal(a.min_val, b.min_val.cpu()) and torch.equal(a.max_val, b.max_val.cpu()), (stock.__name__, step)
+        sa, za = a.calculate_qparams()
+        sb, zb = b.cpu().calculate_qparams()          # same statistics -> same qparams (torch's own arithmetic, on the CPU)
+        assert torch.equal(sa, sb) and torch.equal(za, zb)
+        assert list(a.state_dict().keys()) == list(b.state_dict().keys())

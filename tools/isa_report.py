@@ -28,7 +28,7 @@ def main():
     extra = [a for a in sys.argv[2:]]
     tmp = tempfile.mkdtemp(prefix="lsq_isa_")
     rows = []
-    for src in ("lsq_per_tensor.hip", "lsq_per_channel.hip"):
+    for src in ("lsq_per_tensor.hip", "lsq_per_channel.hip", "lsq_observe.hip"):
         asm = os.path.join(tmp, src + ".s")
         subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + extra + [os.path.join(CSRC, src), "-o", asm],
                        check=True, stderr=subprocess.DEVNULL)

@@ -26,7 +26,7 @@ def build():
     os.makedirs(OUT, exist_ok=True)
     flags = ["-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
              "-DLSQ_TUNING", "-shared"]
-    srcs = [os.path.join(CSRC, f) for f in ("lsq_capi.hip", "lsq_per_tensor.hip", "lsq_per_channel.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("lsq_capi.hip", "lsq_per_tensor.hip", "lsq_per_channel.hip", "lsq_observe.hip")]
     srcs.append(os.path.join(ROOT, "tools", "stream_probe.hip"))
     cmd = ["/opt/rocm/bin/hipcc"] + flags + srcs + ["-o", SO]
     print(" ".join(cmd))
