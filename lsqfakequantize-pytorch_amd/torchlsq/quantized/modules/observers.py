@@ -6,6 +6,16 @@ Behavioural restatement of reference torchlsq/quantized/modules/observers.py (cl
 (:424-462).  The module is the caller of the hot path; the quantize/dequantize arithmetic itself
 runs in the gfx950 kernels behind `torchlsq.functional.lsq`.
 
+State flags without host<->device round trips: the reference tests its four state buffers
+(`fake_quant_enabled`, `observer_enabled`, `learning_enabled`, `current_batch`) with Python `if`s on
+every forward (observers.py:431-451) -- once the module lives on the GPU each test is a blocking
+device synchronisation, four per call, which serialises the whole training step.  Here the buffers stay
+the persisted state (same names, dtypes and state_dict keys) but every decision reads a host-side
+mirror kept by the module's own methods; the mirror is re-read from the buffers after
+`load_state_dict` and on every `train()` / `eval()` call.  Change the flags through the methods
+(`enable_observer()`, `disable_fake_quant()`, `enable_static_estimate()`, ...), as the reference's own
+`apply` helpers do.
+
 Two deliberate differences from the reference, both turning a crash into the documented behaviour:
   * `LSQFakeQuantizer.with_args(...)` works (the reference calls `partial` without importing it,
     observers.py:64);
@@ -219,48 +229,69 @@ class LSQFakeQuantizer(ObserverBase):
         self.register_buffer('observer_enabled', _flag(1))
         self.register_buffer('learning_enabled', _flag(learn_params))
         self.register_buffer('current_batch', torch.tensor([0], dtype=torch.int64))
+        self._h = {'fake_quant': 1, 'observer': 1, 'learning': int(learn_params), 'batch': 0}   # host mirror
         self.enable_observer()           # applies the "observer not needed" rules below
 
+    # ---- host mirror of the state buffers (no device synchronisation on the hot path) --------------
+    def _refresh_host_state(self):
+        """re-read the mirror from the buffers (after load_state_dict / train() / eval())"""
+        self._h = {'fake_quant': int(self.fake_quant_enabled[0]), 'observer': int(self.observer_enabled[0]),
+                   'learning': int(self.learning_enabled[0]), 'batch': int(self.current_batch[0])}
+
+    def _set_flag(self, name, buffer, value):
+        buffer[0] = value                 # tiny async host-to-device write, never a sync
+        self._h[name] = int(value)
+
+    def train(self, mode=True):
+        out = super().train(mode)
+        if hasattr(self, '_h'):
+            self._refresh_host_state()
+        return out
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._refresh_host_state()
+
     def check_is_init_mode(self):
-        return (bool(self.learning_enabled[0]) and self.otype != OTYPES['weight']
-                and bool(self.current_batch[0] <= self.n_batches))
+        return (bool(self._h['learning']) and self.otype != OTYPES['weight']
+                and self._h['batch'] <= self.n_batches)
 
     @torch.jit.export
     def enable_observer(self) -> None:
         needed = True
-        if self.learning_enabled[0] == 1:
+        if self._h['learning'] == 1:
             if self.otype == OTYPES['weight']:
                 needed = False           # learned weights never use the observer
             elif self.init_mode == 'learnable':
                 needed = False           # parameters come from back-propagation
-            elif self.init_mode == 'observer' and self.current_batch[0] > self.n_batches:
+            elif self.init_mode == 'observer' and self._h['batch'] > self.n_batches:
                 needed = False           # the observer-driven init phase is over
-        self.observer_enabled[0] = int(needed)
+        self._set_flag('observer', self.observer_enabled, int(needed))
 
     @torch.jit.export
     def disable_observer(self) -> None:
-        self.observer_enabled[0] = 0
+        self._set_flag('observer', self.observer_enabled, 0)
 
     @torch.jit.export
     def enable_fake_quant(self) -> None:
-        self.fake_quant_enabled[0] = 1
+        self._set_flag('fake_quant', self.fake_quant_enabled, 1)
 
     @torch.jit.export
     def disable_fake_quant(self) -> None:
-        self.fake_quant_enabled[0] = 0
+        self._set_flag('fake_quant', self.fake_quant_enabled, 0)
 
     @torch.jit.export
     def enable_param_learning(self):
         """Learn scale/shift with LSQ; static observer estimates are switched off and the
         initialisation phase is considered done."""
-        self.learning_enabled[0] = 1
+        self._set_flag('learning', self.learning_enabled, 1)
         self.disable_observer()
         self.n_batches = -1
 
     @torch.jit.export
     def enable_static_estimate(self):
         """Stop learning; scale/shift follow the observer (FakeQuantize behaviour)."""
-        self.learning_enabled[0] = 0
+        self._set_flag('learning', self.learning_enabled, 0)
         self.enable_observer()
 
     # ---- parameters ------------------------------------------------------------------------------
@@ -285,7 +316,7 @@ class LSQFakeQuantizer(ObserverBase):
         shift = torch.full((n,), self.init_shift, dtype=torch.float32).to(device)
         self.scale = torch.nn.Parameter(scale)
         self.shift = torch.nn.Parameter(shift)
-        learn = bool(self.learning_enabled[0])
+        learn = bool(self._h['learning'])
         self.scale.requires_grad = learn
         self.shift.requires_grad = learn and self.is_affine
 
@@ -342,10 +373,11 @@ class LSQFakeQuantizer(ObserverBase):
         if not self._initialized:
             self._init_weights(x)
             return x                        # the creating call passes its input through
-        full_lsq = bool(self.learning_enabled[0])
+        h = self._h                          # host mirror: no device synchronisation below
+        full_lsq = bool(h['learning'])
         backprop_init = False
-        if self.current_batch[0] <= self.n_batches and self.training and self.learning_enabled[0] == 1:
-            last = bool(self.current_batch[0] == self.n_batches)
+        if h['batch'] <= self.n_batches and self.training and h['learning'] == 1:
+            last = h['batch'] == self.n_batches
             if self.init_mode == 'observer':
                 # plain fake-quant driven by the observer until the last init batch
                 full_lsq = last
@@ -354,14 +386,15 @@ class LSQFakeQuantizer(ObserverBase):
             elif self.init_mode == 'learnable':
                 self.disable_observer()
                 backprop_init = not last
-            self.current_batch[0] += 1
+            self.current_batch[0] += 1       # in place on the device, asynchronous
+            h['batch'] += 1
 
-        if self.observer_enabled[0] == 1:
+        if h['observer'] == 1:
             self.activation_post_process(x.detach())
             scale, zero_point = self.activation_post_process.calculate_qparams()
             self._set_weights(scale=scale, zero_point=zero_point)
 
-        if self.fake_quant_enabled[0] == 1:
+        if h['fake_quant'] == 1:
             backprop_init = bool(backprop_init and full_lsq)
             tmin, tmax = TYPES_RANGE_MAPPING[self.dtype]['range']
             self.scale.requires_grad = full_lsq

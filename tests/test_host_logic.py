@@ -147,7 +147,8 @@ def test_apply_helpers():
     assert int(act.fake_quant_enabled[0]) == 0 and int(wgt.fake_quant_enabled[0]) == 1 and int(fq.fake_quant_enabled[0]) == 0
     net.apply(TQ.enable_fake_quant)
     assert int(act.fake_quant_enabled[0]) == 1 and int(fq.fake_quant_enabled[0]) == 1
-    wgt.learning_enabled[0] = 0
+    wgt.enable_static_estimate()          # learning off -> the weight observer becomes meaningful
+    assert int(wgt.observer_enabled[0]) == 1
     net.apply(TQ.disable_observer_on_weights)
     assert int(wgt.observer_enabled[0]) == 0 and int(act.observer_enabled[0]) == 1 and int(fq.observer_enabled[0]) == 0
     net.apply(TQ.enable_observer_on_weights)
@@ -228,3 +229,27 @@ def test_picklable_factory():
     m = f()
     m2 = pickle.loads(pickle.dumps(m))
     assert isinstance(m2, LSQFakeQuantizer) and m2.quant_max == 127
+
+
+def test_host_mirror_tracks_buffers(oracle_cpu_backend):
+    """decisions read a host mirror of the four state buffers; it follows the methods, load_state_dict and train()/eval()"""
+    from torch.ao.quantization.observer import MovingAverageMinMaxObserver as Obs
+    from torchlsq.quantized import LSQFakeQuantizer as Q
+    a = Q(Obs, "activation", init_batches=2)
+    x = torch.rand(4, 8) + 0.5
+    for _ in range(5):
+        a(x)
+    mirror = lambda m: (m._h["fake_quant"], m._h["observer"], m._h["learning"], m._h["batch"])
+    bufs = lambda m: (int(m.fake_quant_enabled[0]), int(m.observer_enabled[0]), int(m.learning_enabled[0]), int(m.current_batch[0]))
+    assert mirror(a) == bufs(a) == (1, 0, 1, 3)
+    a.disable_fake_quant(); a.enable_static_estimate()
+    assert mirror(a) == bufs(a) == (0, 1, 0, 3)
+    b = Q(Obs, "activation", init_batches=2)
+    b(x)
+    b.load_state_dict(a.state_dict())
+    assert mirror(b) == bufs(b) == (0, 1, 0, 3)
+    b.fake_quant_enabled[0] = 1          # an out-of-band write is picked up at the next train()/eval()
+    b.train()
+    assert mirror(b) == bufs(b) == (1, 1, 0, 3)
+    import copy, pickle
+    assert mirror(copy.deepcopy(b)) == mirror(b) and mirror(pickle.loads(pickle.dumps(b))) == mirror(b)

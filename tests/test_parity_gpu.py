@@ -549,3 +549,28 @@ def test_accelerated_observers_equal_stock_observers(dev):
         sb, zb = b.cpu().calculate_qparams()          # same statistics -> same qparams (torch's own arithmetic, on the CPU)
         assert torch.equal(sa, sb) and torch.equal(za, zb)
         assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+
+
+def test_steady_state_forward_backward_never_synchronises(dev):
+    """After the init phase a quantizer call must not block on the device: the reference tests its state
+    buffers with Python `if`s (4 device syncs per call on the GPU); here decisions read a host mirror and
+    the ops read scale/shift on the device."""
+    from torch.ao.quantization.observer import MovingAverageMinMaxObserver, MovingAveragePerChannelMinMaxObserver
+    from torchlsq.quantized import LSQFakeQuantizer
+    act = LSQFakeQuantizer(MovingAverageMinMaxObserver, "activation", init_batches=1).to(dev)
+    wq = LSQFakeQuantizer(MovingAveragePerChannelMinMaxObserver, "weight", dtype=torch.qint8,
+                          qscheme=torch.per_channel_symmetric).to(dev)
+    w = torch.nn.Parameter(torch.randn(32, 16, 3, 3, device=dev) * 0.05)
+    x = torch.rand(8, 16, 12, 12, device=dev)
+    for _ in range(4):                      # creation + init batches (these may synchronise)
+        (act(x).sum() + wq(w).sum()).backward()
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        for _ in range(3):
+            out = act(x).sum() + wq(w).sum()
+            out.backward()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert int(act.current_batch[0]) == 2 and act._h["batch"] == 2
