@@ -586,6 +586,38 @@ def _fake_bwd_pc(grad, x, scale, shift, axis, *a):
     return _meta_like(x), torch.empty_like(scale), torch.empty_like(shift)
 
 
+@torch.library.register_fake("torchlsq::lsq_backward_per_tensor_wide", lib=_lib_def)
+def _fake_bwd_pt_wide(grad, x, scale, shift, *a):
+    return _meta_like(x), x.new_empty((2,), dtype=torch.float64)
+
+
+@torch.library.register_fake("torchlsq::lsq_backward_per_channel_wide", lib=_lib_def)
+def _fake_bwd_pc_wide(grad, x, scale, shift, axis, *a):
+    return _meta_like(x), x.new_empty((2, scale.numel()), dtype=torch.float64)
+
+
+@torch.library.register_fake("torchlsq::lsq_quantize_per_tensor", lib=_lib_def)
+def _fake_quantize_pt(x, scale, shift, *a):
+    return _meta_like(x), torch.empty_like(x, dtype=torch.int8)
+
+
+@torch.library.register_fake("torchlsq::lsq_quantize_per_channel", lib=_lib_def)
+def _fake_quantize_pc(x, scale, shift, axis, *a):
+    return _meta_like(x), torch.empty_like(x, dtype=torch.int8)
+
+
+@torch.library.register_fake("torchlsq::lsq_minmax_per_tensor", lib=_lib_def)
+def _fake_minmax_pt(x):
+    pd = _param_dtype(x)
+    return x.new_empty((), dtype=pd), x.new_empty((), dtype=pd)
+
+
+@torch.library.register_fake("torchlsq::lsq_minmax_per_channel", lib=_lib_def)
+def _fake_minmax_pc(x, axis):
+    pd = _param_dtype(x)
+    return x.new_empty((x.size(axis),), dtype=pd), x.new_empty((x.size(axis),), dtype=pd)
+
+
 # -------------------------------------------------------------------------------------------------
 # autograd (restates lsq_autograd.cpp: forward saves {input, scale, shift} + the scalars, backward
 # calls the backward op through the dispatcher and returns grads for the three tensors only)

@@ -253,3 +253,25 @@ def test_host_mirror_tracks_buffers(oracle_cpu_backend):
     assert mirror(b) == bufs(b) == (1, 1, 0, 3)
     import copy, pickle
     assert mirror(copy.deepcopy(b)) == mirror(b) and mirror(pickle.loads(pickle.dumps(b))) == mirror(b)
+
+
+def test_ops_trace_under_torch_compile(oracle_cpu_backend):
+    """every op has a shape-only (fake) kernel, so the dispatcher path traces (aot_eager: no codegen involved)"""
+    x = torch.randn(4, 8, 6, 6)
+    s, b = torch.full((8,), 0.05, requires_grad=True), torch.zeros(8, requires_grad=True)
+
+    def f(x, s, b):
+        y = torch.ops.torchlsq.lsq(x, s, b, -8, 7, -128, 127, 1, True, 1.0, True, True, False, False)
+        return (y * y).sum()
+
+    ref = f(x, s, b)
+    gs_ref = torch.autograd.grad(ref, (s, b))
+    out = torch.compile(f, backend="aot_eager")(x, s, b)
+    gs = torch.autograd.grad(out, (s, b))
+    assert torch.equal(out, ref) and all(torch.equal(a, c) for a, c in zip(gs, gs_ref))
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        fx = torch.empty(4, 8, 6, 6)
+        mn, mx = torch.ops.torchlsq.lsq_minmax_per_channel(fx, 1)
+        yq, q = torch.ops.torchlsq.lsq_quantize_per_tensor(fx, torch.empty(1), torch.empty(1), 0, 127, 0, 255, 0)
+        assert mn.shape == (8,) and q.dtype == torch.int8 and q.shape == fx.shape
