@@ -73,14 +73,15 @@ typedef struct lsq_params {
     int64_t numel_for_scaler;
 } lsq_params;
 
-/* Optional extra outputs of the forward (NULL = not wanted).
- *  levels: int8 quantised integer level of every element,
- *          q = rne(clamp(x/s + zp, quant_min, quant_max))  (lsq_kernel.h:13), stored as
- *          (int8_t)(q - level_bias); level_bias lets quint8 ranges (0..255) fit (use 128). */
+/* Optional extra output of the forward: ONE auxiliary byte per element, laid out like y (NULL = not wanted).
+ *  aux_kind 0 -- integer levels: q = rne(clamp(x/s + zp, quant_min, quant_max))  (lsq_kernel.h:13), stored
+ *                as (int8_t)(q - level_bias); level_bias lets quint8 ranges (0..255) fit (use 128).
+ *  aux_kind 1 -- inside mask: 1 where quant_min < clamp(..) < quant_max strictly, else 0: everything the
+ *                eval-mode backward needs (lsq_kernel.h:126-145), see lsq_hip_backward_from_mask. */
 typedef struct lsq_fwd_extras {
     void* levels;
     int32_t level_bias;
-    int32_t reserved;
+    int32_t aux_kind;
 } lsq_fwd_extras;
 
 /* ---- library / build information -------------------------------------------------------- */
@@ -142,6 +143,14 @@ int lsq_hip_backward_per_channel(int dtype, const void* grad, const void* x, voi
                                  int64_t inner, const void* scale, const void* shift,
                                  const lsq_params* p, void* workspace, size_t workspace_bytes,
                                  void* stream);
+
+/* ---- eval-mode backward from the saved mask ---------------------------------------------------- */
+
+/* dx = grad * mask for the eval-mode / plain fake-quantizer backward (lsq_kernel.h:126-145: dX only,
+ * d_scale = d_shift = 0), per-tensor and per-channel alike: reads grad + 1 byte per element instead of
+ * grad + x (9 instead of 12 bytes per fp32 element) and lets autograd keep the 1-byte mask instead of x.
+ * `mask` is the aux_kind = 1 output of the forward, same memory order as grad / dx. */
+int lsq_hip_backward_from_mask(int dtype, const void* grad, const void* mask, void* dx, int64_t n, void* stream);
 
 /* ---- observer statistics (init phase) ------------------------------------------------------ */
 

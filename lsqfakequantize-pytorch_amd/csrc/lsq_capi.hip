@@ -41,7 +41,7 @@ int check_common(int dtype, const lsq_params* p) {
 }
 
 int check_levels(const lsq_params* p, const lsq_fwd_extras* ex) {
-    if (ex && ex->levels) {
+    if (ex && ex->levels && ex->aux_kind == 0) {
         const int lo = p->quant_min - ex->level_bias, hi = p->quant_max - ex->level_bias;
         if (lo < -128 || hi > 127)
             return fail(LSQ_EINVAL, "levels: [quant_min, quant_max] - level_bias = [%d, %d] does not fit int8", lo, hi);
@@ -187,6 +187,16 @@ int lsq_hip_backward_per_channel(int dtype, const void* grad, const void* x, voi
                                  size_t workspace_bytes, void* stream) {
     return lsq_hip_backward_per_channel_ex(dtype, grad, x, dx, ds, db, dsdb_wide, outer, channels, inner, scale, shift,
                                            p, workspace, workspace_bytes, stream, 0);
+}
+
+int lsq_hip_backward_from_mask(int dtype, const void* grad, const void* mask, void* dx, int64_t n, void* stream) {
+    if (!dtype_ok(dtype)) return fail(LSQ_EINVAL, "unknown dtype code %d", dtype);
+    if (n < 0) return fail(LSQ_EINVAL, "negative element count");
+    if (n == 0) return LSQ_OK;
+    if (!grad || !mask || !dx) return fail(LSQ_EINVAL, "backward_from_mask: NULL buffer");
+    hipError_t e = hipSuccess;
+    LSQ_DISPATCH_IO(dtype, e = lsq::backward_from_mask<IO>(grad, mask, dx, n, static_cast<hipStream_t>(stream)));
+    return hip_status(e, "lsq_hip_backward_from_mask");
 }
 
 void lsq_hip_debug_set_observe_wg_per_cu(int v) { lsq::set_observe_wg_per_cu(v); }

@@ -165,6 +165,21 @@ struct LevelPack {
             for (int j = 0; j < VEC; ++j) dst[j] = b[j];
         }
     }
+    __device__ __forceinline__ void load(const int8_t* src) {
+        if constexpr (VEC == 8) {
+            const uint64_t w = *reinterpret_cast<const uint64_t*>(src);
+            __builtin_memcpy(b, &w, 8);
+        } else if constexpr (VEC == 4) {
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(src);
+            __builtin_memcpy(b, &w, 4);
+        } else if constexpr (VEC == 2) {
+            const uint16_t w = *reinterpret_cast<const uint16_t*>(src);
+            __builtin_memcpy(b, &w, 2);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) b[j] = src[j];
+        }
+    }
 };
 
 // ---- entry points implemented in lsq_per_tensor.hip / lsq_per_channel.hip ------------------------
@@ -187,6 +202,9 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
                                 int64_t outer, int64_t channels, int64_t inner, const void* scale,
                                 const void* shift, const lsq_params& p, void* workspace, size_t workspace_bytes,
                                 int variant, hipStream_t stream);
+
+template <typename IO>
+hipError_t backward_from_mask(const void* grad, const void* mask, void* dx, int64_t n, hipStream_t stream);
 
 // observer statistics (lsq_observe.hip)
 void set_observe_wg_per_cu(int v);

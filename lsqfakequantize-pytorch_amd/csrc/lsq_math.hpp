@@ -74,8 +74,20 @@ __device__ __forceinline__ QParams<T> make_qparams(T s_sanitized, T shift, const
 // ---- forward (lsq_kernel.h:6-14) ---------------------------------------------------------------
 // the integer level, still in floating point: FASTROUND(FMIN(qmax, FMAX(qmin, x*inv_s + zp)))
 template <typename T>
+__device__ __forceinline__ T clamped(T x, const QParams<T>& q, const Range<T>& r) {
+    return fmin_(r.qmax, fmax_(r.qmin, x * q.inv_s + q.zp));
+}
+template <typename T>
 __device__ __forceinline__ T level(T x, const QParams<T>& q, const Range<T>& r) {
-    return rne(fmin_(r.qmax, fmax_(r.qmin, x * q.inv_s + q.zp)));
+    return rne(clamped<T>(x, q, r));
+}
+// One auxiliary byte per element next to y (lsq_fwd_extras): either the integer level (minus a bias) or the
+// "strictly inside the range" flag the eval-mode backward needs (lsq_kernel.h:109 / :139; the two clamp
+// orders of forward and backward give the same flag: both put a NaN on a border).
+template <typename T>
+__device__ __forceinline__ int8_t aux_byte(T c, const Range<T>& r, T bias, int aux_kind) {
+    return aux_kind ? static_cast<int8_t>((r.qmin < c) && (c < r.qmax))
+                    : static_cast<int8_t>(static_cast<int>(rne(c) - bias));
 }
 
 template <typename T>

@@ -111,7 +111,7 @@ struct LaneChannels {
 // ------------------------------------------------------------------------------------------------
 template <typename IO, int V, int CPL, bool INIT, bool LEVELS, int UNROLL, bool NTL, bool NTS>
 __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__ x, void* __restrict__ y,
-                                                        int8_t* __restrict__ levels, int level_bias, PcGeom g,
+                                                        int8_t* __restrict__ levels, int level_bias, int aux_kind, PcGeom g,
                                                         const typename IO::arith* __restrict__ scale,
                                                         const typename IO::arith* __restrict__ shift,
                                                         Range<typename IO::arith> r) {
@@ -144,9 +144,9 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
         for (int j = 0; j < V; ++j) {
             const QParams<T> q = ch.params(j);
             const T xv = static_cast<T>(in[j]);
-            const T l = level<T>(xv, q, r);
-            out[j] = static_cast<E>(INIT ? xv : dequant<T>(l, q));
-            if (LEVELS) lv.b[j] = static_cast<int8_t>(static_cast<int>(l - bias));
+            const T c = clamped<T>(xv, q, r);
+            out[j] = static_cast<E>(INIT ? xv : dequant<T>(rne(c), q));
+            if (LEVELS) lv.b[j] = aux_byte<T>(c, r, bias, aux_kind);
         }
         if (valid) {
             store_elems<IO, V, NTS>(y, e, out);
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(kBlock) void finalize_pc_kernel(const double2* __re
 // =================================================================================================
 template <typename IO, int V, bool INIT, bool LEVELS, int UNROLL, bool NTL, bool NTS>
 __global__ __launch_bounds__(kBlock) void fwd_seg_kernel(const void* __restrict__ x, void* __restrict__ y,
-                                                         int8_t* __restrict__ levels, int level_bias, SegGeom g,
+                                                         int8_t* __restrict__ levels, int level_bias, int aux_kind, SegGeom g,
                                                          const typename IO::arith* __restrict__ scale,
                                                          const typename IO::arith* __restrict__ shift,
                                                          Range<typename IO::arith> r) {
@@ -432,9 +432,9 @@ __global__ __launch_bounds__(kBlock) void fwd_seg_kernel(const void* __restrict_
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             const T xv = static_cast<T>(in[j]);
-            const T l = level<T>(xv, q, r);
-            out[j] = static_cast<E>(INIT ? xv : dequant<T>(l, q));
-            if (LEVELS) lv.b[j] = static_cast<int8_t>(static_cast<int>(l - bias));
+            const T c = clamped<T>(xv, q, r);
+            out[j] = static_cast<E>(INIT ? xv : dequant<T>(rne(c), q));
+            if (LEVELS) lv.b[j] = aux_byte<T>(c, r, bias, aux_kind);
         }
         if (valid) {
             store_elems<IO, V, NTS>(y, e, out);
@@ -589,7 +589,7 @@ size_t bwd_pc_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64
 
 // ---- forward --------------------------------------------------------------------------------------
 template <typename IO, int V, int CPL, bool INIT, bool LEVELS>
-static hipError_t launch_fwd_pc(const void* x, void* y, int8_t* levels, int bias, const PcGeom& g, const void* scale,
+static hipError_t launch_fwd_pc(const void* x, void* y, int8_t* levels, int bias, int aux_kind, const PcGeom& g, const void* scale,
                                 const void* shift, const lsq_params& p, const Variant& v, hipStream_t stream) {
     using T = typename IO::arith;
     const Range<T> r = make_range<T>(p);
@@ -597,7 +597,7 @@ static hipError_t launch_fwd_pc(const void* x, void* y, int8_t* levels, int bias
     const size_t lds = static_cast<size_t>(g.k_slots) * sizeof(QSlot<T>);
 #define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                       \
     hipLaunchKernelGGL((fwd_pc_kernel<IO, V, CPL, INIT, LEVELS, U, NTLF, NTSF>), grid, dim3(kBlock), lds, stream, x, y, levels, \
-                       bias, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r)
+                       bias, aux_kind, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r)
     [[maybe_unused]] constexpr bool kFull = !INIT && !LEVELS && V > 1 && CPL <= 2 && !std::is_same<IO, io_f64>::value &&
                                             !std::is_same<IO, io_f16>::value;
     LSQ_DISPATCH_VARIANT(kFull, 4, v, LSQ_LAUNCH);
@@ -606,28 +606,28 @@ static hipError_t launch_fwd_pc(const void* x, void* y, int8_t* levels, int bias
 }
 
 template <typename IO, bool INIT, bool LEVELS>
-static hipError_t launch_fwd_seg(const void* x, void* y, int8_t* levels, int bias, const SegGeom& g, const void* scale,
+static hipError_t launch_fwd_seg(const void* x, void* y, int8_t* levels, int bias, int aux_kind, const SegGeom& g, const void* scale,
                                  const void* shift, const lsq_params& p, const Variant& v, hipStream_t stream) {
     using T = typename IO::arith;
     const Range<T> r = make_range<T>(p);
     const dim3 grid(static_cast<unsigned>(g.C * g.segs), static_cast<unsigned>(g.osplits));
 #define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                      \
     hipLaunchKernelGGL((fwd_seg_kernel<IO, IO::VEC, INIT, LEVELS, U, NTLF, NTSF>), grid, dim3(kBlock), 0, stream, x, y, levels, \
-                       bias, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r)
+                       bias, aux_kind, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r)
     LSQ_DISPATCH_VARIANT(false, 4, v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH
     return hipGetLastError();
 }
 
 template <typename IO, int V, int CPL>
-static hipError_t fwd_pc_modes(const void* x, void* y, int8_t* levels, int bias, const PcGeom& g, const void* scale,
+static hipError_t fwd_pc_modes(const void* x, void* y, int8_t* levels, int bias, int aux_kind, const PcGeom& g, const void* scale,
                                const void* shift, const lsq_params& p, const Variant& v, hipStream_t stream) {
     if (p.init_mode) {
-        return levels ? launch_fwd_pc<IO, V, CPL, true, true>(x, y, levels, bias, g, scale, shift, p, v, stream)
-                      : launch_fwd_pc<IO, V, CPL, true, false>(x, y, levels, bias, g, scale, shift, p, v, stream);
+        return levels ? launch_fwd_pc<IO, V, CPL, true, true>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream)
+                      : launch_fwd_pc<IO, V, CPL, true, false>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream);
     }
-    return levels ? launch_fwd_pc<IO, V, CPL, false, true>(x, y, levels, bias, g, scale, shift, p, v, stream)
-                  : launch_fwd_pc<IO, V, CPL, false, false>(x, y, levels, bias, g, scale, shift, p, v, stream);
+    return levels ? launch_fwd_pc<IO, V, CPL, false, true>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream)
+                  : launch_fwd_pc<IO, V, CPL, false, false>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream);
 }
 
 template <typename IO>
@@ -636,6 +636,7 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
                                const lsq_fwd_extras* ex, int variant, hipStream_t stream) {
     int8_t* levels = ex ? static_cast<int8_t*>(ex->levels) : nullptr;
     const int bias = ex ? ex->level_bias : 0;
+    const int aux_kind = ex ? ex->aux_kind : 0;
     const DeviceInfo& dev = device_info();
     const bool aligned = is_aligned16(x) && is_aligned16(y) && (!levels || (reinterpret_cast<uintptr_t>(levels) & 7u) == 0);
     const int vec = pick_vec(IO::VEC, channels * inner, aligned);
@@ -646,19 +647,19 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
         const SegGeom sg = make_seg_geom(outer, channels, inner, vec, target);
         if (!grid_fits(sg)) return hipErrorInvalidConfiguration;
         if (p.init_mode) {
-            return levels ? launch_fwd_seg<IO, true, true>(x, y, levels, bias, sg, scale, shift, p, v, stream)
-                          : launch_fwd_seg<IO, true, false>(x, y, levels, bias, sg, scale, shift, p, v, stream);
+            return levels ? launch_fwd_seg<IO, true, true>(x, y, levels, bias, aux_kind, sg, scale, shift, p, v, stream)
+                          : launch_fwd_seg<IO, true, false>(x, y, levels, bias, aux_kind, sg, scale, shift, p, v, stream);
         }
-        return levels ? launch_fwd_seg<IO, false, true>(x, y, levels, bias, sg, scale, shift, p, v, stream)
-                      : launch_fwd_seg<IO, false, false>(x, y, levels, bias, sg, scale, shift, p, v, stream);
+        return levels ? launch_fwd_seg<IO, false, true>(x, y, levels, bias, aux_kind, sg, scale, shift, p, v, stream)
+                      : launch_fwd_seg<IO, false, false>(x, y, levels, bias, aux_kind, sg, scale, shift, p, v, stream);
     }
     const int cpl = pick_cpl(vec, inner);
     const PcGeom g = make_geom(outer, channels, inner, vec, target);
     if (!grid_fits(g)) return hipErrorInvalidConfiguration;
-    if (vec == 1) return fwd_pc_modes<IO, 1, 1>(x, y, levels, bias, g, scale, shift, p, v, stream);
-    if (cpl == 1) return fwd_pc_modes<IO, IO::VEC, 1>(x, y, levels, bias, g, scale, shift, p, v, stream);
-    if (cpl == 2) return fwd_pc_modes<IO, IO::VEC, 2>(x, y, levels, bias, g, scale, shift, p, v, stream);
-    return fwd_pc_modes<IO, IO::VEC, IO::VEC>(x, y, levels, bias, g, scale, shift, p, v, stream);
+    if (vec == 1) return fwd_pc_modes<IO, 1, 1>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream);
+    if (cpl == 1) return fwd_pc_modes<IO, IO::VEC, 1>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream);
+    if (cpl == 2) return fwd_pc_modes<IO, IO::VEC, 2>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream);
+    return fwd_pc_modes<IO, IO::VEC, IO::VEC>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream);
 }
 
 // ---- backward -------------------------------------------------------------------------------------

@@ -46,7 +46,7 @@ struct TileWalk {
 // ------------------------------------------------------------------------------------------------
 template <typename IO, bool INIT, bool LEVELS, int UNROLL, bool NTL, bool NTS>
 __global__ __launch_bounds__(kBlock) void fwd_pt_kernel(const void* __restrict__ x, void* __restrict__ y,
-                                                        int8_t* __restrict__ levels, int level_bias,
+                                                        int8_t* __restrict__ levels, int level_bias, int aux_kind,
                                                         int64_t n, const typename IO::arith* __restrict__ scale,
                                                         const typename IO::arith* __restrict__ shift,
                                                         Range<typename IO::arith> r, int chunked) {
@@ -65,9 +65,9 @@ __global__ __launch_bounds__(kBlock) void fwd_pt_kernel(const void* __restrict__
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const T xv = static_cast<T>(in.v[j]);
-            const T l = level<T>(xv, q, r);
-            out.v[j] = static_cast<typename IO::elem>(INIT ? xv : dequant<T>(l, q));  // lsq_kernel.h:13
-            if (LEVELS) lv.b[j] = static_cast<int8_t>(static_cast<int>(l - bias));
+            const T c = clamped<T>(xv, q, r);
+            out.v[j] = static_cast<typename IO::elem>(INIT ? xv : dequant<T>(rne(c), q));  // lsq_kernel.h:13
+            if (LEVELS) lv.b[j] = aux_byte<T>(c, r, bias, aux_kind);
         }
         if (NTS) store_packet_nt<IO>(y, p * VEC, out); else store_packet<IO>(y, p * VEC, out);
         if (LEVELS) lv.store(levels + p * VEC);
@@ -98,9 +98,9 @@ __global__ __launch_bounds__(kBlock) void fwd_pt_kernel(const void* __restrict__
         const int64_t i = n_packets * VEC + threadIdx.x;
         if (i < n) {
             const T xv = IO::load1(x, i);
-            const T l = level<T>(xv, q, r);
-            IO::store1(y, i, INIT ? xv : dequant<T>(l, q));
-            if (LEVELS) levels[i] = static_cast<int8_t>(static_cast<int>(l - bias));
+            const T c = clamped<T>(xv, q, r);
+            IO::store1(y, i, INIT ? xv : dequant<T>(rne(c), q));
+            if (LEVELS) levels[i] = aux_byte<T>(c, r, bias, aux_kind);
         }
     }
 }
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void fwd_pt_kernel(const void* __restrict__
 // scalar fallback for buffers that are not 16-byte aligned (sliced views): 1 element per lane
 template <typename IO, bool INIT, bool LEVELS>
 __global__ __launch_bounds__(kBlock) void fwd_pt_scalar_kernel(const void* __restrict__ x, void* __restrict__ y,
-                                                               int8_t* __restrict__ levels, int level_bias,
+                                                               int8_t* __restrict__ levels, int level_bias, int aux_kind,
                                                                int64_t n, const typename IO::arith* __restrict__ scale,
                                                                const typename IO::arith* __restrict__ shift,
                                                                Range<typename IO::arith> r) {
@@ -118,9 +118,9 @@ __global__ __launch_bounds__(kBlock) void fwd_pt_scalar_kernel(const void* __res
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * kBlock) {
         const T xv = IO::load1(x, i);
-        const T l = level<T>(xv, q, r);
-        IO::store1(y, i, INIT ? xv : dequant<T>(l, q));
-        if (LEVELS) levels[i] = static_cast<int8_t>(static_cast<int>(l - bias));
+        const T c = clamped<T>(xv, q, r);
+        IO::store1(y, i, INIT ? xv : dequant<T>(rne(c), q));
+        if (LEVELS) levels[i] = aux_byte<T>(c, r, bias, aux_kind);
     }
 }
 
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kBlock) void finalize_pt_kernel(const double2* __re
 // host-side launchers
 // ------------------------------------------------------------------------------------------------
 template <typename IO, bool INIT, bool LEVELS>
-static hipError_t launch_fwd_pt(const void* x, void* y, int8_t* levels, int level_bias, int64_t n,
+static hipError_t launch_fwd_pt(const void* x, void* y, int8_t* levels, int level_bias, int aux_kind, int64_t n,
                                 const void* scale, const void* shift, const lsq_params& p, int variant,
                                 hipStream_t stream) {
     using T = typename IO::arith;
@@ -284,7 +284,7 @@ static hipError_t launch_fwd_pt(const void* x, void* y, int8_t* levels, int leve
         const int64_t want = (n + kBlock - 1) / kBlock;
         const int grid = static_cast<int>(std::min<int64_t>(want, static_cast<int64_t>(dev.cu_count) * 16));
         hipLaunchKernelGGL((fwd_pt_scalar_kernel<IO, INIT, LEVELS>), dim3(grid), dim3(kBlock), 0, stream, x, y, levels,
-                           level_bias, n, sc, sh, r);
+                           level_bias, aux_kind, n, sc, sh, r);
         return hipGetLastError();
     }
     const Variant v = decode_variant(variant, kDefaultFwdVariant);
@@ -295,7 +295,7 @@ static hipError_t launch_fwd_pt(const void* x, void* y, int8_t* levels, int leve
     // (the partial tile is owned by workgroup n_full % grid, which exists because grid <= n_tiles)
 #define LSQ_LAUNCH_FWD(U, NTLF, NTSF)                                                                                   \
     hipLaunchKernelGGL((fwd_pt_kernel<IO, INIT, LEVELS, U, NTLF, NTSF>), dim3(grid), dim3(kBlock), 0, stream, x, y, levels, \
-                       level_bias, n, sc, sh, r, v.chunked ? 1 : 0)
+                       level_bias, aux_kind, n, sc, sh, r, v.chunked ? 1 : 0)
     [[maybe_unused]] constexpr bool kFull = std::is_same<IO, io_f32>::value && !INIT && !LEVELS;
     LSQ_DISPATCH_VARIANT(kFull, 4, v, LSQ_LAUNCH_FWD);
 #undef LSQ_LAUNCH_FWD
@@ -307,12 +307,13 @@ hipError_t forward_per_tensor(const void* x, void* y, int64_t n, const void* sca
                               const lsq_params& p, const lsq_fwd_extras* ex, int variant, hipStream_t stream) {
     int8_t* levels = ex ? static_cast<int8_t*>(ex->levels) : nullptr;
     const int bias = ex ? ex->level_bias : 0;
+    const int aux_kind = ex ? ex->aux_kind : 0;
     if (p.init_mode) {
-        return levels ? launch_fwd_pt<IO, true, true>(x, y, levels, bias, n, scale, shift, p, variant, stream)
-                      : launch_fwd_pt<IO, true, false>(x, y, levels, bias, n, scale, shift, p, variant, stream);
+        return levels ? launch_fwd_pt<IO, true, true>(x, y, levels, bias, aux_kind, n, scale, shift, p, variant, stream)
+                      : launch_fwd_pt<IO, true, false>(x, y, levels, bias, aux_kind, n, scale, shift, p, variant, stream);
     }
-    return levels ? launch_fwd_pt<IO, false, true>(x, y, levels, bias, n, scale, shift, p, variant, stream)
-                  : launch_fwd_pt<IO, false, false>(x, y, levels, bias, n, scale, shift, p, variant, stream);
+    return levels ? launch_fwd_pt<IO, false, true>(x, y, levels, bias, aux_kind, n, scale, shift, p, variant, stream)
+                  : launch_fwd_pt<IO, false, false>(x, y, levels, bias, aux_kind, n, scale, shift, p, variant, stream);
 }
 
 int bwd_pt_grid(int64_t n, int vec, const Variant& v, bool aligned) {
@@ -385,12 +386,70 @@ hipError_t backward_per_tensor(const void* grad, const void* x, void* dx, void* 
 #undef LSQ_BWD_CASE
 }
 
+// ------------------------------------------------------------------------------------------------
+// eval-mode backward from the 1-byte inside mask the forward saved: dx = grad * mask
+// ------------------------------------------------------------------------------------------------
+template <typename IO, int UNROLL>
+__global__ __launch_bounds__(kBlock) void bwd_mask_kernel(const void* __restrict__ grad, const int8_t* __restrict__ mask,
+                                                          void* __restrict__ dx, int64_t n, int vec_ok) {
+    using T = typename IO::arith;
+    constexpr int VEC = IO::VEC;
+    const int64_t n_packets = vec_ok ? n / VEC : 0;
+    constexpr int64_t kTile = static_cast<int64_t>(kBlock) * UNROLL;
+    const int64_t n_full = n_packets / kTile;
+    auto emit = [&](const Packet<IO>& gi, const LevelPack<VEC>& m, int64_t p) {
+        Packet<IO> out;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)   // a real multiply, like the reference (inf * 0 = NaN)
+            out.v[j] = static_cast<typename IO::elem>(static_cast<T>(gi.v[j]) * static_cast<T>(m.b[j]));
+        store_packet_nt<IO>(dx, p * VEC, out);
+    };
+    for (int64_t tile = blockIdx.x; tile < n_full; tile += gridDim.x) {
+        const int64_t p0 = tile * kTile + threadIdx.x;
+        Packet<IO> gi[UNROLL];
+        LevelPack<VEC> mi[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t p = p0 + static_cast<int64_t>(u) * kBlock;
+            gi[u] = load_packet_nt<IO>(grad, p * VEC);
+            mi[u].load(mask + p * VEC);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) emit(gi[u], mi[u], p0 + static_cast<int64_t>(u) * kBlock);
+    }
+    if (static_cast<int64_t>(blockIdx.x) == n_full % gridDim.x) {
+        for (int64_t p = n_full * kTile + threadIdx.x; p < n_packets; p += kBlock) {
+            LevelPack<VEC> m;
+            m.load(mask + p * VEC);
+            emit(load_packet<IO>(grad, p * VEC), m, p);
+        }
+    }
+    // element-wise remainder (everything, when the buffers are not aligned for packets)
+    for (int64_t i = n_packets * VEC + static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * kBlock)
+        IO::store1(dx, i, IO::load1(grad, i) * static_cast<T>(mask[i]));
+}
+
+template <typename IO>
+hipError_t backward_from_mask(const void* grad, const void* mask, void* dx, int64_t n, hipStream_t stream) {
+    const DeviceInfo& dev = device_info();
+    const bool aligned = is_aligned16(grad) && is_aligned16(dx) && (reinterpret_cast<uintptr_t>(mask) & 7u) == 0;
+    constexpr int kU = 4;
+    const int64_t tile = static_cast<int64_t>(kBlock) * kU * IO::VEC;
+    const int64_t want = std::max<int64_t>(1, (n + tile - 1) / tile);
+    const int grid = static_cast<int>(std::min<int64_t>(want, static_cast<int64_t>(dev.cu_count) * 8));
+    hipLaunchKernelGGL((bwd_mask_kernel<IO, kU>), dim3(grid), dim3(kBlock), 0, stream, grad,
+                       static_cast<const int8_t*>(mask), dx, n, aligned ? 1 : 0);
+    return hipGetLastError();
+}
+
 // explicit instantiations used by the C ABI (lsq_capi.hip)
 #define LSQ_INSTANTIATE(IO)                                                                                        \
     template hipError_t forward_per_tensor<IO>(const void*, void*, int64_t, const void*, const void*,              \
                                                const lsq_params&, const lsq_fwd_extras*, int, hipStream_t);        \
     template hipError_t backward_per_tensor<IO>(const void*, const void*, void*, void*, void*, double*, int64_t,   \
-                                                const void*, const void*, const lsq_params&, void*, int, hipStream_t);
+                                                const void*, const void*, const lsq_params&, void*, int, hipStream_t); \
+    template hipError_t backward_from_mask<IO>(const void*, const void*, void*, int64_t, hipStream_t);
 LSQ_INSTANTIATE(io_f32)
 LSQ_INSTANTIATE(io_f64)
 LSQ_INSTANTIATE(io_bf16)

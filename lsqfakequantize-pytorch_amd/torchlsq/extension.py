@@ -41,7 +41,7 @@ class LsqParams(ctypes.Structure):
 
 class LsqFwdExtras(ctypes.Structure):
     """struct lsq_fwd_extras (include/lsq_hip.h)."""
-    _fields_ = [("levels", ctypes.c_void_p), ("level_bias", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+    _fields_ = [("levels", ctypes.c_void_p), ("level_bias", ctypes.c_int32), ("aux_kind", ctypes.c_int32)]
 
 
 _vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
@@ -61,6 +61,7 @@ C_ABI = {
     "lsq_hip_forward_per_channel": (_int, [_int, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP, _EP, _vp]),
     "lsq_hip_backward_per_channel": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP, _vp,
                                             _sz, _vp]),
+    "lsq_hip_backward_from_mask": (_int, [_int, _vp, _vp, _vp, _i64, _vp]),
     "lsq_hip_minmax_workspace": (_sz, [_int, _i64, _i64, _i64]),
     "lsq_hip_minmax_per_tensor": (_int, [_int, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "lsq_hip_minmax_per_channel": (_int, [_int, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
@@ -159,6 +160,8 @@ _lib_def.define("lsq_backward_per_tensor_wide(Tensor grad, Tensor x, Tensor scal
 _lib_def.define("lsq_backward_per_channel_wide(Tensor grad, Tensor x, Tensor scale, Tensor shift, int axis, " + _TAIL +
                 ", int numel_for_scaler) -> (Tensor, Tensor)")
 #  * `lsq_minmax*`: one-pass running min/max (torch.aminmax semantics) for the observer init phase.
+#  * `lsq_backward_from_mask`: eval-mode backward from the forward's one-byte inside mask (dx = grad * mask).
+_lib_def.define("lsq_backward_from_mask(Tensor grad, Tensor mask) -> Tensor")
 _lib_def.define("lsq_minmax_per_tensor(Tensor x) -> (Tensor, Tensor)")
 _lib_def.define("lsq_minmax_per_channel(Tensor x, int axis) -> (Tensor, Tensor)")
 _lib_def.define("lsq_quantize_per_tensor(Tensor x, Tensor scale, Tensor shift, int quant_min, int quant_max, "
@@ -326,20 +329,27 @@ def _require_gpu(what, *tensors):
             raise RuntimeError("%s: expected a tensor on the GPU (HIP device) but got device %s" % (what, t.device))
 
 
+def _aux_output(xd, levels_bias, want_mask):
+    """(aux tensor, byref(lsq_fwd_extras)) for the optional one-byte-per-element output of the forward."""
+    if levels_bias is None and not want_mask:
+        return None, None
+    aux = torch.empty_strided(xd.shape, xd.stride(), dtype=torch.int8, device=xd.device)
+    ex = LsqFwdExtras(aux.data_ptr(), 0 if want_mask else int(levels_bias), 1 if want_mask else 0)
+    return aux, ctypes.byref(ex)
+
+
 def hip_forward_per_tensor(x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode,
-                           levels_bias=None, variant=0):
+                           levels_bias=None, variant=0, want_mask=False):
     _assert_has_ops()
     check_forward_dtypes(x, scale, shift)
     _require_gpu("lsq_forward_per_tensor", x, scale, shift)
     xd, _ = _dense(x)
     y = torch.empty_like(xd)
     n = xd.numel()
+    has_aux = levels_bias is not None or want_mask
     if n == 0:
-        return (y, torch.empty(x.shape, dtype=torch.int8, device=x.device)) if levels_bias is not None else y
-    lv, ex = None, None
-    if levels_bias is not None:
-        lv = torch.empty_strided(xd.shape, xd.stride(), dtype=torch.int8, device=x.device)
-        ex = ctypes.byref(LsqFwdExtras(lv.data_ptr(), int(levels_bias), 0))
+        return (y, torch.empty(x.shape, dtype=torch.int8, device=x.device)) if has_aux else y
+    lv, ex = _aux_output(xd, levels_bias, want_mask)
     _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
     scale_c, shift_c = scale.contiguous(), shift.contiguous()
     idx = x.device.index
@@ -347,7 +357,7 @@ def hip_forward_per_tensor(x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, 
                     scale_c.data_ptr(), shift_c.data_ptr(), pref, ex, _stream_of(idx), variant)
     if rc:
         _status(rc, "lsq_hip_forward_per_tensor")
-    return (y, lv) if levels_bias is not None else y
+    return (y, lv) if has_aux else y
 
 
 def hip_backward_per_tensor(grad, x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode,
@@ -385,20 +395,18 @@ def hip_backward_per_tensor(grad, x, scale, shift, qmin, qmax, tmin, tmax, use_g
 
 
 def hip_forward_per_channel(x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode,
-                            levels_bias=None, variant=0):
+                            levels_bias=None, variant=0, want_mask=False):
     _assert_has_ops()
     check_forward_dtypes(x, scale, shift)
     check_channel_args(x, scale, shift, axis, backward=False)
     _require_gpu("lsq_forward_per_channel", x, scale, shift)
     xd, order = _dense(x)
     y = torch.empty_like(xd)
+    has_aux = levels_bias is not None or want_mask
     if x.numel() == 0:
-        return (y, torch.empty(x.shape, dtype=torch.int8, device=x.device)) if levels_bias is not None else y
+        return (y, torch.empty(x.shape, dtype=torch.int8, device=x.device)) if has_aux else y
     outer, C, inner = _ocl(xd, order, axis)
-    lv, ex = None, None
-    if levels_bias is not None:
-        lv = torch.empty_strided(xd.shape, xd.stride(), dtype=torch.int8, device=x.device)
-        ex = ctypes.byref(LsqFwdExtras(lv.data_ptr(), int(levels_bias), 0))
+    lv, ex = _aux_output(xd, levels_bias, want_mask)
     _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
     scale_c, shift_c = scale.contiguous(), shift.contiguous()
     idx = x.device.index
@@ -406,7 +414,30 @@ def hip_forward_per_channel(x, scale, shift, axis, qmin, qmax, tmin, tmax, use_g
                     C, inner, scale_c.data_ptr(), shift_c.data_ptr(), pref, ex, _stream_of(idx), variant)
     if rc:
         _status(rc, "lsq_hip_forward_per_channel")
-    return (y, lv) if levels_bias is not None else y
+    return (y, lv) if has_aux else y
+
+
+def hip_backward_from_mask(grad, mask):
+    """dx = grad * mask: the eval-mode backward (lsq_kernel.h:126-145) from the one-byte inside mask the
+    forward saved (`want_mask=True`) -- per-tensor and per-channel alike."""
+    _assert_has_ops()
+    _check(grad.dtype in _DTYPE_CODE, '"lsq_backward" not implemented for \'%s\'' % str(grad.dtype).replace("torch.", ""))
+    _check(mask.dtype == torch.int8 and mask.numel() == grad.numel(), "`mask` must be the int8 inside mask of the forward")
+    _require_gpu("lsq_backward_from_mask", grad, mask)
+    if grad.shape == mask.shape and grad.stride() == mask.stride():
+        gd = grad
+    else:
+        gd = torch.empty_strided(mask.shape, mask.stride(), dtype=grad.dtype, device=grad.device)
+        gd.copy_(grad.reshape(mask.shape) if grad.shape != mask.shape else grad)
+    dx = torch.empty_strided(mask.shape, mask.stride(), dtype=grad.dtype, device=grad.device)
+    if grad.numel() == 0:
+        return dx
+    idx = grad.device.index
+    rc = _on_device(idx, _LIB.lsq_hip_backward_from_mask, _DTYPE_CODE[grad.dtype], gd.data_ptr(), mask.data_ptr(),
+                    dx.data_ptr(), gd.numel(), _stream_of(idx))
+    if rc:
+        _status(rc, "lsq_hip_backward_from_mask")
+    return dx
 
 
 def _pc_workspace_bytes(idx, code, outer, C, inner):
@@ -555,6 +586,7 @@ _lib_hip.impl("lsq_backward_per_tensor_wide", _impl_bwd_pt_wide)
 _lib_hip.impl("lsq_backward_per_channel_wide", _impl_bwd_pc_wide)
 _lib_hip.impl("lsq_quantize_per_tensor", _impl_quantize_pt)
 _lib_hip.impl("lsq_quantize_per_channel", _impl_quantize_pc)
+_lib_hip.impl("lsq_backward_from_mask", hip_backward_from_mask)
 _lib_hip.impl("lsq_minmax_per_tensor", _impl_minmax_pt)
 _lib_hip.impl("lsq_minmax_per_channel", _impl_minmax_pc)
 
@@ -604,6 +636,11 @@ def _fake_quantize_pt(x, scale, shift, *a):
 @torch.library.register_fake("torchlsq::lsq_quantize_per_channel", lib=_lib_def)
 def _fake_quantize_pc(x, scale, shift, axis, *a):
     return _meta_like(x), torch.empty_like(x, dtype=torch.int8)
+
+
+@torch.library.register_fake("torchlsq::lsq_backward_from_mask", lib=_lib_def)
+def _fake_bwd_mask(grad, mask):
+    return torch.empty_strided(mask.shape, mask.stride(), dtype=grad.dtype, device=grad.device)
 
 
 @torch.library.register_fake("torchlsq::lsq_minmax_per_tensor", lib=_lib_def)

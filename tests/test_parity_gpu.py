@@ -574,3 +574,45 @@ def test_steady_state_forward_backward_never_synchronises(dev):
         torch.cuda.set_sync_debug_mode("default")
     torch.cuda.synchronize()
     assert int(act.current_batch[0]) == 2 and act._h["batch"] == 2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16])
+def test_eval_mode_masked_backward(dev, dtype):
+    """eval mode through functional.lsq: the forward saves a 1-byte inside mask instead of x and the backward is
+    dx = grad * mask; results must equal the reference-style eval backward (op level, from x) bit for bit."""
+    from torchlsq import synth
+    from torchlsq.functional import lsq
+    ops = torch.ops.torchlsq
+    pdt = torch.float64 if dtype == torch.float64 else torch.float32
+    for shape, pc, axis in (((4, 16, 7, 7), False, 1), ((4, 16, 7, 7), True, 1), ((32, 16, 3, 3), True, 0), ((10007,), False, 0)):
+        n = int(np.prod(shape))
+        x = synth.normal_like(n, 81, 0.5, 1.0, dtype=dtype, device=dev).view(shape)
+        g = synth.normal_like(n, 82, 0.0, 1.0, dtype=dtype, device=dev).view(shape)
+        g.view(-1)[3] = float("inf")                      # a real multiply: inf * 0 = NaN, like the reference
+        C = shape[axis] if pc else 1
+        s = synth.uniform_like(C, 83, 0.05, 0.2, dtype=pdt, device=dev).requires_grad_(True)
+        b = synth.normal_like(C, 84, 0.0, 0.1, dtype=pdt, device=dev).requires_grad_(True)
+        xr = x.clone().requires_grad_(True)
+        y = lsq(xr, s, b, -8, 7, -128, 127, axis, True, 1.0, True, pc, eval_mode=True)
+        assert y.grad_fn is not None and all(t.dtype == torch.int8 or t.numel() == C for t in y.grad_fn.saved_tensors)
+        y.backward(g)
+        if pc:
+            y0 = ops.lsq_forward_per_channel(x, s.detach(), b.detach(), axis, -8, 7, -128, 127, True, 1.0, False, True, False)
+            dx0, ds0, db0 = ops.lsq_backward_per_channel(g, x, s.detach(), b.detach(), axis, -8, 7, -128, 127, True, 1.0,
+                                                         False, True, False)
+        else:
+            y0 = ops.lsq_forward_per_tensor(x, s.detach(), b.detach(), -8, 7, -128, 127, True, 1.0, False, True, False)
+            dx0, ds0, db0 = ops.lsq_backward_per_tensor(g, x, s.detach(), b.detach(), -8, 7, -128, 127, True, 1.0, False, True, False)
+        assert torch.equal(y.detach(), y0)
+        a, c = xr.grad, dx0
+        assert torch.equal(a.isnan(), c.isnan()) and torch.equal(a[~a.isnan()], c[~c.isnan()])
+        assert torch.equal(s.grad, torch.zeros_like(s)) and torch.equal(b.grad, torch.zeros_like(b))
+        assert float(ds0.abs().sum()) == 0.0 and float(db0.abs().sum()) == 0.0
+    # channels-last input: the mask keeps the layout, a contiguous grad is re-laid
+    x = torch.randn(2, 8, 5, 5, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    s1, b1 = torch.tensor([0.1], device=dev), torch.tensor([0.0], device=dev)
+    y = lsq(x, s1, b1, 0, 15, 0, 255, eval_mode=True)
+    y.backward(torch.ones(2, 8, 5, 5, device=dev))
+    dx0, _, _ = ops.lsq_backward_per_tensor(torch.ones(2, 8, 5, 5, device=dev), x.detach(), s1, b1, 0, 15, 0, 255, True, 1.0,
+                                            False, True, False)
+    assert torch.equal(x.grad, dx0)
