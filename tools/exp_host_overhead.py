@@ -29,5 +29,5 @@ for name, fn in (("fwd op", loop_fwd_op), ("bwd op", loop_bwd_op), ("fwd direct"
     fn(); torch.cuda.synchronize()
     t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); t = time.perf_counter() - t0
     print("%-16s %.2f us per call" % (name, t / N * 1e6))
-pr = cProfile.Profile(); pr.enable(); loop_fwd_op(); loop_bwd_op(); pr.disable(); torch.cuda.synchronize()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(22)
+pr = cProfile.Profile(); pr.enable(); loop_autograd(); pr.disable(); torch.cuda.synchronize()
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(16)
