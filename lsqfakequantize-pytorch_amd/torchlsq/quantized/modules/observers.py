@@ -325,19 +325,20 @@ class LSQFakeQuantizer(ObserverBase):
         (shift = -zero_point * scale) (reference :346-373)."""
         if self.scale is None:
             self._init_weights(None, _init_device=_init_device)   # per-tensor technical init
-        if scale is not None:
+
+        def overwrite(param, value):
             with torch.no_grad():
-                scale = scale.to(self.scale.device).to(self.scale.dtype)
-                scale.resize_(self.scale.shape)
-            self.scale.data.copy_(scale)
-        if zero_point is not None:
+                value = value.to(device=param.device, dtype=param.dtype)
+                value.resize_(param.shape)
+            param.data.copy_(value)
+
+        if scale is not None:
+            overwrite(self.scale, scale)
+        if zero_point is not None:      # shift = -zero_point * scale, with the (possibly just updated) scale
             with torch.no_grad():
                 shift = -zero_point.to(self.scale.device) * self.scale.detach()
         if shift is not None:
-            with torch.no_grad():
-                shift = shift.to(self.shift.device).to(self.shift.dtype)
-                shift.resize_(self.shift.shape)
-            self.shift.data.copy_(shift)
+            overwrite(self.shift, shift)
 
     def set_weights(self, scale, zero_point=None, _init_device=torch.device('cpu')):
         self._set_weights(scale, shift=None, zero_point=zero_point, _init_device=_init_device)
@@ -355,14 +356,14 @@ class LSQFakeQuantizer(ObserverBase):
     def calculate_qparams(self, verbose=True, need_shift=False) -> Tuple[Tensor, Tensor]:
         if not self._initialized:
             if verbose:
-                print("Scale and Zero Point are not initialized properly, because  LSQObserver was never called.\
-                       You must at least run model on random tensor, before calling convert!\
-                       Returned init_scale and init_zero_point")
+                print("Scale and Zero Point are not initialized properly, because  LSQObserver was never called."
+                      "                       You must at least run model on random tensor, before calling convert!"
+                      "                       Returned init_scale and init_zero_point")
             zp = self.convert_shift_to_zp(torch.tensor(self.init_shift), torch.tensor(self.init_scale),
                                           self.dtype).item()
             return (self.init_scale, self.init_shift, zp) if need_shift else (self.init_scale, zp)
-        scale = torch.max(self.scale.detach().clone().cpu(), torch.tensor(torch.finfo(torch.float32).eps))
-        shift = self.shift.detach().clone().cpu()
+        eps = torch.tensor(torch.finfo(torch.float32).eps)
+        scale, shift = torch.max(self.scale.detach().clone().cpu(), eps), self.shift.detach().clone().cpu()
         zero_point = self.convert_shift_to_zp(shift, scale, self.dtype)
         return (scale, shift, zero_point) if need_shift else (scale, zero_point)
 
@@ -399,9 +400,9 @@ class LSQFakeQuantizer(ObserverBase):
             tmin, tmax = TYPES_RANGE_MAPPING[self.dtype]['range']
             self.scale.requires_grad = full_lsq
             self.shift.requires_grad = full_lsq and self.is_affine
-            return lsq(x, self.scale, self.shift, self.quant_min, self.quant_max, tmin, tmax,
-                       self.ch_axis, self.use_grad_scaling, self.grad_scaler,
-                       self.is_affine, self.is_perchannel,
+            return lsq(x, self.scale, self.shift, quant_min=self.quant_min, quant_max=self.quant_max,
+                       type_min=tmin, type_max=tmax, axis=self.ch_axis, use_grad_scaling=self.use_grad_scaling,
+                       grad_scaler=self.grad_scaler, is_affine=self.is_affine, is_perchannel=self.is_perchannel,
                        eval_mode=(not full_lsq), init_mode=backprop_init)
         return x
 
