@@ -1,0 +1,331 @@
+// lsq_torch_binding.cpp -- the host-only torch binding of liblsq_hip.so: INTEGRATION.md section 1 as code.
+//
+// What a maintainer of the reference would put in place of csrc/ops/cuda/lsq_cuda.cu plus
+// csrc/ops/autograd/lsq_autograd.cpp: no device code, only tensor bookkeeping (checks, dense layout,
+// output / workspace allocation from the caching allocator, current stream) around the C ABI of
+// include/lsq_hip.h.  Compiled with g++ (no hipcc) into torchlsq/_lsq_torch.so and registered under the
+// namespace `torchlsq_native`, so it lives next to the torch.library registration of torchlsq/extension.py
+// (namespace `torchlsq`, ctypes) instead of fighting it for the same operator names:
+//
+//   torchlsq_native::lsq_forward_per_tensor / lsq_backward_per_tensor      <- lsq_cuda.cu:18-61 / 64-143
+//   torchlsq_native::lsq_forward_per_channel / lsq_backward_per_channel    <- lsq_cuda.cu:147-199 / 202-297
+//   torchlsq_native::lsq_backward_from_mask                                 (eval-mode backward, 1-byte mask)
+//   torchlsq_native::lsq                                                    <- lsq.cpp:104-134 + lsq_autograd.cpp
+//
+// torchlsq.functional.lsq uses torchlsq_native::lsq for GPU tensors when this library is present: one
+// dispatcher call and a C++ autograd node instead of a Python autograd.Function (host cost per
+// forward+backward of a small layer: see DESIGN.md section 7).
+#include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/csrc/autograd/custom_function.h>
+#include <torch/library.h>
+
+#include <array>
+#include <limits>
+#include <tuple>
+#include <vector>
+
+#include "lsq_hip.h"
+
+namespace {
+
+using at::Tensor;
+
+struct Scalars {
+    int64_t qmin, qmax, tmin, tmax;
+    bool use_gs;
+    double gs;
+    bool sym, eval_mode, init_mode;
+};
+
+int dtype_code(at::ScalarType t, const char* what) {
+    switch (t) {
+        case at::kFloat: return LSQ_F32;
+        case at::kDouble: return LSQ_F64;
+        case at::kBFloat16: return LSQ_BF16;
+        case at::kHalf: return LSQ_F16;
+        default: TORCH_CHECK(false, "\"", what, "\" not implemented for '", c10::toString(t), "'");
+    }
+}
+
+// scale/shift type for input type t: the same (lsq_cpu.cpp:28-29); 16-bit storage takes fp32 parameters.
+at::ScalarType param_type(at::ScalarType t) { return (t == at::kBFloat16 || t == at::kHalf) ? at::kFloat : t; }
+
+int32_t narrow(int64_t v, const char* name) {
+    TORCH_CHECK(v >= std::numeric_limits<int32_t>::min() && v <= std::numeric_limits<int32_t>::max(), name, "=", v,
+                " does not fit a 32-bit integer");
+    return static_cast<int32_t>(v);
+}
+
+lsq_params pack(const Scalars& s) {
+    lsq_params p;
+    p.quant_min = narrow(s.qmin, "quant_min");
+    p.quant_max = narrow(s.qmax, "quant_max");
+    p.type_min = narrow(s.tmin, "type_min");
+    p.type_max = narrow(s.tmax, "type_max");
+    p.use_grad_scaling = s.use_gs;
+    p.sym = s.sym;
+    p.eval_mode = s.eval_mode;
+    p.init_mode = s.init_mode;
+    p.grad_scaler = s.gs;
+    p.numel_for_scaler = 0;
+    return p;
+}
+
+void status(int rc, const char* what) { TORCH_CHECK(rc == 0, what, " failed (", rc, "): ", lsq_hip_last_error()); }
+
+void require_gpu(const char* what, std::initializer_list<const Tensor*> ts) {
+    for (const Tensor* t : ts)
+        TORCH_CHECK(t->is_cuda(), what, ": expected a tensor on the GPU (HIP device) but got device ", t->device());
+}
+
+void check_forward_types(const Tensor& x, const Tensor& scale, const Tensor& shift) {
+    dtype_code(x.scalar_type(), "lsq_forward");
+    const auto pt = param_type(x.scalar_type());
+    TORCH_CHECK(scale.scalar_type() == pt, "`input` and `scale` must have the same floating-point type");
+    TORCH_CHECK(shift.scalar_type() == pt, "`input` and `shift` must have the same floating-point type");
+}
+
+void check_backward_types(const Tensor& grad, const Tensor& x, const Tensor& scale, const Tensor& shift) {
+    dtype_code(x.scalar_type(), "lsq_backward");
+    const auto pt = param_type(x.scalar_type());
+    TORCH_CHECK(grad.scalar_type() == x.scalar_type(), "`grad` and `input` must have the same floating-point type");
+    TORCH_CHECK(scale.scalar_type() == pt, "`grad` and `scale` must have the same floating-point type");
+    TORCH_CHECK(shift.scalar_type() == pt, "`grad` and `shift` must have the same floating-point type");
+    TORCH_CHECK(x.numel() == grad.numel(), "`x` and `grad` are not the same size");
+}
+
+void check_channel_args(const Tensor& x, const Tensor& scale, const Tensor& shift, int64_t axis) {
+    TORCH_CHECK(scale.numel() == shift.numel(), "scale and shift need to have the same dimensions");
+    TORCH_CHECK(axis >= 0 && axis < x.dim(), "`axis` must be between 0 and number of dimensions of input");
+    TORCH_CHECK(scale.numel() == x.size(axis), "dimensions of scale and shift are not consistent with input tensor");
+}
+
+// The kernels see dense memory.  Channel geometry of dense `t` along `axis` in MEMORY order -- the
+// [outer, C, inner] view of lsq_hip.h -- for any permutation of a contiguous tensor (channels-last
+// included); a tensor that is not dense is replaced by a contiguous copy first.
+struct Geometry {
+    int64_t outer, channels, inner;
+};
+
+Tensor dense(const Tensor& t) { return t.is_non_overlapping_and_dense() ? t : t.contiguous(); }
+
+Geometry geometry(const Tensor& t, int64_t axis) {
+    const int64_t c = t.size(axis);
+    if (c == 1) return {1, 1, t.numel()};  // one channel covering the whole tensor
+    // dims slower than `axis` in memory have a larger stride (ties cannot happen between non-unit dims of a dense tensor)
+    int64_t outer = 1, inner = 1;
+    const int64_t sa = t.stride(axis);
+    for (int64_t d = 0; d < t.dim(); ++d) {
+        if (d == axis || t.size(d) == 1) continue;
+        if (t.stride(d) > sa) outer *= t.size(d);
+        else inner *= t.size(d);
+    }
+    return {outer, c, inner};
+}
+
+Tensor like_layout(const Tensor& g, const Tensor& xd) {
+    if (g.sizes() == xd.sizes() && g.strides() == xd.strides()) return g;
+    Tensor out = at::empty_like(xd);  // preserve_format keeps the strides of the dense xd
+    out.copy_(g.sizes() == xd.sizes() ? g : g.reshape(xd.sizes()));
+    return out;
+}
+
+void* stream_of(const Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+Tensor byte_workspace(const Tensor& like, size_t nbytes) {
+    return at::empty({static_cast<int64_t>(nbytes < 256 ? 256 : nbytes)}, like.options().dtype(at::kByte));
+}
+
+// ---- the four kernels of the reference + the masked eval backward --------------------------------------
+
+std::tuple<Tensor, Tensor> forward_impl(const Tensor& x, const Tensor& scale, const Tensor& shift, bool per_channel,
+                                        int64_t axis, const Scalars& s, bool want_mask) {
+    check_forward_types(x, scale, shift);
+    if (per_channel) check_channel_args(x, scale, shift, axis);
+    require_gpu(per_channel ? "lsq_forward_per_channel" : "lsq_forward_per_tensor", {&x, &scale, &shift});
+    const Tensor xd = dense(x);
+    Tensor y = at::empty_like(xd);
+    Tensor mask;
+    if (want_mask) mask = at::empty_strided(xd.sizes(), xd.strides(), xd.options().dtype(at::kChar));
+    if (xd.numel() == 0) return {y, mask};
+    const lsq_params p = pack(s);
+    const lsq_fwd_extras ex{want_mask ? mask.data_ptr() : nullptr, 0, 1};
+    const Tensor sc = scale.contiguous(), sh = shift.contiguous();
+    const int code = dtype_code(x.scalar_type(), "lsq_forward");
+    c10::DeviceGuard guard(x.device());
+    if (per_channel) {
+        const Geometry g = geometry(xd, axis);
+        status(lsq_hip_forward_per_channel(code, xd.data_ptr(), y.data_ptr(), g.outer, g.channels, g.inner, sc.data_ptr(),
+                                           sh.data_ptr(), &p, want_mask ? &ex : nullptr, stream_of(x)),
+               "lsq_hip_forward_per_channel");
+    } else {
+        status(lsq_hip_forward_per_tensor(code, xd.data_ptr(), y.data_ptr(), xd.numel(), sc.data_ptr(), sh.data_ptr(), &p,
+                                          want_mask ? &ex : nullptr, stream_of(x)),
+               "lsq_hip_forward_per_tensor");
+    }
+    return {y, mask};
+}
+
+std::tuple<Tensor, Tensor, Tensor> backward_impl(const Tensor& grad, const Tensor& x, const Tensor& scale,
+                                                 const Tensor& shift, bool per_channel, int64_t axis, const Scalars& s) {
+    check_backward_types(grad, x, scale, shift);
+    if (per_channel) check_channel_args(x, scale, shift, axis);
+    if (x.numel() <= 0) return {x.clone(), scale.clone(), shift.clone()};  // lsq_cpu.cpp:76-78,221-223
+    require_gpu(per_channel ? "lsq_backward_per_channel" : "lsq_backward_per_tensor", {&grad, &x, &scale, &shift});
+    const Tensor xd = dense(x);
+    const Tensor gd = like_layout(grad, xd);
+    Tensor dx = at::empty_like(xd);
+    const lsq_params p = pack(s);
+    const Tensor sc = scale.contiguous(), sh = shift.contiguous();
+    const int code = dtype_code(x.scalar_type(), "lsq_backward");
+    const auto popt = x.options().dtype(param_type(x.scalar_type()));
+    c10::DeviceGuard guard(x.device());
+    if (per_channel) {
+        const Geometry g = geometry(xd, axis);
+        Tensor ds = at::empty({g.channels}, popt), db = at::empty({g.channels}, popt);
+        const Tensor ws = byte_workspace(x, lsq_hip_backward_per_channel_workspace(code, g.outer, g.channels, g.inner));
+        status(lsq_hip_backward_per_channel(code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(), ds.data_ptr(), db.data_ptr(),
+                                            nullptr, g.outer, g.channels, g.inner, sc.data_ptr(), sh.data_ptr(), &p,
+                                            ws.data_ptr(), static_cast<size_t>(ws.numel()), stream_of(x)),
+               "lsq_hip_backward_per_channel");
+        return {dx, ds, db};
+    }
+    Tensor ds = at::empty({1}, popt), db = at::empty({1}, popt);
+    const Tensor ws = byte_workspace(x, lsq_hip_backward_per_tensor_workspace(code, xd.numel()));
+    status(lsq_hip_backward_per_tensor(code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(), ds.data_ptr(), db.data_ptr(), nullptr,
+                                       xd.numel(), sc.data_ptr(), sh.data_ptr(), &p, ws.data_ptr(),
+                                       static_cast<size_t>(ws.numel()), stream_of(x)),
+           "lsq_hip_backward_per_tensor");
+    return {dx, ds, db};
+}
+
+Tensor backward_from_mask(const Tensor& grad, const Tensor& mask) {
+    const int code = dtype_code(grad.scalar_type(), "lsq_backward");
+    TORCH_CHECK(mask.scalar_type() == at::kChar && mask.numel() == grad.numel(),
+                "`mask` must be the int8 inside mask of the forward");
+    require_gpu("lsq_backward_from_mask", {&grad, &mask});
+    Tensor gd = grad;
+    if (!(grad.sizes() == mask.sizes() && grad.strides() == mask.strides())) {
+        gd = at::empty_strided(mask.sizes(), mask.strides(), grad.options());
+        gd.copy_(grad.sizes() == mask.sizes() ? grad : grad.reshape(mask.sizes()));
+    }
+    Tensor dx = at::empty_strided(mask.sizes(), mask.strides(), grad.options());
+    if (grad.numel() == 0) return dx;
+    c10::DeviceGuard guard(grad.device());
+    status(lsq_hip_backward_from_mask(code, gd.data_ptr(), mask.data_ptr(), dx.data_ptr(), gd.numel(), stream_of(grad)),
+           "lsq_hip_backward_from_mask");
+    return dx;
+}
+
+// ---- operator-level wrappers (schemas of lsq.cpp:138-145) -----------------------------------------------
+
+Tensor forward_per_tensor(const Tensor& x, const Tensor& scale, const Tensor& shift, int64_t qmin, int64_t qmax,
+                          int64_t tmin, int64_t tmax, bool use_gs, double gs, bool sym, bool eval_mode, bool init_mode) {
+    return std::get<0>(forward_impl(x, scale, shift, false, 0, {qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode}, false));
+}
+
+std::tuple<Tensor, Tensor, Tensor> backward_per_tensor(const Tensor& grad, const Tensor& x, const Tensor& scale,
+                                                       const Tensor& shift, int64_t qmin, int64_t qmax, int64_t tmin,
+                                                       int64_t tmax, bool use_gs, double gs, bool sym, bool eval_mode,
+                                                       bool init_mode) {
+    return backward_impl(grad, x, scale, shift, false, 0, {qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode});
+}
+
+Tensor forward_per_channel(const Tensor& x, const Tensor& scale, const Tensor& shift, int64_t axis, int64_t qmin,
+                           int64_t qmax, int64_t tmin, int64_t tmax, bool use_gs, double gs, bool sym, bool eval_mode,
+                           bool init_mode) {
+    return std::get<0>(forward_impl(x, scale, shift, true, axis, {qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode}, false));
+}
+
+std::tuple<Tensor, Tensor, Tensor> backward_per_channel(const Tensor& grad, const Tensor& x, const Tensor& scale,
+                                                        const Tensor& shift, int64_t axis, int64_t qmin, int64_t qmax,
+                                                        int64_t tmin, int64_t tmax, bool use_gs, double gs, bool sym,
+                                                        bool eval_mode, bool init_mode) {
+    return backward_impl(grad, x, scale, shift, true, axis, {qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode});
+}
+
+// ---- autograd node: LSQPerTensorFunction / LSQPerChannelFunction of lsq_autograd.cpp:16-74,111-173 in one ----
+// saves {input, scale, shift} (or {mask, scale, shift} in eval mode: the backward then only needs "was the
+// element strictly inside the range", lsq_kernel.h:126-145), returns gradients for those three only.
+class LsqNode : public torch::autograd::Function<LsqNode> {
+   public:
+    static Tensor forward(torch::autograd::AutogradContext* ctx, const Tensor& x, const Tensor& scale,
+                          const Tensor& shift, int64_t qmin, int64_t qmax, int64_t tmin, int64_t tmax, int64_t axis,
+                          bool use_gs, double gs, bool sym, bool per_channel, bool eval_mode, bool init_mode) {
+        at::AutoDispatchBelowADInplaceOrView below;
+        const bool masked = eval_mode && !init_mode && x.requires_grad();
+        const Scalars s{qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode};
+        auto [y, mask] = forward_impl(x, scale, shift, per_channel, axis, s, masked);
+        ctx->save_for_backward({masked ? mask : x, scale, shift});
+        auto& d = ctx->saved_data;
+        d["qmin"] = qmin; d["qmax"] = qmax; d["tmin"] = tmin; d["tmax"] = tmax; d["axis"] = axis;
+        d["use_gs"] = use_gs; d["gs"] = gs; d["sym"] = sym; d["per_channel"] = per_channel;
+        d["eval_mode"] = eval_mode; d["init_mode"] = init_mode; d["masked"] = masked;
+        return y;
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx,
+                                                   const torch::autograd::variable_list& grads) {
+        const auto saved = ctx->get_saved_variables();
+        auto& d = ctx->saved_data;
+        Tensor dx, ds, db;
+        if (d["masked"].toBool()) {
+            dx = backward_from_mask(grads[0], saved[0]);
+            ds = at::zeros_like(saved[1]);
+            db = at::zeros_like(saved[2]);
+        } else {
+            const Scalars s{d["qmin"].toInt(), d["qmax"].toInt(), d["tmin"].toInt(), d["tmax"].toInt(), d["use_gs"].toBool(),
+                            d["gs"].toDouble(), d["sym"].toBool(), d["eval_mode"].toBool(), d["init_mode"].toBool()};
+            std::tie(dx, ds, db) = backward_impl(grads[0], saved[0], saved[1], saved[2], d["per_channel"].toBool(),
+                                                 d["axis"].toInt(), s);
+        }
+        torch::autograd::variable_list out(14);
+        out[0] = dx; out[1] = ds; out[2] = db;
+        return out;
+    }
+};
+
+// quantops::ops::lsq (lsq.cpp:104-134): checks, per-channel broadcast of single-element parameters, routing.
+Tensor lsq(const Tensor& x, const Tensor& scale, const Tensor& shift, int64_t qmin, int64_t qmax, int64_t tmin,
+           int64_t tmax, int64_t axis, bool use_gs, double gs, bool is_affine, bool is_perchannel, bool eval_mode,
+           bool init_mode) {
+    TORCH_CHECK(scale.dim() == 1, "scale should be a 1-D tensor, even in per tensor case(please, avoid torch.Scalar too)");
+    TORCH_CHECK(shift.dim() == 1, "shift should be a 1-D tensor, even in per tensor case(please, avoid torch.Scalar too)");
+    Tensor sc = scale, sh = shift;
+    if (is_perchannel) {
+        const int64_t size = std::max(sc.size(0), sh.size(0));
+        if (sc.size(0) != size) sc = sc.repeat({size});  // differentiable: a size-1 leaf receives the summed gradient
+        if (sh.size(0) != size) sh = sh.repeat({size});
+    }
+    return LsqNode::apply(x, sc, sh, qmin, qmax, tmin, tmax, axis, use_gs, gs, !is_affine, is_perchannel, eval_mode, init_mode);
+}
+
+}  // namespace
+
+#define LSQ_TAIL \
+    "int quant_min, int quant_max, int type_min, int type_max, bool use_grad_scaling, float grad_scaler, " \
+    "bool sym, bool eval_mode, bool init_mode"
+
+TORCH_LIBRARY(torchlsq_native, m) {
+    m.def("lsq_forward_per_tensor(Tensor x, Tensor scale, Tensor shift, " LSQ_TAIL ") -> Tensor");
+    m.def("lsq_backward_per_tensor(Tensor grad, Tensor x, Tensor scale, Tensor shift, " LSQ_TAIL ") -> (Tensor, Tensor, Tensor)");
+    m.def("lsq_forward_per_channel(Tensor x, Tensor scale, Tensor shift, int axis, " LSQ_TAIL ") -> Tensor");
+    m.def("lsq_backward_per_channel(Tensor grad, Tensor x, Tensor scale, Tensor shift, int axis, " LSQ_TAIL
+          ") -> (Tensor, Tensor, Tensor)");
+    m.def("lsq_backward_from_mask(Tensor grad, Tensor mask) -> Tensor");
+    // composite (autograd handled by the node inside), like the reference's front op
+    m.def("lsq(Tensor x, Tensor scale, Tensor shift, int quant_min, int quant_max, int type_min, int type_max, int axis, "
+          "bool use_grad_scaling, float grad_scale, bool is_affine, bool is_perchannel, bool eval_mode, bool init_mode) -> Tensor",
+          &lsq);
+    m.def("_abi_version() -> int", []() -> int64_t { return lsq_hip_abi_version(); });
+}
+
+TORCH_LIBRARY_IMPL(torchlsq_native, CUDA, m) {  // PyTorch-ROCm dispatches HIP tensors under the CUDA key
+    m.impl("lsq_forward_per_tensor", &forward_per_tensor);
+    m.impl("lsq_backward_per_tensor", &backward_per_tensor);
+    m.impl("lsq_forward_per_channel", &forward_per_channel);
+    m.impl("lsq_backward_per_channel", &backward_per_channel);
+    m.impl("lsq_backward_from_mask", &backward_from_mask);
+}

@@ -100,6 +100,63 @@ except (ImportError, OSError, AttributeError) as e:  # surfaced by _assert_has_o
     error_str = str(e)
 
 
+# The optional second host layer: torchlsq/_lsq_torch.so, the C++ torch binding of the same C ABI
+# (csrc/torch_binding/lsq_torch_binding.cpp, namespace `torchlsq_native`).  It adds no device code; it only
+# moves the per-call tensor bookkeeping and the autograd node from Python to C++.  `functional.lsq` prefers it
+# for GPU tensors; everything in this module keeps working without it.  TORCHLSQ_HOST_BINDING=ctypes skips it.
+_NATIVE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lsq_torch.so")
+_NATIVE_LSQ = None
+native_error_str = ""
+
+
+def _load_native_binding():
+    global _NATIVE_LSQ, native_error_str
+    if os.environ.get("TORCHLSQ_HOST_BINDING", "").lower() == "ctypes":
+        native_error_str = "disabled by TORCHLSQ_HOST_BINDING=ctypes"
+        return
+    if not os.path.isfile(_NATIVE_PATH):
+        native_error_str = "%s not found (make -C lsqfakequantize-pytorch_amd/csrc binding)" % _NATIVE_PATH
+        return
+    try:
+        torch.ops.load_library(_NATIVE_PATH)
+        if int(torch.ops.torchlsq_native._abi_version()) != 1:
+            raise OSError("_lsq_torch.so was built against another ABI version of liblsq_hip.so")
+        _NATIVE_LSQ = torch.ops.torchlsq_native.lsq.default
+    except (OSError, RuntimeError, AttributeError) as e:
+        native_error_str = str(e)
+
+
+if _HAS_OPS:
+    _load_native_binding()
+
+
+def native_lsq():
+    """`torch.ops.torchlsq_native.lsq` (the C++ front op + autograd node) or None when _lsq_torch.so is absent."""
+    return _NATIVE_LSQ
+
+
+def host_binding():
+    """'native' (C++ torch binding loaded) or 'ctypes'."""
+    return "native" if _NATIVE_LSQ is not None else "ctypes"
+
+
+def set_host_binding(kind):
+    """Switch `functional.lsq` between the two host layers at run time (tests, A/B measurements)."""
+    global _NATIVE_LSQ
+    if kind == "ctypes":
+        _NATIVE_LSQ = None
+    elif kind == "native":
+        if not hasattr(torch.ops, "torchlsq_native") or not os.path.isfile(_NATIVE_PATH):
+            raise RuntimeError("the C++ torch binding is not available: %s" % native_error_str)
+        try:
+            _NATIVE_LSQ = torch.ops.torchlsq_native.lsq.default
+        except (AttributeError, RuntimeError):
+            torch.ops.load_library(_NATIVE_PATH)
+            _NATIVE_LSQ = torch.ops.torchlsq_native.lsq.default
+    else:
+        raise ValueError("host binding must be 'native' or 'ctypes'")
+
+
 def _has_ops():
     return _HAS_OPS
 

@@ -119,6 +119,10 @@ def lsq(x: Tensor, scale: Tensor, shift: Tensor,
     if x.is_cuda and scale.is_cuda and shift.is_cuda and not torch.jit.is_tracing() \
             and not torch.compiler.is_compiling():
         # front-op checks and routing of quantops::ops::lsq (lsq.cpp:104-134), then straight to the kernels
+        native = _E._NATIVE_LSQ
+        if native is not None:      # C++ front op + autograd node (csrc/torch_binding): same kernels, less host time
+            return native(x, scale, shift, quant_min, quant_max, type_min, type_max, axis, bool(use_grad_scaling),
+                          float(grad_scaler), bool(is_affine), bool(is_perchannel), bool(eval_mode), bool(init_mode))
         if scale.dim() != 1:
             raise RuntimeError("scale should be a 1-D tensor, even in per tensor case(please, avoid torch.Scalar too)")
         if shift.dim() != 1:

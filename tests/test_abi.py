@@ -103,3 +103,41 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "lsq_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_cpp_torch_binding_uses_only_the_public_abi():
+    """torchlsq/_lsq_torch.so (csrc/torch_binding) is host code over the SAME header:
+    every lsq_hip_* symbol it imports is declared in include/lsq_hip.h (none of the internal `_ex` twins), it
+    contains no device code, and it registers the reference's operator set under `torchlsq_native`."""
+    import torch
+    from torchlsq import extension as E
+    binding = os.path.join(os.path.dirname(LIB), "_lsq_torch.so")
+    assert os.path.isfile(binding), "build it: make -C lsqfakequantize-pytorch_amd/csrc binding"
+    nm = subprocess.run(["nm", "-D", "--undefined-only", binding], capture_output=True, text=True, check=True).stdout
+    imported = sorted(set(l.split()[-1] for l in nm.splitlines() if "lsq_hip_" in l))
+    assert imported and set(imported) <= set(_declared()), imported
+    for needed in ("lsq_hip_forward_per_tensor", "lsq_hip_backward_per_tensor", "lsq_hip_forward_per_channel",
+                   "lsq_hip_backward_per_channel", "lsq_hip_backward_from_mask"):
+        assert needed in imported
+    sections = subprocess.run(["readelf", "-S", "-W", binding], capture_output=True, text=True, check=True).stdout
+    assert ".hip_fatbin" not in sections and ".hipFatBinSegment" not in sections
+    assert E.host_binding() == "native", E.native_error_str
+    ns = torch.ops.torchlsq_native
+    assert int(ns._abi_version()) == 1
+    ref = torch.ops.torchlsq
+    for op in ("lsq", "lsq_forward_per_tensor", "lsq_backward_per_tensor", "lsq_forward_per_channel", "lsq_backward_per_channel"):
+        a = str(getattr(ns, op).default._schema).split("(", 1)[1]
+        b = str(getattr(ref, op).default._schema).split("(", 1)[1]
+        assert a == b, (op, a, b)                       # argument lists identical to the reference schemas
+    # CPU tensors: no kernel registered and the composite refuses them -- never a fallback
+    x, s, b = torch.zeros(4), torch.ones(1), torch.zeros(1)
+    import pytest
+    with pytest.raises(NotImplementedError):
+        ns.lsq_forward_per_tensor(x, s, b, 0, 255, 0, 255, True, 1.0, False, False, False)
+    with pytest.raises(RuntimeError, match="expected a tensor on the GPU"):
+        ns.lsq(x, s, b, 0, 255, 0, 255, 1, True, 1.0, True, False, False, False)
+    # switching host layers at run time
+    E.set_host_binding("ctypes")
+    assert E.host_binding() == "ctypes" and E.native_lsq() is None
+    E.set_host_binding("native")
+    assert E.host_binding() == "native"

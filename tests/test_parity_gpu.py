@@ -25,6 +25,18 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(params=["native", "ctypes"])
+def host_binding(request, dev):
+    """Run the test once per host layer of functional.lsq: the C++ torch binding (_lsq_torch.so) and the
+    Python/ctypes autograd.Function.  Both sit on the same C ABI; a missing C++ binding fails the test."""
+    from torchlsq import extension
+    before = extension.host_binding()
+    extension.set_host_binding(request.param)
+    assert extension.host_binding() == request.param
+    yield request.param
+    extension.set_host_binding(before)
+
+
 def _lsq_fwd_bwd(dev, x, g, scale, shift, p):
     from torchlsq.functional import lsq
     xg = torch.from_numpy(x).to(dev).requires_grad_(True)
@@ -38,7 +50,7 @@ def _lsq_fwd_bwd(dev, x, g, scale, shift, p):
     return y.detach().cpu().numpy(), xg.grad.cpu().numpy(), zs(sg.grad, scale), zs(bg.grad, shift)
 
 
-def test_small_cases_match_reference(dev, small_cases):
+def test_small_cases_match_reference(dev, small_cases, host_binding):
     manifest, arrays = small_cases
     for case in manifest["cases"]:
         k, p = case["key"], case["params"]
@@ -311,7 +323,7 @@ def test_empty_tensors(dev):
     assert dx.shape == (0, 3) and ds.item() == 0.5 and db.item() == 0.25      # lsq_cpu.cpp:76-78
 
 
-def test_errors_match_reference_checks(dev):
+def test_errors_match_reference_checks(dev, host_binding):
     from torchlsq.functional import lsq
     x = torch.randn(4, 8, device=dev)
     s, b = torch.ones(1, device=dev), torch.zeros(1, device=dev)
@@ -386,7 +398,7 @@ def test_full_size_properties_cfg2(dev):
     assert torch.equal(w_all.to(torch.float32)[0], ds[0])
 
 
-def test_dispatcher_path_equals_direct_path(dev, small_cases):
+def test_dispatcher_path_equals_direct_path(dev, small_cases, host_binding):
     """functional.lsq binds the kernels directly for GPU tensors; torch.ops.torchlsq.lsq goes through the
     dispatcher (front op -> register_autograd -> CUDA-key kernels).  Both must give identical results,
     including the size-1 `repeat` route of the per-channel front op (lsq.cpp:124-126)."""
@@ -551,7 +563,7 @@ def test_accelerated_observers_equal_stock_observers(dev):
         assert list(a.state_dict().keys()) == list(b.state_dict().keys())
 
 
-def test_steady_state_forward_backward_never_synchronises(dev):
+def test_steady_state_forward_backward_never_synchronises(dev, host_binding):
     """After the init phase a quantizer call must not block on the device: the reference tests its state
     buffers with Python `if`s (4 device syncs per call on the GPU); here decisions read a host mirror and
     the ops read scale/shift on the device."""
@@ -577,7 +589,7 @@ def test_steady_state_forward_backward_never_synchronises(dev):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16])
-def test_eval_mode_masked_backward(dev, dtype):
+def test_eval_mode_masked_backward(dev, dtype, host_binding):
     """eval mode through functional.lsq: the forward saves a 1-byte inside mask instead of x and the backward is
     dx = grad * mask; results must equal the reference-style eval backward (op level, from x) bit for bit."""
     from torchlsq import synth
@@ -594,7 +606,9 @@ def test_eval_mode_masked_backward(dev, dtype):
         b = synth.normal_like(C, 84, 0.0, 0.1, dtype=pdt, device=dev).requires_grad_(True)
         xr = x.clone().requires_grad_(True)
         y = lsq(xr, s, b, -8, 7, -128, 127, axis, True, 1.0, True, pc, eval_mode=True)
-        assert y.grad_fn is not None and all(t.dtype == torch.int8 or t.numel() == C for t in y.grad_fn.saved_tensors)
+        assert y.grad_fn is not None
+        if host_binding == "ctypes":      # a Python node exposes what it saved: the 1-byte mask, never x
+            assert all(t.dtype == torch.int8 or t.numel() == C for t in y.grad_fn.saved_tensors)
         y.backward(g)
         if pc:
             y0 = ops.lsq_forward_per_channel(x, s.detach(), b.detach(), axis, -8, 7, -128, 127, True, 1.0, False, True, False)
@@ -616,3 +630,96 @@ def test_eval_mode_masked_backward(dev, dtype):
     dx0, _, _ = ops.lsq_backward_per_tensor(torch.ones(2, 8, 5, 5, device=dev), x.detach(), s1, b1, 0, 15, 0, 255, True, 1.0,
                                             False, True, False)
     assert torch.equal(x.grad, dx0)
+
+
+NATIVE_LAYOUTS = [((4, 16, 6, 10), 1), ((32, 16, 3, 3), 0), ((8, 5, 7), 2), ((3, 1, 9), 1), ((4099,), 0), ((2, 3, 4, 5, 6), 3)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16, torch.float16])
+def test_native_binding_ops_equal_ctypes_ops(dev, dtype):
+    """torch.ops.torchlsq_native.* (C++ binding, public C ABI) against torch.ops.torchlsq.* (Python/ctypes): same
+    kernels, same launch geometry -> identical bits for y, dx (and the per-tensor reductions), for every layout the host layer
+    has to translate into [outer, C, inner] (row-major, channels-last, permuted, non-dense, size-1 channel axis)."""
+    from torchlsq import extension, synth
+    extension.set_host_binding("native")
+    nat, ops = torch.ops.torchlsq_native, torch.ops.torchlsq
+    pdt = torch.float64 if dtype == torch.float64 else torch.float32
+    p = (-8, 7, -128, 127)
+    for shape, axis in NATIVE_LAYOUTS:
+        n = int(np.prod(shape))
+        x = synth.normal_like(n, 91, 0.3, 1.0, dtype=dtype, device=dev).view(shape)
+        g = synth.normal_like(n, 92, 0.0, 1e-2, dtype=dtype, device=dev).view(shape)
+        C = shape[axis]
+        sc = synth.uniform_like(C, 93, 0.05, 0.3, dtype=pdt, device=dev)
+        sh = synth.normal_like(C, 94, 0.0, 0.1, dtype=pdt, device=dev)
+        layouts = {"row_major": (x, g)}
+        if len(shape) == 4:
+            layouts["channels_last"] = (x.contiguous(memory_format=torch.channels_last), g.contiguous(memory_format=torch.channels_last))
+            layouts["grad_other_layout"] = (x.contiguous(memory_format=torch.channels_last), g)
+        if len(shape) >= 3:
+            perm = list(range(len(shape)))[::-1]
+            inv = [perm.index(i) for i in range(len(shape))]
+            layouts["permuted"] = (x.permute(perm).contiguous().permute(inv), g)
+        wide = torch.empty(shape[:-1] + (2 * shape[-1],), dtype=dtype, device=dev)[..., ::2]
+        wide.copy_(x)
+        layouts["non_dense"] = (wide, g)
+        for name, (xv, gv) in layouts.items():
+            tag = "%s %s axis %d %s" % (dtype, shape, axis, name)
+            for sym, ev, init in ((False, False, False), (True, False, False), (False, True, False), (False, False, True)):
+                tail = p + (True, 1.0, sym, ev, init)
+                ya = nat.lsq_forward_per_channel(xv, sc, sh, axis, *tail)
+                yb = ops.lsq_forward_per_channel(xv, sc, sh, axis, *tail)
+                assert torch.equal(ya, yb) and ya.stride() == yb.stride(), tag
+                ra = nat.lsq_backward_per_channel(gv, xv, sc, sh, axis, *tail)
+                rb = ops.lsq_backward_per_channel(gv, xv, sc, sh, axis, *tail)
+                assert torch.equal(ra[0], rb[0]) and ra[0].stride() == rb[0].stride(), tag
+                # per-channel sums: the four waves of a workgroup add their fp64 run totals into LDS in no fixed
+                # order, so two launches agree to fp64 rounding (exactly, once rounded to fp32), not bit for bit in fp64
+                for a, b in zip(ra[1:], rb[1:]):
+                    if dtype == torch.float64:
+                        torch.testing.assert_close(a, b, rtol=1e-10, atol=1e-15, msg=tag)
+                    else:
+                        assert torch.equal(a, b), tag
+            tail = p + (True, 1.0, False, False, False)
+            ya = nat.lsq_forward_per_tensor(xv, sc[:1], sh[:1], *tail)
+            yb = ops.lsq_forward_per_tensor(xv, sc[:1], sh[:1], *tail)
+            assert torch.equal(ya, yb) and ya.stride() == yb.stride(), tag
+            for a, b in zip(nat.lsq_backward_per_tensor(gv, xv, sc[:1], sh[:1], *tail),
+                            ops.lsq_backward_per_tensor(gv, xv, sc[:1], sh[:1], *tail)):
+                assert torch.equal(a, b), tag
+    # empty input, reference early-outs (lsq_cpu.cpp:76-78)
+    xe = torch.zeros(0, 3, dtype=dtype, device=dev)
+    s1, b1 = torch.full((1,), 0.5, dtype=pdt, device=dev), torch.full((1,), 0.25, dtype=pdt, device=dev)
+    assert nat.lsq_forward_per_tensor(xe, s1, b1, 0, 127, 0, 255, True, 1.0, False, False, False).shape == (0, 3)
+    dx, ds, db = nat.lsq_backward_per_tensor(xe, xe, s1, b1, 0, 127, 0, 255, True, 1.0, False, False, False)
+    assert dx.shape == (0, 3) and ds.item() == 0.5 and db.item() == 0.25
+    # rejected arguments carry the reference's messages
+    with pytest.raises(RuntimeError, match="`axis` must be between 0 and number of dimensions of input"):
+        nat.lsq_forward_per_channel(x, sc, sh, 7, *p, True, 1.0, False, False, False)
+    with pytest.raises(RuntimeError, match="scale and shift need to have the same dimensions"):
+        nat.lsq_forward_per_channel(x, sc, sh[:1], axis, *p, True, 1.0, False, False, False)
+    with pytest.raises(RuntimeError, match="are not the same size"):
+        nat.lsq_backward_per_tensor(g.view(-1)[:5], x, s1, b1, *p, True, 1.0, False, False, False)
+    with pytest.raises(RuntimeError, match="does not fit a 32-bit integer"):
+        nat.lsq_forward_per_tensor(x, s1, b1, 0, 2 ** 40, 0, 255, True, 1.0, False, False, False)
+    with pytest.raises(RuntimeError, match="not implemented for"):
+        nat.lsq_forward_per_tensor(x.to(torch.int32), s1, b1, 0, 127, 0, 255, True, 1.0, False, False, False)
+
+
+def test_native_binding_runs_on_the_callers_stream_and_device(dev):
+    """The C++ binding hands the CURRENT stream of the tensor's device to the C ABI: work enqueued on a side stream
+    must be ordered after that stream's earlier work (a long fill) without any synchronisation in between."""
+    from torchlsq import extension
+    from torchlsq.functional import lsq
+    extension.set_host_binding("native")
+    side = torch.cuda.Stream(device=dev)
+    s, b = torch.tensor([0.5], device=dev), torch.tensor([0.0], device=dev)
+    x = torch.empty(1 << 26, device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        x.fill_(3.2)                       # 256 MiB fill, then the op on the same stream
+        xr = x.requires_grad_(True)
+        y = lsq(xr, s, b, 0, 15, 0, 255)
+        y.backward(torch.ones_like(y))
+    side.synchronize()
+    assert float(y.detach().min()) == 3.0 and float(y.detach().max()) == 3.0 and float(xr.grad.min()) == 1.0
