@@ -38,11 +38,12 @@ constexpr int kDefaultFwdVariant = encode_variant(4, true, true, 16);
 constexpr int kDefaultBwdVariant = encode_variant(4, true, true, 2);
 // Per-channel (profiles/r01_pc_variant_sweep2.txt, BASELINE config 5, measured AFTER the finalize kernels
 // were parallelised -- before that their serial chain of `splits` dependent loads made few workgroups look
-// best): 16 workgroups/CU in both directions for 4/8-byte elements; the 16-bit backward, which is VALU-
-// rather than HBM-limited, prefers unroll 2 at 8/CU.
+// best): 16 workgroups/CU in both directions for 4/8-byte elements; the 16-bit backward (twice the arithmetic
+// per byte, half the packets per lane) prefers the software-pipelined loop at unroll 1, 4/CU
+// (profiles/r01_pc_pipeline_sweep.txt).
 constexpr int kDefaultPcFwdVariant = encode_variant(4, true, true, 16);
 constexpr int kDefaultPcBwdWideVariant = encode_variant(4, true, true, 16);   // fp32 / fp64 storage
-constexpr int kDefaultPcBwdNarrowVariant = encode_variant(2, true, true, 8);  // bf16 / fp16 storage
+constexpr int kDefaultPcBwdNarrowVariant = encode_variant(1, true, true, 4) | (1 << 10);  // bf16 / fp16 storage (bit 10: pipelined)
 constexpr int kDefaultPcSegVariant = encode_variant(4, true, true, 16);
 
 inline Variant decode_variant(int code, int dflt) {

@@ -209,7 +209,7 @@ __device__ __forceinline__ void segmented_wave_accumulate(int key, double s, dou
     }
 }
 
-template <typename IO, int V, int CPL, bool SYM, bool INIT, bool EVAL, int UNROLL, bool NTL, bool NTS>
+template <typename IO, int V, int CPL, bool SYM, bool INIT, bool EVAL, int UNROLL, bool NTL, bool NTS, bool PIPE>
 __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__ grad, const void* __restrict__ x,
                                                         void* __restrict__ dx, PcGeom g,
                                                         const typename IO::arith* __restrict__ scale,
@@ -226,16 +226,19 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
 
     const LaneSite site = lane_site(g, V);
     const RowWalk walk(g, site);
-    E first_g[UNROLL][V], first_x[UNROLL][V];   // first group in flight before the table build (see K3)
-    const bool first_full = walk.n_rows >= UNROLL;
-    if (first_full) {
+    // A group = UNROLL rows.  load_group never predicates: rows past the lane's last one re-read the last row.
+    auto load_group = [&](E (&gb)[UNROLL][V], E (&xb)[UNROLL][V], int64_t i0) {
+        const int64_t last = walk.n_rows - 1;
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            const int64_t e = walk.row(u) * g.L + site.p0;
-            load_elems<IO, V, NTL>(grad, e, first_g[u]);
-            load_elems<IO, V, NTL>(x, e, first_x[u]);
+            const int64_t e = walk.row(i0 + u < last ? i0 + u : last) * g.L + site.p0;
+            load_elems<IO, V, NTL>(grad, e, gb[u]);
+            load_elems<IO, V, NTL>(x, e, xb[u]);
         }
-    }
+    };
+    E first_g[UNROLL][V], first_x[UNROLL][V];   // first group in flight before the table build (see K3)
+    const bool first_full = PIPE ? walk.n_rows > 0 : walk.n_rows >= UNROLL;
+    if (first_full) load_group(first_g, first_x, 0);
     build_channel_table<T>(table, g.k_slots, site.c_lo, g.C, scale, shift, r);
     if (!EVAL) {
         for (int k = threadIdx.x; k < g.k_slots; k += kBlock) {
@@ -247,11 +250,12 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
     LC ch;
     ch.init(table, site, g);
 
-    // CPL == 1 / V: one accumulator pair per channel of the lane.  CPL == 2: [0] = ALL components,
-    // [1] = the components of the lane's second channel (first channel = [0] - [1] at the end).
-    double acc_s[LC::N], acc_b[LC::N];
+    // CPL == 1: one accumulator pair.  CPL == 2 / V: one pair per COMPONENT of the packet (a cvt + an add per
+    // term in the loop, no selects); CPL == 2 folds them into its two channels after the walk, by `split`.
+    constexpr int kAcc = (LC::N == 1) ? 1 : V;
+    double acc_s[kAcc], acc_b[kAcc];
 #pragma unroll
-    for (int j = 0; j < LC::N; ++j) { acc_s[j] = 0.0; acc_b[j] = 0.0; }
+    for (int j = 0; j < kAcc; ++j) { acc_s[j] = 0.0; acc_b[j] = 0.0; }
 
     auto emit_row = [&](int64_t oo, const E (&gi)[V], const E (&xi)[V], bool valid) {
         const int64_t e = oo * g.L + site.p0;
@@ -267,77 +271,98 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
                 out[j] = static_cast<E>(backward_elem<T, SYM, INIT>(gv, xv, q, r, grad_scaler, ds_t, db_t));
                 if (!valid) { ds_t = static_cast<T>(0); db_t = static_cast<T>(0); }
                 const double a = static_cast<double>(ds_t), c = static_cast<double>(db_t);
-                if (LC::N == 1) {
-                    acc_s[0] += a;
-                    if (!SYM) acc_b[0] += c;
-                } else if (CPL == 2) {
-                    const bool hi = j >= ch.split;
-                    acc_s[0] += a;
-                    acc_s[LC::N - 1] += hi ? a : 0.0;
-                    if (!SYM) {
-                        acc_b[0] += c;
-                        acc_b[LC::N - 1] += hi ? c : 0.0;
-                    }
-                } else {
-                    acc_s[j < LC::N ? j : 0] += a;
-                    if (!SYM) acc_b[j < LC::N ? j : 0] += c;
-                }
+                acc_s[j < kAcc ? j : 0] += a;
+                if (!SYM) acc_b[j < kAcc ? j : 0] += c;
             }
         }
         if (valid) store_elems<IO, V, NTS>(dx, e, out);
     };
 
-    int64_t i = 0;
-    if (first_full) {
+    auto emit_full = [&](int64_t i0, const E (&gb)[UNROLL][V], const E (&xb)[UNROLL][V]) {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) emit_row(walk.row(u), first_g[u], first_x[u], true);
-        i = UNROLL;
-    }
-    for (; i + UNROLL <= walk.n_rows; i += UNROLL) {
-        E gi[UNROLL][V], xi[UNROLL][V];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int64_t e = walk.row(i + u) * g.L + site.p0;
-            load_elems<IO, V, NTL>(grad, e, gi[u]);
-            load_elems<IO, V, NTL>(x, e, xi[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) emit_row(walk.row(i + u), gi[u], xi[u], true);
-    }
-    if (i < walk.n_rows) {
-        E gi[UNROLL][V], xi[UNROLL][V];
+        for (int u = 0; u < UNROLL; ++u) emit_row(walk.row(i0 + u), gb[u], xb[u], true);
+    };
+    auto emit_ragged = [&](int64_t i0, const E (&gb)[UNROLL][V], const E (&xb)[UNROLL][V]) {
         const int64_t last = walk.n_rows - 1;
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int64_t e = walk.row(i + u < last ? i + u : last) * g.L + site.p0;
-            load_elems<IO, V, NTL>(grad, e, gi[u]);
-            load_elems<IO, V, NTL>(x, e, xi[u]);
+        for (int u = 0; u < UNROLL; ++u) emit_row(walk.row(i0 + u < last ? i0 + u : last), gb[u], xb[u], i0 + u <= last);
+    };
+    int64_t i = 0;
+    if (PIPE) {
+        // Software pipeline, two register buffers: the loads of group k+1 are issued BEFORE the arithmetic of
+        // group k, so every wave keeps HBM requests in flight while it computes (for 16-bit storage the VALU time
+        // of a group is about its HBM time: without this the two only overlap across waves).
+        if (first_full) {
+            E other_g[UNROLL][V], other_x[UNROLL][V];
+            // sched_barrier: the machine scheduler otherwise sinks each load group below the arithmetic that
+            // precedes its first use (to save registers), which undoes the pipeline
+            while (i + 2 * UNROLL <= walk.n_rows) {          // groups i and i + UNROLL are both full
+                load_group(other_g, other_x, i + UNROLL);
+                __builtin_amdgcn_sched_barrier(0);
+                emit_full(i, first_g, first_x);
+                __builtin_amdgcn_sched_barrier(0);
+                load_group(first_g, first_x, i + 2 * UNROLL);   // may be ragged or past the end: clamped re-reads
+                __builtin_amdgcn_sched_barrier(0);
+                emit_full(i + UNROLL, other_g, other_x);
+                __builtin_amdgcn_sched_barrier(0);
+                i += 2 * UNROLL;
+            }
+            if (i + UNROLL <= walk.n_rows) {                  // `first` holds a full group
+                load_group(other_g, other_x, i + UNROLL);
+                __builtin_amdgcn_sched_barrier(0);
+                emit_full(i, first_g, first_x);
+                i += UNROLL;
+                if (i < walk.n_rows) emit_ragged(i, other_g, other_x);
+            } else if (i < walk.n_rows) {
+                emit_ragged(i, first_g, first_x);
+            }
         }
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) emit_row(walk.row(i + u < last ? i + u : last), gi[u], xi[u], i + u <= last);
+    } else {
+        if (first_full) {
+            emit_full(0, first_g, first_x);
+            i = UNROLL;
+        }
+        for (; i + UNROLL <= walk.n_rows; i += UNROLL) {
+            E gi[UNROLL][V], xi[UNROLL][V];
+            load_group(gi, xi, i);
+            emit_full(i, gi, xi);
+        }
+        if (i < walk.n_rows) {
+            E gi[UNROLL][V], xi[UNROLL][V];
+            load_group(gi, xi, i);
+            emit_ragged(i, gi, xi);
+        }
     }
     if (EVAL) return;
 
     if (CPL == 2) {
-        // [0] all, [1] second channel  ->  [0] first channel, [1] second channel.  The second channel of
-        // lane i is the FIRST channel of lane i+1 (their positions are contiguous and inner >= V), so
-        // its sums travel one lane up and join that lane's run: ONE segmented reduction instead of two.
-        // Only the last lane of a wave / of a row has no neighbour and adds its second channel itself.
+        // components below `split` -> first channel, the rest -> second channel (two disjoint sums: a
+        // non-finite term of one channel never reaches the other).  The second channel of lane i is
+        // the FIRST channel of lane i+1 (their positions are contiguous and inner >= V), so its sums
+        // travel one lane up and join that lane's run: ONE segmented reduction instead of two.  Only
+        // the last lane of a wave / of a row has no neighbour and adds its second channel itself.
         const int lane = threadIdx.x & 63;
         const bool has_hi = site.live && ch.split < V;
-        acc_s[0] -= acc_s[LC::N - 1];
-        acc_b[0] -= acc_b[LC::N - 1];
+        double lo_s = 0.0, lo_b = 0.0, hi_s = 0.0, hi_b = 0.0;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const bool hi = j >= ch.split;
+            lo_s += hi ? 0.0 : acc_s[j];
+            hi_s += hi ? acc_s[j] : 0.0;
+            lo_b += hi ? 0.0 : acc_b[j];
+            hi_b += hi ? acc_b[j] : 0.0;
+        }
         const int key_hi = has_hi ? ch.key[LC::N - 1] : -1;
         const int next_key0 = __shfl_down(site.live ? ch.key[0] : -2, 1, 64);
         const bool handoff = has_hi && lane < 63 && next_key0 == key_hi;
-        const double give_s = handoff ? acc_s[LC::N - 1] : 0.0, give_b = handoff ? acc_b[LC::N - 1] : 0.0;
+        const double give_s = handoff ? hi_s : 0.0, give_b = handoff ? hi_b : 0.0;
         const double got_s = shfl_up_f64(give_s, 1), got_b = shfl_up_f64(give_b, 1);
-        if (lane > 0) { acc_s[0] += got_s; acc_b[0] += got_b; }
+        if (lane > 0) { lo_s += got_s; lo_b += got_b; }
         if (has_hi && !handoff) {
-            __hip_atomic_fetch_add(&lds_s[key_hi], acc_s[LC::N - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (!SYM) __hip_atomic_fetch_add(&lds_b[key_hi], acc_b[LC::N - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&lds_s[key_hi], hi_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!SYM) __hip_atomic_fetch_add(&lds_b[key_hi], hi_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        segmented_wave_accumulate<SYM>(site.live ? ch.key[0] : -1, acc_s[0], acc_b[0], lds_s, lds_b);
+        segmented_wave_accumulate<SYM>(site.live ? ch.key[0] : -1, lo_s, lo_b, lds_s, lds_b);
     } else {
         // lanes -> window slots.  Dead lanes carry key -1 (never written).
 #pragma unroll
@@ -671,14 +696,34 @@ static hipError_t launch_bwd_pc(const void* grad, const void* x, void* dx, const
     const Range<T> r = make_range<T>(p);
     const dim3 grid(static_cast<unsigned>(g.n_windows), static_cast<unsigned>(g.splits));
     const size_t lds = static_cast<size_t>(g.k_slots) * (sizeof(QSlot<T>) + 2 * sizeof(double));
-#define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                          \
-    hipLaunchKernelGGL((bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, U, NTLF, NTSF>), grid, dim3(kBlock), lds, stream, grad, x, dx, \
-                       g, static_cast<const T*>(scale), static_cast<const T*>(shift), r, gs, partials)
     [[maybe_unused]] constexpr bool kFull = !SYM && !INIT && !EVAL && V > 1 && CPL <= 2 && !std::is_same<IO, io_f64>::value &&
                                             !std::is_same<IO, io_f16>::value;
-    constexpr int kDefU = sizeof(typename IO::elem) >= 4 ? 4 : 2;
+    // 16-bit storage: unroll 1 + the software-pipelined loop (profiles/r01_pc_pipeline_sweep.txt: 36.3 us against
+    // 38.5 us for the best plain variant at BASELINE config 5); 4/8-byte storage gains nothing from it (55.6 vs 55.9 us)
+    // and keeps the plain loop at unroll 4.
+    constexpr bool kNarrow = sizeof(typename IO::elem) < 4;
+    constexpr int kDefU = kNarrow ? 1 : 4;
+#define LSQ_LAUNCH_P(U, NTLF, NTSF, PIPEF)                                                                                 \
+    hipLaunchKernelGGL((bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, U, NTLF, NTSF, PIPEF>), grid, dim3(kBlock), lds, stream, grad, \
+                       x, dx, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r, gs, partials)
+#ifdef LSQ_TUNING
+    // tuning builds compile both loops for the swept kernels; the switch is the variant's `chunked` bit (unused here)
+    const bool pipe = kFull ? v.chunked : kNarrow;
+#define LSQ_LAUNCH(U, NTLF, NTSF)                                   \
+    do {                                                            \
+        if constexpr (kFull) {                                      \
+            if (pipe) LSQ_LAUNCH_P(U, NTLF, NTSF, true);            \
+            else LSQ_LAUNCH_P(U, NTLF, NTSF, false);                \
+        } else {                                                    \
+            LSQ_LAUNCH_P(U, NTLF, NTSF, kNarrow);                   \
+        }                                                           \
+    } while (0)
+#else
+#define LSQ_LAUNCH(U, NTLF, NTSF) LSQ_LAUNCH_P(U, NTLF, NTSF, kNarrow)
+#endif
     LSQ_DISPATCH_VARIANT(kFull, kDefU, v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH
+#undef LSQ_LAUNCH_P
     return hipGetLastError();
 }
 

@@ -723,3 +723,43 @@ def test_native_binding_runs_on_the_callers_stream_and_device(dev):
         y.backward(torch.ones_like(y))
     side.synchronize()
     assert float(y.detach().min()) == 3.0 and float(y.detach().max()) == 3.0 and float(xr.grad.min()) == 1.0
+
+
+@pytest.mark.parametrize("shape,axis", [((8, 6, 7, 7), 1), ((64, 5, 3), 1), ((16, 8, 4, 4), 1), ((6, 40, 25), 1), ((4, 6, 300), 1),
+                                        ((12, 6, 3, 3), 0)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_non_finite_gradients_stay_in_their_channel(dev, shape, axis, dtype):
+    """An inf / NaN upstream gradient poisons d_scale / d_shift of ITS channel only (the reference sums every channel
+    separately, lsq_cpu.cpp:287-292).  Lanes whose packet straddles two channels keep two disjoint sums, so the
+    finite neighbour must come out finite and within tolerance -- also at the packets right at a channel border."""
+    from torchlsq import synth
+    n = int(np.prod(shape))
+    C = shape[axis]
+    x = synth.normal_like(n, 71, 0.0, 1.0, dtype=dtype).view(shape).clone()
+    g = synth.normal_like(n, 72, 0.0, 1e-3, dtype=dtype).view(shape).clone()
+    outer, C_, inner = O.axis_to_ocl(shape, axis)
+    g3 = g.view(outer, C_, inner)
+    x3 = x.view(outer, C_, inner)
+    g3[0, 1, inner - 1] = float("inf")          # last element of channel 1 (shares a packet with channel 2 when inner % V != 0)
+    x3[0, 1, inner - 1] = 100.0                 # saturated: contributes to d_shift as well
+    g3[outer - 1, 4, 0] = float("nan")          # first element of channel 4
+    g3[outer // 2, 4, inner // 2] = float("-inf")
+    scale = synth.uniform_like(C, 73, 0.05, 0.35, dtype=dtype)
+    shift = synth.normal_like(C, 74, 0.0, 0.1, dtype=dtype)
+    p = (-8, 7, -128, 127)
+    dx, ds, db = torch.ops.torchlsq.lsq_backward_per_channel(g.to(dev), x.to(dev), scale.to(dev), shift.to(dev), axis, *p,
+                                                              True, 1.0, False, False, False)
+    r = O.bwd_pc(g.numpy(), x.numpy(), scale.numpy(), shift.numpy(), outer, C_, inner, *p, True, 1.0, False)
+    assert_bits_equal(dx.cpu().numpy(), r.dx, "dx")
+    ds, db = ds.cpu().numpy(), db.cpu().numpy()
+    want_s, want_b = np.asarray(r.ds_wide, dtype=np.float64), np.asarray(r.db_wide, dtype=np.float64)
+    bad_s, bad_b = ~np.isfinite(want_s), ~np.isfinite(want_b)
+    assert bad_s[1] and bad_s[4] and bad_b[1] and not bad_s[[0, 2, 3]].any()
+    assert (np.isfinite(ds) == ~bad_s).all() and (np.isfinite(db) == ~bad_b).all(), (ds, want_s, db, want_b)
+    assert (np.isnan(ds) == np.isnan(want_s)).all() and (np.isnan(db) == np.isnan(want_b)).all()
+    inf_s = np.isinf(want_s)
+    assert (ds[inf_s] == want_s[inf_s]).all()
+    ok = ~bad_s
+    assert_reduction_close(ds[ok], want_s[ok], np.asarray(r.abs_ds)[ok], "ds (finite channels)")
+    ok = ~bad_b
+    assert_reduction_close(db[ok], want_b[ok], np.asarray(r.abs_db)[ok], "db (finite channels)")

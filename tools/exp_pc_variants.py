@@ -48,7 +48,11 @@ for dt, code in ((torch.float32, 0), (torch.bfloat16, 2)):
             def bwd(s):
                 assert lib.lsq_hip_backward_per_channel_ex(code, g.data_ptr(), x.data_ptr(), dx.data_ptr(), ds.data_ptr(), db.data_ptr(), None, outer, C, inner, scale.data_ptr(), shift.data_ptr(), ctypes.byref(p), ws.data_ptr(), ws.numel(), s, v) == 0
             tf, tb = timeit(fwd), timeit(bwd)
-            rows.append((unroll, bpc, round(tf, 2), round(2 * esz * n / tf / 1e3), round(tb, 2), round(3 * esz * n / tb / 1e3)))
+            v |= 1 << 10                      # the software-pipelined backward loop (tuning builds: `chunked` bit)
+            tbp = timeit(bwd)
+            rows.append((unroll, bpc, round(tf, 2), round(2 * esz * n / tf / 1e3), round(tb, 2), round(3 * esz * n / tb / 1e3),
+                         round(tbp, 2)))
     print(str(dt), "best fwd:", sorted(rows, key=lambda r: r[2])[:4])
     print(str(dt), "best bwd:", sorted(rows, key=lambda r: r[4])[:6])
-    print(str(dt), "bwd @bpc 2/3:", [(r[0], r[1], r[4]) for r in rows if r[1] in (2, 3)])
+    print(str(dt), "best bwd pipelined:", sorted([(r[0], r[1], r[6]) for r in rows], key=lambda r: r[2])[:6])
+    print(str(dt), "bwd (unroll, wg/CU, plain us, pipelined us):", [(r[0], r[1], r[4], r[6]) for r in rows if r[1] in (2, 4, 8, 16)])
