@@ -168,6 +168,19 @@ int lsq_hip_minmax_per_channel(int dtype, const void* x, int64_t outer, int64_t 
                                void* min_out, void* max_out, void* workspace, size_t workspace_bytes,
                                void* stream);
 
+/* Mean and (unbiased) standard deviation in ONE read-only pass: the statistics behind the 3-sigma initialisation
+ * of a weight quantizer's scale, scale = max(|mu - 3 sigma|, |mu + 3 sigma|) / 2^bits, which the reference module
+ * computes with torch.mean / torch.std over the tensor or per channel over the other axes on the first call
+ * (reference quantized/modules/observers.py:329-337).  fp64 shifted-data sums (pivot = the channel's first
+ * element); n = 1 gives std = NaN and non-finite inputs propagate, as in torch.  Outputs and workspace as for
+ * lsq_hip_minmax_* (float for F32|BF16|F16 storage, double for F64). */
+size_t lsq_hip_meanstd_workspace(int dtype, int64_t outer, int64_t channels, int64_t inner);
+int lsq_hip_meanstd_per_tensor(int dtype, const void* x, int64_t n, void* mean_out, void* std_out,
+                               void* workspace, size_t workspace_bytes, void* stream);
+int lsq_hip_meanstd_per_channel(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner,
+                                void* mean_out, void* std_out, void* workspace, size_t workspace_bytes,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -235,4 +235,38 @@ int lsq_hip_minmax_per_channel(int dtype, const void* x, int64_t outer, int64_t 
     return hip_status(e, "lsq_hip_minmax_per_channel");
 }
 
+size_t lsq_hip_meanstd_workspace(int dtype, int64_t outer, int64_t channels, int64_t inner) {
+    if (!dtype_ok(dtype) || outer <= 0 || channels <= 0 || inner <= 0) return 256;
+    return lsq::meanstd_workspace_bytes(io_vec(dtype), outer, channels, inner);
+}
+
+int lsq_hip_meanstd_per_tensor(int dtype, const void* x, int64_t n, void* mean_out, void* std_out, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    if (!dtype_ok(dtype)) return fail(LSQ_EINVAL, "unknown dtype code %d", dtype);
+    if (n <= 0) return fail(LSQ_EINVAL, "meanstd_per_tensor: element count must be positive");
+    if (!x || !mean_out || !std_out) return fail(LSQ_EINVAL, "meanstd_per_tensor: NULL buffer");
+    if (!workspace || workspace_bytes < lsq::meanstd_workspace_bytes(io_vec(dtype), 1, 1, 1) - 256 ||
+        (reinterpret_cast<uintptr_t>(workspace) & 15u))
+        return fail(LSQ_EWORKSPACE, "meanstd_per_tensor: workspace too small or misaligned (%zu bytes)", workspace_bytes);
+    hipError_t e = hipSuccess;
+    LSQ_DISPATCH_IO(dtype, e = lsq::meanstd_per_tensor<IO>(x, n, mean_out, std_out, workspace, static_cast<hipStream_t>(stream)));
+    return hip_status(e, "lsq_hip_meanstd_per_tensor");
+}
+
+int lsq_hip_meanstd_per_channel(int dtype, const void* x, int64_t outer, int64_t channels, int64_t inner, void* mean_out,
+                                void* std_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dtype_ok(dtype)) return fail(LSQ_EINVAL, "unknown dtype code %d", dtype);
+    if (int rc = check_ocl(outer, channels, inner)) return rc;
+    if (outer == 0 || inner == 0) return fail(LSQ_EINVAL, "meanstd_per_channel: empty tensor");
+    if (!x || !mean_out || !std_out) return fail(LSQ_EINVAL, "meanstd_per_channel: NULL buffer");
+    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15u))
+        return fail(LSQ_EWORKSPACE, "meanstd_per_channel: NULL or misaligned workspace");
+    hipError_t e = hipSuccess;
+    LSQ_DISPATCH_IO(dtype, e = lsq::meanstd_per_channel<IO>(x, outer, channels, inner, mean_out, std_out, workspace,
+                                                             workspace_bytes, static_cast<hipStream_t>(stream)));
+    if (e == hipErrorInvalidValue)
+        return fail(LSQ_EWORKSPACE, "meanstd_per_channel: workspace of %zu bytes is too small", workspace_bytes);
+    return hip_status(e, "lsq_hip_meanstd_per_channel");
+}
+
 }  // extern "C"

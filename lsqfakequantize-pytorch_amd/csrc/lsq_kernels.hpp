@@ -217,4 +217,11 @@ template <typename IO>
 hipError_t minmax_per_channel(const void* x, int64_t outer, int64_t channels, int64_t inner, void* out_min,
                               void* out_max, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
+size_t meanstd_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64_t inner);
+template <typename IO>
+hipError_t meanstd_per_tensor(const void* x, int64_t n, void* out_mean, void* out_std, void* workspace, hipStream_t stream);
+template <typename IO>
+hipError_t meanstd_per_channel(const void* x, int64_t outer, int64_t channels, int64_t inner, void* out_mean,
+                               void* out_std, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 }  // namespace lsq

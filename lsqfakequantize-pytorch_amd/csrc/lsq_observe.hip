@@ -1,4 +1,4 @@
-// lsq_observe.hip -- observer statistics (running min / max) for the init phase of LSQFakeQuantizer.
+// lsq_observe.hip -- observer statistics (running min / max; mean / std) for the init phase of LSQFakeQuantizer.
 //
 // during its initialisation batches the reference module runs a
 // torch MinMax observer over the input right before the fake-quantize op
@@ -353,6 +353,292 @@ __global__ __launch_bounds__(kBlock) void minmax_seg_finalize_kernel(const MinMa
     }
 }
 
+// =================================================================================================
+// mean / standard deviation (the 3-sigma initialisation of weight quantizers)
+// =================================================================================================
+// The reference module creates the scale of a weight quantizer from the weight itself on its first call:
+// scale = max(|mu - 3 sigma|, |mu + 3 sigma|) / 2^bits with mu / sigma = torch.mean / torch.std (unbiased) over
+// everything, or per channel over the other axes (/root/reference/torchlsq/quantized/modules/observers.py:329-337):
+// two library reductions, each several passes for the per-channel case.  Here: ONE read-only pass, same walk as
+// the min/max kernels.  Numerics: shifted-data sums in fp64 -- S1 = sum(x - K), S2 = sum((x - K)^2) with the pivot
+// K = the channel's first element (a sample of the data, so |K - mu| is O(sigma) and S2 - S1^2/n does not cancel);
+// mean = K + S1/n, var = (S2 - S1^2/n) / (n - 1).  A non-finite pivot is replaced by 0 so that inf / NaN
+// propagate the way they do through torch (mean inf or NaN, std NaN); n = 1 gives std = NaN like torch.
+template <typename T>
+__device__ __forceinline__ double pivot_of(T v) {
+    const double d = static_cast<double>(v);
+    return (d - d == 0.0) ? d : 0.0;   // inf - inf and NaN - NaN are NaN
+}
+
+struct RunningMoments {
+    double s1 = 0.0, s2 = 0.0;
+    __device__ __forceinline__ void push(double v, double pivot) {
+        const double d = v - pivot;
+        s1 += d;
+        s2 = __builtin_fma(d, d, s2);
+    }
+};
+
+// wave64 butterfly, then the 4 wave results through LDS in a fixed order; thread 0 returns the workgroup's sums
+__device__ __forceinline__ double2 block_sum2(double a, double b) {
+    __shared__ double2 wave_res[kBlock / 64];
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) wave_res[threadIdx.x >> 6] = make_double2(a, b);
+    __syncthreads();
+    double2 out = wave_res[0];
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; ++w) { out.x += wave_res[w].x; out.y += wave_res[w].y; }
+    return out;
+}
+
+template <typename T>
+__device__ __forceinline__ void write_mean_std(double pivot, double s1, double s2, double n, T* mean_out, T* std_out, int64_t c) {
+    const double var = (s2 - s1 * s1 / n) / (n - 1.0);          // n == 1: 0/0 = NaN, like torch.std
+    mean_out[c] = static_cast<T>(pivot + s1 / n);
+    std_out[c] = static_cast<T>(__builtin_sqrt(var < 0.0 ? 0.0 : var));   // NaN stays NaN
+}
+
+template <typename IO, int UNROLL>
+__global__ __launch_bounds__(kBlock) void moments_pt_kernel(const void* __restrict__ x, int64_t n, double2* __restrict__ partials) {
+    using T = typename IO::arith;
+    constexpr int VEC = IO::VEC;
+    const double pivot = pivot_of<T>(IO::load1(x, 0));
+    RunningMoments r;
+    const int64_t n_packets = n / VEC;
+    constexpr int64_t kTile = static_cast<int64_t>(kBlock) * UNROLL;
+    const int64_t n_full = n_packets / kTile;
+    for (int64_t tile = blockIdx.x; tile < n_full; tile += gridDim.x) {
+        const int64_t p0 = tile * kTile + threadIdx.x;
+        Packet<IO> in[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) in[u] = load_packet_nt<IO>(x, (p0 + static_cast<int64_t>(u) * kBlock) * VEC);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) r.push(static_cast<double>(static_cast<T>(in[u].v[j])), pivot);
+    }
+    if (static_cast<int64_t>(blockIdx.x) == n_full % gridDim.x) {
+        for (int64_t p = n_full * kTile + threadIdx.x; p < n_packets; p += kBlock) {
+            const Packet<IO> in = load_packet<IO>(x, p * VEC);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) r.push(static_cast<double>(static_cast<T>(in.v[j])), pivot);
+        }
+    }
+    if (blockIdx.x == 0) {
+        const int64_t i = n_packets * VEC + threadIdx.x;
+        if (i < n) r.push(static_cast<double>(IO::load1(x, i)), pivot);
+    }
+    const double2 res = block_sum2(r.s1, r.s2);
+    if (threadIdx.x == 0) partials[blockIdx.x] = res;
+}
+
+template <typename IO>
+__global__ __launch_bounds__(kBlock) void moments_pt_scalar_kernel(const void* __restrict__ x, int64_t n, double2* __restrict__ partials) {
+    using T = typename IO::arith;
+    const double pivot = pivot_of<T>(IO::load1(x, 0));
+    RunningMoments r;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock)
+        r.push(static_cast<double>(IO::load1(x, i)), pivot);
+    const double2 res = block_sum2(r.s1, r.s2);
+    if (threadIdx.x == 0) partials[blockIdx.x] = res;
+}
+
+template <typename IO>
+__global__ __launch_bounds__(kBlock) void moments_pt_finalize_kernel(const double2* __restrict__ partials, int n_partials,
+                                                                     const void* __restrict__ x, int64_t n,
+                                                                     typename IO::arith* __restrict__ mean_out,
+                                                                     typename IO::arith* __restrict__ std_out) {
+    using T = typename IO::arith;
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < n_partials; i += kBlock) { a += partials[i].x; b += partials[i].y; }
+    const double2 t = block_sum2(a, b);
+    if (threadIdx.x == 0) write_mean_std<T>(pivot_of<T>(IO::load1(x, 0)), t.x, t.y, static_cast<double>(n), mean_out, std_out, 0);
+}
+
+// per-channel, window mode: every component of a lane keeps its own channel, pivot and pair of sums
+template <typename IO, int V, int UNROLL>
+__global__ __launch_bounds__(kBlock) void moments_pc_kernel(const void* __restrict__ x, PcGeom g, double2* __restrict__ partials) {
+    using T = typename IO::arith;
+    using E = typename IO::elem;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* lds_pivot = reinterpret_cast<double*>(smem);
+    double* lds_s1 = lds_pivot + g.k_slots;
+    double* lds_s2 = lds_s1 + g.k_slots;
+
+    const LaneSite site = lane_site(g, V);
+    const RowWalk walk(g, site);
+    E first[UNROLL][V];
+    const bool first_full = walk.n_rows >= UNROLL;
+    if (first_full) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) load_elems<IO, V, true>(x, walk.row(u) * g.L + site.p0, first[u]);
+    }
+    for (int k = threadIdx.x; k < g.k_slots; k += kBlock) {
+        const int64_t c = site.c_lo + k;
+        lds_pivot[k] = c < g.C ? pivot_of<T>(IO::load1(x, c * g.inner)) : 0.0;   // row 0, first element of the channel
+        lds_s1[k] = 0.0;
+        lds_s2[k] = 0.0;
+    }
+    int32_t slot[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+        slot[j] = site.live ? static_cast<int32_t>(udiv(site.p0 + j, g.inner, g.fits32 != 0) - site.c_lo) : 0;
+    __syncthreads();
+    double pivot[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) pivot[j] = lds_pivot[slot[j]];
+
+    RunningMoments r[V];
+    auto absorb = [&](const E (&in)[V], bool valid) {
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+            if (valid) r[j].push(static_cast<double>(static_cast<T>(in[j])), pivot[j]);
+    };
+    int64_t i = 0;
+    if (first_full) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) absorb(first[u], true);
+        i = UNROLL;
+    }
+    for (; i + UNROLL <= walk.n_rows; i += UNROLL) {
+        E in[UNROLL][V];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) load_elems<IO, V, true>(x, walk.row(i + u) * g.L + site.p0, in[u]);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) absorb(in[u], true);
+    }
+    if (i < walk.n_rows) {
+        E in[UNROLL][V];
+        const int64_t last = walk.n_rows - 1;
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+            load_elems<IO, V, true>(x, walk.row(i + u < last ? i + u : last) * g.L + site.p0, in[u]);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) absorb(in[u], i + u <= last);
+    }
+    if (site.live && walk.n_rows > 0) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            __hip_atomic_fetch_add(&lds_s1[slot[j]], r[j].s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&lds_s2[slot[j]], r[j].s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    const int64_t block_linear = static_cast<int64_t>(blockIdx.y) * g.n_windows + blockIdx.x;
+    double2* out = partials + block_linear * g.k_slots;
+    for (int k = threadIdx.x; k < g.k_slots; k += kBlock) out[k] = make_double2(lds_s1[k], lds_s2[k]);
+}
+
+template <typename IO>
+__global__ __launch_bounds__(kBlock) void moments_pc_finalize_kernel(const double2* __restrict__ partials, PcGeom g,
+                                                                     const void* __restrict__ x,
+                                                                     typename IO::arith* __restrict__ mean_out,
+                                                                     typename IO::arith* __restrict__ std_out) {
+    using T = typename IO::arith;
+    __shared__ double2 part_res[kMmFinParts][kMmFinCh];
+    const int lane_c = threadIdx.x % kMmFinCh, part = threadIdx.x / kMmFinCh;
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * kMmFinCh + lane_c;
+    double a = 0.0, b = 0.0;
+    if (c < g.C) {
+        int64_t w_lo = 0, w_hi = 0;
+        if (g.R == 1) {
+            w_lo = (c * g.inner) / g.wpos;
+            w_hi = ((c + 1) * g.inner - 1) / g.wpos;
+        }
+        for (int64_t w = w_lo; w <= w_hi; ++w) {
+            const int64_t c_lo = (g.R == 1) ? (w * g.wpos) / g.inner : 0;
+            const double2* col = partials + w * g.k_slots + (c - c_lo);
+            const int64_t stride = g.n_windows * g.k_slots;
+#pragma unroll 4
+            for (int32_t sy = part; sy < g.splits; sy += kMmFinParts) {
+                const double2 p = col[static_cast<int64_t>(sy) * stride];
+                a += p.x;
+                b += p.y;
+            }
+        }
+    }
+    part_res[part][lane_c] = make_double2(a, b);
+    __syncthreads();
+    if (part == 0 && c < g.C) {
+        double2 t = part_res[0][lane_c];
+#pragma unroll
+        for (int k = 1; k < kMmFinParts; ++k) { t.x += part_res[k][lane_c].x; t.y += part_res[k][lane_c].y; }
+        write_mean_std<T>(pivot_of<T>(IO::load1(x, c * g.inner)), t.x, t.y, static_cast<double>(g.outer) * static_cast<double>(g.inner),
+                          mean_out, std_out, c);
+    }
+}
+
+// per-channel, segment mode: one channel per workgroup
+template <typename IO, int V, int UNROLL>
+__global__ __launch_bounds__(kBlock) void moments_seg_kernel(const void* __restrict__ x, SegGeom g, double2* __restrict__ partials) {
+    using T = typename IO::arith;
+    using E = typename IO::elem;
+    const SegWalk w(g);
+    const int64_t W = static_cast<int64_t>(kBlock) * V;
+    const int64_t q0 = static_cast<int64_t>(threadIdx.x) * V;
+    const int64_t q_last = g.inner - V;
+    const double pivot = pivot_of<T>(IO::load1(x, w.c * g.inner));
+    RunningMoments r;
+    auto site = [&](int64_t it, bool& valid) {
+        const int64_t oi = static_cast<int64_t>(static_cast<uint32_t>(it) / static_cast<uint32_t>(w.n_r));
+        const int64_t ri = it - oi * w.n_r;
+        const int64_t pos = (w.r_begin + ri) * W + q0;
+        valid = pos < g.inner;
+        return ((w.o_begin + oi) * g.C + w.c) * g.inner + (valid ? pos : q_last);
+    };
+    for (int64_t it = 0; it < w.n_it; it += UNROLL) {
+        E in[UNROLL][V];
+        bool ok[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t k = it + u < w.n_it ? it + u : w.n_it - 1;
+            const int64_t e = site(k, ok[u]);
+            ok[u] = ok[u] && (it + u < w.n_it);
+            load_elems<IO, V, true>(x, e, in[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int j = 0; j < V; ++j)
+                if (ok[u]) r.push(static_cast<double>(static_cast<T>(in[u][j])), pivot);
+    }
+    const double2 res = block_sum2(r.s1, r.s2);
+    if (threadIdx.x == 0) partials[static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = res;
+}
+
+template <typename IO>
+__global__ __launch_bounds__(kBlock) void moments_seg_finalize_kernel(const double2* __restrict__ partials, SegGeom g,
+                                                                      const void* __restrict__ x,
+                                                                      typename IO::arith* __restrict__ mean_out,
+                                                                      typename IO::arith* __restrict__ std_out) {
+    using T = typename IO::arith;
+    __shared__ double2 part_res[kMmFinParts][kMmFinCh];
+    const int lane_c = threadIdx.x % kMmFinCh, part = threadIdx.x / kMmFinCh;
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * kMmFinCh + lane_c;
+    double a = 0.0, b = 0.0;
+    if (c < g.C) {
+        const int64_t gx = g.C * g.segs;
+        const int32_t total = g.osplits * g.segs;
+#pragma unroll 4
+        for (int32_t sl = part; sl < total; sl += kMmFinParts) {
+            const int32_t oy = sl / g.segs, sg = sl - oy * g.segs;
+            const double2 p = partials[static_cast<int64_t>(oy) * gx + c * g.segs + sg];
+            a += p.x;
+            b += p.y;
+        }
+    }
+    part_res[part][lane_c] = make_double2(a, b);
+    __syncthreads();
+    if (part == 0 && c < g.C) {
+        double2 t = part_res[0][lane_c];
+#pragma unroll
+        for (int k = 1; k < kMmFinParts; ++k) { t.x += part_res[k][lane_c].x; t.y += part_res[k][lane_c].y; }
+        write_mean_std<T>(pivot_of<T>(IO::load1(x, c * g.inner)), t.x, t.y, static_cast<double>(g.outer) * static_cast<double>(g.inner),
+                          mean_out, std_out, c);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -458,7 +744,75 @@ hipError_t minmax_per_channel(const void* x, int64_t outer, int64_t channels, in
     return hipGetLastError();
 }
 
+size_t meanstd_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64_t inner) {
+    // same launch geometry as the min/max kernels, 16-byte {S1, S2} partials
+    return minmax_workspace_bytes(io_vec, 8, outer, channels, inner);   // sizeof(MinMaxPartial<double>) = 24 >= 16
+}
+
+template <typename IO>
+hipError_t meanstd_per_tensor(const void* x, int64_t n, void* out_mean, void* out_std, void* workspace, hipStream_t stream) {
+    using T = typename IO::arith;
+    const DeviceInfo& dev = device_info();
+    auto* partials = static_cast<double2*>(workspace);
+    int grid;
+    if (!is_aligned16(x)) {
+        const int64_t want = std::max<int64_t>(1, (n + kBlock - 1) / kBlock);
+        grid = static_cast<int>(std::min<int64_t>(want, static_cast<int64_t>(dev.cu_count) * observe_wg_per_cu(kObserveWgPerTensor)));
+        hipLaunchKernelGGL((moments_pt_scalar_kernel<IO>), dim3(grid), dim3(kBlock), 0, stream, x, n, partials);
+    } else {
+        const int64_t tile = static_cast<int64_t>(kBlock) * kObserveUnroll;
+        const int64_t n_tiles = std::max<int64_t>(1, (n / IO::VEC + tile - 1) / tile);
+        grid = static_cast<int>(std::min<int64_t>(n_tiles, static_cast<int64_t>(dev.cu_count) * observe_wg_per_cu(kObserveWgPerTensor)));
+        hipLaunchKernelGGL((moments_pt_kernel<IO, kObserveUnroll>), dim3(grid), dim3(kBlock), 0, stream, x, n, partials);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((moments_pt_finalize_kernel<IO>), dim3(1), dim3(kBlock), 0, stream, partials, grid, x, n,
+                       static_cast<T*>(out_mean), static_cast<T*>(out_std));
+    return hipGetLastError();
+}
+
+template <typename IO>
+hipError_t meanstd_per_channel(const void* x, int64_t outer, int64_t channels, int64_t inner, void* out_mean,
+                               void* out_std, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    using T = typename IO::arith;
+    const DeviceInfo& dev = device_info();
+    const int vec = pick_vec(IO::VEC, channels * inner, is_aligned16(x));
+    const unsigned fgrid = static_cast<unsigned>((channels + kMmFinCh - 1) / kMmFinCh);
+    auto* partials = static_cast<double2*>(workspace);
+    if (pick_segment_mode(vec, outer, channels, inner)) {
+        const SegGeom sg = make_seg_geom(outer, channels, inner, vec, dev.cu_count * observe_wg_per_cu(kObserveWgSegment));
+        if (!grid_fits(sg)) return hipErrorInvalidConfiguration;
+        if (workspace_bytes < static_cast<size_t>(channels) * sg.segs * sg.osplits * sizeof(double2)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((moments_seg_kernel<IO, IO::VEC, kObserveUnroll>),
+                           dim3(static_cast<unsigned>(sg.C * sg.segs), static_cast<unsigned>(sg.osplits)), dim3(kBlock), 0,
+                           stream, x, sg, partials);
+        hipError_t es = hipGetLastError();
+        if (es != hipSuccess) return es;
+        hipLaunchKernelGGL((moments_seg_finalize_kernel<IO>), dim3(fgrid), dim3(kBlock), 0, stream, partials, sg, x,
+                           static_cast<T*>(out_mean), static_cast<T*>(out_std));
+        return hipGetLastError();
+    }
+    const PcGeom g = observe_geom(outer, channels, inner, vec, dev.cu_count);
+    if (!grid_fits(g)) return hipErrorInvalidConfiguration;
+    if (workspace_bytes < static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2)) return hipErrorInvalidValue;
+    const dim3 grid(static_cast<unsigned>(g.n_windows), static_cast<unsigned>(g.splits));
+    const size_t lds = static_cast<size_t>(g.k_slots) * 3 * sizeof(double);
+    if (vec == 1)
+        hipLaunchKernelGGL((moments_pc_kernel<IO, 1, kObserveUnroll>), grid, dim3(kBlock), lds, stream, x, g, partials);
+    else
+        hipLaunchKernelGGL((moments_pc_kernel<IO, IO::VEC, kObserveUnroll>), grid, dim3(kBlock), lds, stream, x, g, partials);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((moments_pc_finalize_kernel<IO>), dim3(fgrid), dim3(kBlock), 0, stream, partials, g, x,
+                       static_cast<T*>(out_mean), static_cast<T*>(out_std));
+    return hipGetLastError();
+}
+
 #define LSQ_INSTANTIATE(IO)                                                                                   \
+    template hipError_t meanstd_per_tensor<IO>(const void*, int64_t, void*, void*, void*, hipStream_t);       \
+    template hipError_t meanstd_per_channel<IO>(const void*, int64_t, int64_t, int64_t, void*, void*, void*, \
+                                                size_t, hipStream_t);                                        \
     template hipError_t minmax_per_tensor<IO>(const void*, int64_t, void*, void*, void*, hipStream_t);        \
     template hipError_t minmax_per_channel<IO>(const void*, int64_t, int64_t, int64_t, void*, void*, void*,  \
                                                size_t, hipStream_t);

@@ -65,6 +65,9 @@ C_ABI = {
     "lsq_hip_minmax_workspace": (_sz, [_int, _i64, _i64, _i64]),
     "lsq_hip_minmax_per_tensor": (_int, [_int, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "lsq_hip_minmax_per_channel": (_int, [_int, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "lsq_hip_meanstd_workspace": (_sz, [_int, _i64, _i64, _i64]),
+    "lsq_hip_meanstd_per_tensor": (_int, [_int, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "lsq_hip_meanstd_per_channel": (_int, [_int, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
 }
 # tuning twins (csrc/lsq_internal.h): same signatures + a trailing launch-variant code
 C_ABI_INTERNAL = {
@@ -221,6 +224,10 @@ _lib_def.define("lsq_backward_per_channel_wide(Tensor grad, Tensor x, Tensor sca
 _lib_def.define("lsq_backward_from_mask(Tensor grad, Tensor mask) -> Tensor")
 _lib_def.define("lsq_minmax_per_tensor(Tensor x) -> (Tensor, Tensor)")
 _lib_def.define("lsq_minmax_per_channel(Tensor x, int axis) -> (Tensor, Tensor)")
+#  * `lsq_meanstd*`: one-pass mean and unbiased standard deviation (torch.mean / torch.std semantics) for the
+#    3-sigma initialisation of weight quantizers.
+_lib_def.define("lsq_meanstd_per_tensor(Tensor x) -> (Tensor, Tensor)")
+_lib_def.define("lsq_meanstd_per_channel(Tensor x, int axis) -> (Tensor, Tensor)")
 _lib_def.define("lsq_quantize_per_tensor(Tensor x, Tensor scale, Tensor shift, int quant_min, int quant_max, "
                 "int type_min, int type_max, int level_bias) -> (Tensor, Tensor)")
 _lib_def.define("lsq_quantize_per_channel(Tensor x, Tensor scale, Tensor shift, int axis, int quant_min, "
@@ -547,13 +554,12 @@ def hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax
 _WS_BYTES_MM = {}
 
 
-def hip_minmax(x, axis=None):
-    """(min, max) of x -- over everything (axis None) or per channel along `axis` -- in one read-only pass.
-    torch.aminmax semantics (a NaN makes both results NaN); results are fp32 (fp64 for fp64 input)."""
+def _two_stats(x, axis, what, ws_fn, pt_fn, pc_fn):
+    """Shared host path of the one-pass statistics kernels: two results, scalar (axis None) or per channel."""
     _assert_has_ops()
-    _check(x.dtype in _DTYPE_CODE, '"lsq_minmax" not implemented for \'%s\'' % str(x.dtype).replace("torch.", ""))
-    _check(x.numel() > 0, "lsq_minmax: cannot reduce an empty tensor")
-    _require_gpu("lsq_minmax", x)
+    _check(x.dtype in _DTYPE_CODE, '"%s" not implemented for \'%s\'' % (what, str(x.dtype).replace("torch.", "")))
+    _check(x.numel() > 0, "%s: cannot reduce an empty tensor" % what)
+    _require_gpu(what, x)
     xd, order = _dense(x.detach())
     pd = _param_dtype(x)
     dev = x.device
@@ -564,26 +570,43 @@ def hip_minmax(x, axis=None):
     else:
         _check(0 <= axis < x.dim(), "`axis` must be between 0 and number of dimensions of input")
         outer, C, inner = _ocl(xd, order, axis)
-    mn = torch.empty(C, dtype=pd, device=dev)
-    mx = torch.empty(C, dtype=pd, device=dev)
-    wkey = (idx, code, outer, C, inner)
+    a = torch.empty(C, dtype=pd, device=dev)
+    b = torch.empty(C, dtype=pd, device=dev)
+    wkey = (what, idx, code, outer, C, inner)
     nbytes = _WS_BYTES_MM.get(wkey)
     if nbytes is None:
-        nbytes = int(_on_device(idx, _LIB.lsq_hip_minmax_workspace, code, outer, C, inner))
+        nbytes = int(_on_device(idx, ws_fn, code, outer, C, inner))
         if len(_WS_BYTES_MM) < 4096:
             _WS_BYTES_MM[wkey] = nbytes
     ws = _workspace(dev, nbytes)
     if axis is None:
-        rc = _on_device(idx, _LIB.lsq_hip_minmax_per_tensor, code, xd.data_ptr(), xd.numel(), mn.data_ptr(), mx.data_ptr(),
+        rc = _on_device(idx, pt_fn, code, xd.data_ptr(), xd.numel(), a.data_ptr(), b.data_ptr(),
                         ws.data_ptr(), ws.numel(), _stream_of(idx))
     else:
-        rc = _on_device(idx, _LIB.lsq_hip_minmax_per_channel, code, xd.data_ptr(), outer, C, inner, mn.data_ptr(),
-                        mx.data_ptr(), ws.data_ptr(), ws.numel(), _stream_of(idx))
+        rc = _on_device(idx, pc_fn, code, xd.data_ptr(), outer, C, inner, a.data_ptr(),
+                        b.data_ptr(), ws.data_ptr(), ws.numel(), _stream_of(idx))
     if rc:
-        _status(rc, "lsq_hip_minmax")
+        _status(rc, what)
     if axis is None:
-        return mn.reshape(()), mx.reshape(())
-    return mn, mx
+        return a.reshape(()), b.reshape(())
+    return a, b
+
+
+def hip_minmax(x, axis=None):
+    """(min, max) of x -- over everything (axis None) or per channel along `axis` -- in one read-only pass.
+    torch.aminmax semantics (a NaN makes both results NaN); results are fp32 (fp64 for fp64 input)."""
+    _assert_has_ops()
+    return _two_stats(x, axis, "lsq_minmax", _LIB.lsq_hip_minmax_workspace, _LIB.lsq_hip_minmax_per_tensor,
+                      _LIB.lsq_hip_minmax_per_channel)
+
+
+def hip_meanstd(x, axis=None):
+    """(mean, unbiased std) of x -- over everything (axis None) or per channel along `axis`, over the other axes --
+    in one read-only pass (reference observers.py:329-337 uses torch.mean + torch.std); fp64 accumulation,
+    results fp32 (fp64 for fp64 input)."""
+    _assert_has_ops()
+    return _two_stats(x, axis, "lsq_meanstd", _LIB.lsq_hip_meanstd_workspace, _LIB.lsq_hip_meanstd_per_tensor,
+                      _LIB.lsq_hip_meanstd_per_channel)
 
 
 def _impl_minmax_pt(x):
@@ -592,6 +615,14 @@ def _impl_minmax_pt(x):
 
 def _impl_minmax_pc(x, axis):
     return hip_minmax(x, axis)
+
+
+def _impl_meanstd_pt(x):
+    return hip_meanstd(x, None)
+
+
+def _impl_meanstd_pc(x, axis):
+    return hip_meanstd(x, axis)
 
 
 def _impl_fwd_pt(x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode):
@@ -646,6 +677,8 @@ _lib_hip.impl("lsq_quantize_per_channel", _impl_quantize_pc)
 _lib_hip.impl("lsq_backward_from_mask", hip_backward_from_mask)
 _lib_hip.impl("lsq_minmax_per_tensor", _impl_minmax_pt)
 _lib_hip.impl("lsq_minmax_per_channel", _impl_minmax_pc)
+_lib_hip.impl("lsq_meanstd_per_tensor", _impl_meanstd_pt)
+_lib_hip.impl("lsq_meanstd_per_channel", _impl_meanstd_pc)
 
 
 # -------------------------------------------------------------------------------------------------
@@ -710,6 +743,10 @@ def _fake_minmax_pt(x):
 def _fake_minmax_pc(x, axis):
     pd = _param_dtype(x)
     return x.new_empty((x.size(axis),), dtype=pd), x.new_empty((x.size(axis),), dtype=pd)
+
+
+torch.library.register_fake("torchlsq::lsq_meanstd_per_tensor", _fake_minmax_pt, lib=_lib_def)
+torch.library.register_fake("torchlsq::lsq_meanstd_per_channel", _fake_minmax_pc, lib=_lib_def)
 
 
 # -------------------------------------------------------------------------------------------------

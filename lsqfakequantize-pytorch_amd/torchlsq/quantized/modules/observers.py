@@ -307,7 +307,12 @@ class LSQFakeQuantizer(ObserverBase):
             other_axes = [d for d in range(w.ndim) if d != self.ch_axis]
             bits = ceil(log(self.quant_max - self.quant_min) / log(2)) - 1
             with torch.no_grad():
-                if n == 1:
+                if w.is_cuda and w.numel() > 0:      # one read-only pass in the gfx950 statistics kernels
+                    if n == 1:
+                        mu, sigma = (t.reshape(1) for t in torch.ops.torchlsq.lsq_meanstd_per_tensor(w))
+                    else:
+                        mu, sigma = torch.ops.torchlsq.lsq_meanstd_per_channel(w, self.ch_axis)
+                elif n == 1:
                     mu, sigma = w.mean().unsqueeze(0), w.std().unsqueeze(0)
                 else:
                     mu, sigma = torch.mean(w, other_axes), torch.std(w, other_axes)

@@ -217,3 +217,27 @@ def axis_to_ocl(shape, axis):
     outer = int(np.prod(shape[:axis], dtype=np.int64)) if axis > 0 else 1
     inner = int(np.prod(shape[axis + 1:], dtype=np.int64)) if axis + 1 < len(shape) else 1
     return outer, int(shape[axis]), inner
+
+
+def meanstd(x, outer, C, inner):
+    """Per-channel mean and unbiased standard deviation over the [outer, C, inner] view: the statistics of the
+    reference module's 3-sigma weight initialisation (quantized/modules/observers.py:329-337: torch.mean / torch.std
+    over the non-channel axes, or over everything for C == 1).  The algorithm itself lives in ATen (torch.std =
+    sqrt(sum((x - mean)^2) / (n - 1))); restated here as the textbook two-pass form in fp64 -- pinned against
+    torch.mean / torch.std and against the scales the reference module produced (tests/golden/module_traces.json)
+    in tests/test_oracle_pinned.py.  n == 1 gives std = NaN, like torch."""
+    v = np.asarray(x, dtype=np.float64).reshape(outer, C, inner)
+    n = outer * inner
+    with np.errstate(invalid="ignore", divide="ignore"):
+        mu = v.sum(axis=(0, 2)) / n
+        dev = v - mu.reshape(1, C, 1)
+        var = (dev * dev).sum(axis=(0, 2)) / (n - 1) if n > 1 else np.full(C, np.nan)
+        return mu, np.sqrt(var)
+
+
+def sigma_init_scale(mu, sigma, quant_min, quant_max):
+    """scale = max(|mu - 3 sigma|, |mu + 3 sigma|) / 2^bits, bits = ceil(log2(quant_max - quant_min)) - 1
+    (reference observers.py:329-337)."""
+    import math
+    bits = math.ceil(math.log(quant_max - quant_min) / math.log(2)) - 1
+    return np.maximum(np.abs(mu - 3 * sigma), np.abs(mu + 3 * sigma)) / 2 ** bits

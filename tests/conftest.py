@@ -38,6 +38,13 @@ def small_cases():
 
 
 @pytest.fixture(scope="session")
+def traces():
+    """State-machine traces of the reference LSQFakeQuantizer (tests/golden/make_module_traces.py)."""
+    with open(os.path.join(GOLDEN, "module_traces.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
 def config_digests():
     with open(os.path.join(GOLDEN, "config_digests.json")) as f:
         return json.load(f)["configs"]
@@ -115,9 +122,20 @@ def install_oracle_cpu_backend():
         y = x.detach().to(E._param_dtype(x))
         return torch.amin(y, dims), torch.amax(y, dims)
 
+    def meanstd_pt(x):
+        y = x.detach().to(E._param_dtype(x))
+        return y.mean(), y.std()
+
+    def meanstd_pc(x, axis):
+        dims = [d for d in range(x.dim()) if d != axis]
+        y = x.detach().to(E._param_dtype(x))
+        return torch.mean(y, dims), torch.std(y, dims)
+
     lib = torch.library.Library("torchlsq", "IMPL", "CPU")
     lib.impl("lsq_minmax_per_tensor", minmax_pt)
     lib.impl("lsq_minmax_per_channel", minmax_pc)
+    lib.impl("lsq_meanstd_per_tensor", meanstd_pt)
+    lib.impl("lsq_meanstd_per_channel", meanstd_pc)
     lib.impl("lsq_forward_per_tensor", fwd_pt)
     lib.impl("lsq_backward_per_tensor", bwd_pt)
     lib.impl("lsq_backward_per_tensor_wide", bwd_pt_wide)

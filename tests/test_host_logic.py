@@ -25,12 +25,6 @@ def _load_driver():
     return m
 
 
-@pytest.fixture(scope="module")
-def traces():
-    with open(os.path.join(GOLDEN, "module_traces.json")) as f:
-        return json.load(f)
-
-
 def _close(a, b, what):
     if a is None or b is None:
         assert a is None and b is None, what

@@ -166,3 +166,42 @@ def test_oracle_bitwise_vs_reference_scalar_header(dtype):
     assert_bits_equal(r.dx, dx_ref, "dx_pc")
     assert_bits_equal(r.ds_buf, dsb, "ds_buffer_pc")
     assert_bits_equal(r.db_buf, dbb, "db_buffer_pc")
+
+
+def test_oracle_meanstd_pinned(traces):
+    """The statistics restatement against (1) torch.mean / torch.std, which is what the reference module calls
+    (observers.py:329-337), and (2) the scales the reference module itself produced for its weight scenarios
+    (tests/golden/module_traces.json, generated by importing the reference in place)."""
+    import torch
+    from torchlsq import synth
+    for shape, axis in (((16, 8, 3, 3), 0), ((4, 8, 6, 6), 1), ((33, 1000), 1), ((7,), None), ((1, 5, 1), 1)):
+        n = int(np.prod(shape))
+        x = synth.normal_like(n, 5, 0.7, 1.3, dtype=torch.float64).view(shape)
+        if axis is None:
+            mu, sd = O.meanstd(x.numpy(), 1, 1, n)
+            wmu, wsd = x.mean().reshape(1), x.std().reshape(1)
+        else:
+            outer, C, inner = O.axis_to_ocl(shape, axis)
+            mu, sd = O.meanstd(x.numpy(), outer, C, inner)
+            dims = [d for d in range(len(shape)) if d != axis]
+            wmu, wsd = torch.mean(x, dims), torch.std(x, dims)
+        np.testing.assert_allclose(mu, wmu.numpy(), rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(sd, wsd.numpy(), rtol=1e-12, atol=0, equal_nan=True)
+    checked = 0
+    for name, t in traces["traces"].items():
+        sc = t["scenario"]
+        if sc["ctor"].get("otype") != "weight":
+            continue
+        shape = sc["shape"]
+        n = int(np.prod(shape))
+        w = synth.normal_like(n, 100, sc["x_mean"], sc["x_std"]).view(shape).numpy()     # the creating call's input
+        per_channel = "per_channel" in sc["ctor"].get("qscheme", "")
+        axis = sc["ctor"].get("ch_axis", 0)
+        outer, C, inner = O.axis_to_ocl(tuple(shape), axis) if per_channel else (1, 1, n)
+        mu, sd = O.meanstd(w, outer, C, inner)
+        fin = t["final"]
+        scale = O.sigma_init_scale(mu, sd, fin["quant_min"], fin["quant_max"])
+        np.testing.assert_allclose(scale, np.asarray(t["calls"][0]["scale"], dtype=np.float64), rtol=2e-6, atol=0,
+                                   err_msg=name)
+        checked += 1
+    assert checked >= 3

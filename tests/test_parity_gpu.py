@@ -763,3 +763,86 @@ def test_non_finite_gradients_stay_in_their_channel(dev, shape, axis, dtype):
     assert_reduction_close(ds[ok], want_s[ok], np.asarray(r.abs_ds)[ok], "ds (finite channels)")
     ok = ~bad_b
     assert_reduction_close(db[ok], want_b[ok], np.asarray(r.abs_db)[ok], "db (finite channels)")
+
+
+@pytest.mark.parametrize("shape,axis", MM_SHAPES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16])
+def test_meanstd_matches_oracle(dev, shape, axis, dtype):
+    """One-pass mean / unbiased std (the 3-sigma weight initialisation, reference observers.py:329-337) against the
+    fp64 two-pass oracle: 1e-6 relative for fp32 results (they are the correctly rounded fp64 values up to the
+    accumulation error), 1e-12 for fp64; also with a mean 1e5 sigma away from zero (a one-pass sum of squares
+    without the pivot loses everything there) and with non-finite inputs (torch semantics)."""
+    from torchlsq import synth
+    n = int(np.prod(shape))
+    pdt = torch.float64 if dtype == torch.float64 else torch.float32
+    rtol = 1e-12 if dtype == torch.float64 else 1e-6
+    for mean, std in ((0.3, 2.0), (1000.0, 0.01)):
+        if dtype == torch.bfloat16 and mean == 1000.0:
+            continue                                     # bf16 cannot represent that data
+        x = synth.normal_like(n, 62, mean, std, dtype=dtype).view(shape)
+        if axis is None:
+            mu, sd = torch.ops.torchlsq.lsq_meanstd_per_tensor(x.to(dev))
+            wmu, wsd = O.meanstd(x.to(torch.float64).numpy(), 1, 1, n)
+            assert mu.shape == () and sd.shape == ()
+        else:
+            mu, sd = torch.ops.torchlsq.lsq_meanstd_per_channel(x.to(dev), axis)
+            outer, C, inner = O.axis_to_ocl(shape, axis)
+            wmu, wsd = O.meanstd(x.to(torch.float64).numpy(), outer, C, inner)
+            assert mu.shape == (C,) and sd.shape == (C,)
+        assert mu.dtype == pdt and sd.dtype == pdt
+        np.testing.assert_allclose(mu.cpu().numpy().reshape(-1), wmu, rtol=rtol, atol=1e-7 * std)
+        np.testing.assert_allclose(sd.cpu().numpy().reshape(-1), wsd, rtol=rtol, atol=0, equal_nan=True)
+    # non-finite inputs propagate like torch.mean / torch.std (per channel)
+    x = synth.normal_like(n, 63, 0.0, 1.0, dtype=dtype).view(shape).clone()
+    x.view(-1)[0] = float("inf")             # also the pivot of channel 0
+    x.view(-1)[n - 1] = float("nan")
+    xr = x.to(pdt)
+    if axis is None:
+        mu, sd = torch.ops.torchlsq.lsq_meanstd_per_tensor(x.to(dev))
+        wmu, wsd = xr.mean(), xr.std()
+    else:
+        mu, sd = torch.ops.torchlsq.lsq_meanstd_per_channel(x.to(dev), axis)
+        dims = [d for d in range(len(shape)) if d != axis]
+        wmu, wsd = torch.mean(xr, dims), torch.std(xr, dims)
+    mu, sd, wmu, wsd = (t.reshape(-1).cpu().double() for t in (mu, sd, wmu, wsd))
+    assert torch.equal(mu.isnan(), wmu.isnan()) and torch.equal(mu.isinf(), wmu.isinf()), (mu, wmu)
+    assert torch.equal(sd.isnan(), wsd.isnan()), (sd, wsd)
+    ok = ~(wmu.isnan() | wmu.isinf())
+    np.testing.assert_allclose(mu[ok].numpy(), wmu[ok].numpy(), rtol=1e-5, atol=1e-6)
+    # misaligned view (scalar path)
+    if axis is None and n > 8:
+        v = synth.normal_like(n, 64, 0.3, 2.0, dtype=dtype)
+        mu, sd = torch.ops.torchlsq.lsq_meanstd_per_tensor(v.to(dev)[1:])
+        wmu, wsd = O.meanstd(v[1:].to(torch.float64).numpy(), 1, 1, n - 1)
+        np.testing.assert_allclose(mu.item(), wmu[0], rtol=rtol, atol=2e-7)
+        np.testing.assert_allclose(sd.item(), wsd[0], rtol=rtol)
+
+
+def test_sigma_init_on_gpu_matches_reference_traces(dev, traces):
+    """The weight quantizer's creating call on a GPU weight: scale from the one-pass statistics kernel == the scale
+    the reference module computed with torch.mean / torch.std (goldens generated from the reference itself)."""
+    import importlib.util
+    import os
+    from torchlsq import synth
+    from torchlsq.quantized import LSQFakeQuantizer
+    spec = importlib.util.spec_from_file_location("make_module_traces", os.path.join(os.path.dirname(__file__), "golden",
+                                                                                       "make_module_traces.py"))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    from torch.ao.quantization import observer as obs_mod
+    checked = 0
+    for name, t in traces["traces"].items():
+        sc = t["scenario"]
+        if sc["ctor"].get("otype") != "weight":
+            continue
+        observer = getattr(obs_mod, sc["observer"]) if sc["observer"] else None
+        m = LSQFakeQuantizer(observer, **drv.build_kwargs(sc["ctor"])).to(dev)
+        m.train()
+        n = int(np.prod(sc["shape"]))
+        w = synth.normal_like(n, 100, sc["x_mean"], sc["x_std"]).view(sc["shape"]).to(dev)
+        assert m(w) is w                                                 # the creating call passes its input through
+        want = np.asarray(t["calls"][0]["scale"], dtype=np.float64)
+        assert m.scale.is_cuda and m.scale.dtype == torch.float32
+        np.testing.assert_allclose(m.scale.detach().cpu().numpy().astype(np.float64), want, rtol=2e-6, atol=0, err_msg=name)
+        checked += 1
+    assert checked >= 3

@@ -53,3 +53,23 @@ for name, shape, axis, dt in (("cfg2 per-tensor fp32", (128, 512, 56, 56), None,
         t_old = timeit(stock)
     print("%-36s one-pass kernel %8.2f us = %6.0f GB/s (%.1f%% of 8 TB/s) | torch path %8.2f us (%.1fx)" %
           (name, t_new, nb / t_new / 1e3, nb / t_new / 1e3 / 80, t_old, t_old / t_new))
+
+# mean / unbiased std (3-sigma weight initialisation) against torch.mean + torch.std
+for name, shape, axis, dt in (("cfg3 weights axis0 fp32", (512, 512, 3, 3), 0, torch.float32),
+                              ("cfg3 weights per-tensor fp32", (512, 512, 3, 3), None, torch.float32),
+                              ("linear weight [4096,11008] axis0 bf16", (4096, 11008), 0, torch.bfloat16),
+                              ("cfg2 per-tensor fp32", (128, 512, 56, 56), None, torch.float32),
+                              ("cfg5 per-channel axis1 fp32", (256, 2048, 7, 7), 1, torch.float32)):
+    n = 1
+    for d in shape: n *= d
+    x = synth.normal_like(n, 5, 0.0, 1.0, device=dev, dtype=dt).view(shape)
+    nb = n * x.element_size()
+    if axis is None:
+        t_new = timeit(lambda: ops.lsq_meanstd_per_tensor(x))
+        t_old = timeit(lambda: (x.mean(), x.std()))
+    else:
+        dims = [d for d in range(x.dim()) if d != axis]
+        t_new = timeit(lambda: ops.lsq_meanstd_per_channel(x, axis))
+        t_old = timeit(lambda: (torch.mean(x, dims), torch.std(x, dims)))
+    print("meanstd %-38s one-pass kernel %8.2f us = %6.0f GB/s (%.1f%% of 8 TB/s) | torch mean+std %8.2f us (%.1fx)" %
+          (name, t_new, nb / t_new / 1e3, nb / t_new / 1e3 / 80, t_old, t_old / t_new))
