@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--variant-bwd", type=int, default=0, help=argparse.SUPPRESS)
     a = ap.parse_args()
 
+    # multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise); the
+    # launcher normally exports it already
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import torchlsq  # noqa: F401
