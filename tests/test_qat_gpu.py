@@ -66,3 +66,59 @@ def test_qat_training_loop_with_lsq_qconfig():
     model2.load_state_dict(sd)
     model.eval(); model2.eval()
     assert torch.equal(model(x), model2(x))
+
+
+def test_quantized_block_runs_as_a_hip_graph():
+    """Steady-state QAT block (activation quantizer x per-channel weight quantizer) captured with
+    torch.cuda.make_graphed_callables: forward AND backward replay as HIP graphs (possible because no op or module
+    decision synchronises with the device) and equal the eager results bit for bit.  (The consumer of the two
+    quantizers is a deterministic elementwise/sum expression on purpose: a convolution's weight-gradient kernel
+    picks its own summation order and differs between eager and captured runs by itself.)"""
+    import copy
+    import torch
+    from torch.ao.quantization.observer import MovingAverageMinMaxObserver, MovingAveragePerChannelMinMaxObserver
+    from torchlsq.quantized import LSQFakeQuantizer
+    dev = torch.device("cuda:0")
+
+    class Block(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.aq = LSQFakeQuantizer(MovingAverageMinMaxObserver, "activation", init_batches=1)
+            self.wq = LSQFakeQuantizer(MovingAveragePerChannelMinMaxObserver, "weight", dtype=torch.qint8,
+                                       qscheme=torch.per_channel_symmetric)
+            self.weight = torch.nn.Parameter(torch.randn(16, 16, 3, 3) * 0.05)
+
+        def forward(self, x):
+            per_channel_gain = self.wq(self.weight).sum(dim=(1, 2, 3)).view(1, -1, 1, 1)
+            return self.aq(x) * per_channel_gain
+
+    torch.manual_seed(0)
+    eager = Block().to(dev).train()
+    x = torch.rand(8, 16, 12, 12, device=dev)
+    for _ in range(4):                                   # parameter creation + init batches (not capturable: they
+        eager(x).sum().backward()                        # create parameters and flip host-side state)
+    eager.zero_grad(set_to_none=True)
+    assert eager.aq._h["learning"] == 1 and eager.aq._h["observer"] == 0
+    graphed_src = copy.deepcopy(eager)
+    sample = torch.rand(8, 16, 12, 12, device=dev, requires_grad=True)
+    graphed = torch.cuda.make_graphed_callables(graphed_src, (sample,))
+
+    for step in range(3):
+        xi = torch.rand(8, 16, 12, 12, device=dev)
+        gi = torch.randn(8, 16, 12, 12, device=dev)
+        xa = xi.clone().requires_grad_(True)
+        xb = xi.clone().requires_grad_(True)
+        ya = eager(xa)
+        ya.backward(gi)
+        yb = graphed(xb)
+        yb.backward(gi)
+        assert torch.equal(ya, yb), step
+        assert torch.equal(xa.grad, xb.grad), step
+        for (na, pa), (nb, pb) in zip(eager.named_parameters(), graphed_src.named_parameters()):
+            assert na == nb
+            if na == "wq.shift":                         # symmetric: no gradient for the shift on either route
+                assert pa.grad is None and pb.grad is None
+            else:
+                assert pa.grad is not None and torch.equal(pa.grad, pb.grad), (step, na)
+        eager.zero_grad(set_to_none=True)        # (graphed callables hand out their static gradient buffers: an in-place
+        graphed_src.zero_grad(set_to_none=True)  # zero would alias them -- the usual make_graphed_callables rule)
