@@ -137,6 +137,7 @@ struct io_f32 {
     static constexpr int VEC = 4;
     __device__ static __forceinline__ float load1(const void* p, int64_t i) { return static_cast<const float*>(p)[i]; }
     __device__ static __forceinline__ void store1(void* p, int64_t i, float v) { static_cast<float*>(p)[i] = v; }
+    __device__ static __forceinline__ float to_elem(float v) { return v; }
 };
 struct io_f64 {
     using elem = double;
@@ -144,6 +145,7 @@ struct io_f64 {
     static constexpr int VEC = 2;
     __device__ static __forceinline__ double load1(const void* p, int64_t i) { return static_cast<const double*>(p)[i]; }
     __device__ static __forceinline__ void store1(void* p, int64_t i, double v) { static_cast<double*>(p)[i] = v; }
+    __device__ static __forceinline__ double to_elem(double v) { return v; }
 };
 struct io_bf16 {
     using elem = __bf16;
@@ -152,9 +154,8 @@ struct io_bf16 {
     __device__ static __forceinline__ float load1(const void* p, int64_t i) {
         return static_cast<float>(static_cast<const __bf16*>(p)[i]);
     }
-    __device__ static __forceinline__ void store1(void* p, int64_t i, float v) {
-        static_cast<__bf16*>(p)[i] = static_cast<__bf16>(v);  // RNE (v_cvt_pk_bf16_f32 on gfx950)
-    }
+    __device__ static __forceinline__ __bf16 to_elem(float v) { return static_cast<__bf16>(v); }  // RNE (v_cvt_pk_bf16_f32)
+    __device__ static __forceinline__ void store1(void* p, int64_t i, float v) { static_cast<__bf16*>(p)[i] = to_elem(v); }
 };
 struct io_f16 {
     using elem = _Float16;
@@ -163,9 +164,14 @@ struct io_f16 {
     __device__ static __forceinline__ float load1(const void* p, int64_t i) {
         return static_cast<float>(static_cast<const _Float16*>(p)[i]);
     }
-    __device__ static __forceinline__ void store1(void* p, int64_t i, float v) {
-        static_cast<_Float16*>(p)[i] = static_cast<_Float16>(v);
+    // The fp32 result and its rounding to fp16 are kept apart by an (empty) asm: hipcc otherwise selects
+    // "fp16 -> fp32, multiply by the 0/1 mask, -> fp16" as v_fma_mixlo_f16 a, b, +0, and the +0 addend turns the
+    // -0 of (negative grad) * 0 into +0 (found by tests/test_fuzz_gpu.py; fp32 and bf16 storage keep the sign).
+    __device__ static __forceinline__ _Float16 to_elem(float v) {
+        asm("" : "+v"(v));
+        return static_cast<_Float16>(v);
     }
+    __device__ static __forceinline__ void store1(void* p, int64_t i, float v) { static_cast<_Float16*>(p)[i] = to_elem(v); }
 };
 
 // A 16-byte packet of IO::VEC storage elements, moved with one global_load/store_dwordx4.

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
             const QParams<T> q = ch.params(j);
             const T xv = static_cast<T>(in[j]);
             const T c = clamped<T>(xv, q, r);
-            out[j] = static_cast<E>(INIT ? xv : dequant<T>(rne(c), q));
+            out[j] = IO::to_elem(INIT ? xv : dequant<T>(rne(c), q));
             if (LEVELS) lv.b[j] = aux_byte<T>(c, r, bias, aux_kind);
         }
         if (valid) {
@@ -265,10 +265,10 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
             const QParams<T> q = ch.params(j);
             const T gv = static_cast<T>(gi[j]), xv = static_cast<T>(xi[j]);
             if (EVAL) {
-                out[j] = static_cast<E>(backward_elem_eval<T, INIT>(gv, xv, q, r));
+                out[j] = IO::to_elem(backward_elem_eval<T, INIT>(gv, xv, q, r));
             } else {
                 T ds_t, db_t;
-                out[j] = static_cast<E>(backward_elem<T, SYM, INIT>(gv, xv, q, r, grad_scaler, ds_t, db_t));
+                out[j] = IO::to_elem(backward_elem<T, SYM, INIT>(gv, xv, q, r, grad_scaler, ds_t, db_t));
                 if (!valid) { ds_t = static_cast<T>(0); db_t = static_cast<T>(0); }
                 const double a = static_cast<double>(ds_t), c = static_cast<double>(db_t);
                 acc_s[j < kAcc ? j : 0] += a;
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(kBlock) void fwd_seg_kernel(const void* __restrict_
         for (int j = 0; j < V; ++j) {
             const T xv = static_cast<T>(in[j]);
             const T c = clamped<T>(xv, q, r);
-            out[j] = static_cast<E>(INIT ? xv : dequant<T>(rne(c), q));
+            out[j] = IO::to_elem(INIT ? xv : dequant<T>(rne(c), q));
             if (LEVELS) lv.b[j] = aux_byte<T>(c, r, bias, aux_kind);
         }
         if (valid) {
@@ -512,10 +512,10 @@ __global__ __launch_bounds__(kBlock) void bwd_seg_kernel(const void* __restrict_
         for (int j = 0; j < V; ++j) {
             const T gv = static_cast<T>(gi[j]), xv = static_cast<T>(xi[j]);
             if (EVAL) {
-                out[j] = static_cast<E>(backward_elem_eval<T, INIT>(gv, xv, q, r));
+                out[j] = IO::to_elem(backward_elem_eval<T, INIT>(gv, xv, q, r));
             } else {
                 T ds_t, db_t;
-                out[j] = static_cast<E>(backward_elem<T, SYM, INIT>(gv, xv, q, r, grad_scaler, ds_t, db_t));
+                out[j] = IO::to_elem(backward_elem<T, SYM, INIT>(gv, xv, q, r, grad_scaler, ds_t, db_t));
                 if (!valid) { ds_t = static_cast<T>(0); db_t = static_cast<T>(0); }
                 acc_s += static_cast<double>(ds_t);
                 if (!SYM) acc_b += static_cast<double>(db_t);

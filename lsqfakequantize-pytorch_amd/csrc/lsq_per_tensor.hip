@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void fwd_pt_kernel(const void* __restrict__
         for (int j = 0; j < VEC; ++j) {
             const T xv = static_cast<T>(in.v[j]);
             const T c = clamped<T>(xv, q, r);
-            out.v[j] = static_cast<typename IO::elem>(INIT ? xv : dequant<T>(rne(c), q));  // lsq_kernel.h:13
+            out.v[j] = IO::to_elem(INIT ? xv : dequant<T>(rne(c), q));  // lsq_kernel.h:13
             if (LEVELS) lv.b[j] = aux_byte<T>(c, r, bias, aux_kind);
         }
         if (NTS) store_packet_nt<IO>(y, p * VEC, out); else store_packet<IO>(y, p * VEC, out);
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void bwd_pt_kernel(const void* __restrict__
         Packet<IO> out;
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
-            out.v[j] = static_cast<typename IO::elem>(
+            out.v[j] = IO::to_elem(
                 acc.step(static_cast<T>(gi.v[j]), static_cast<T>(xi.v[j]), q, r, grad_scaler));
         if (NTS) store_packet_nt<IO>(dx, p * VEC, out); else store_packet<IO>(dx, p * VEC, out);
     };
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(kBlock) void bwd_mask_kernel(const void* __restrict
         Packet<IO> out;
 #pragma unroll
         for (int j = 0; j < VEC; ++j)   // a real multiply, like the reference (inf * 0 = NaN)
-            out.v[j] = static_cast<typename IO::elem>(static_cast<T>(gi.v[j]) * static_cast<T>(m.b[j]));
+            out.v[j] = IO::to_elem(static_cast<T>(gi.v[j]) * static_cast<T>(m.b[j]));
         store_packet_nt<IO>(dx, p * VEC, out);
     };
     for (int64_t tile = blockIdx.x; tile < n_full; tile += gridDim.x) {
