@@ -129,3 +129,72 @@ def test_random_cases_against_the_oracle(seed):
         assert_reduction_close(db, r.db_wide, r.abs_db, tag + " db")
         ran += 1
     assert ran == 30
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_cases_of_the_side_outputs(seed):
+    """Same draws for the ops beside the reference's four: integer levels (int8, bit-exact against the oracle's
+    rne(clamp(x/s + zp))), the eval-mode mask + backward_from_mask, one-pass min/max (exact) and mean/std (1e-6)."""
+    assert torch.cuda.is_available()
+    import torchlsq  # noqa: F401
+    from torchlsq import extension
+    extension._assert_has_ops()
+    ops = torch.ops.torchlsq
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5000 + seed)
+    for case in range(25):
+        shape = _draw_shape(rng)
+        n = int(np.prod(shape))
+        dtype = [torch.float32, torch.float64][int(rng.integers(0, 2))]
+        npdt = np.float64 if dtype == torch.float64 else np.float32
+        per_channel = rng.random() < 0.6
+        axis = int(rng.integers(0, len(shape)))
+        C = shape[axis] if per_channel else 1
+        qmin, qmax, tmin, tmax = RANGES[int(rng.integers(0, len(RANGES)))]
+        step = float(rng.choice([0.003, 0.05, 0.4, 2.0]))
+        x = (rng.standard_normal(n) * step * (qmax - qmin) * 0.4 + step * (qmax + qmin) * 0.5).astype(npdt).reshape(shape)
+        g = (rng.standard_normal(n) * 1e-2).astype(npdt).reshape(shape)
+        scale = (rng.uniform(0.5, 1.5, size=C) * step).astype(npdt)
+        shift = (rng.standard_normal(C) * step * 2.0).astype(npdt)
+        kind = str(rng.choice(["contiguous", "permuted", "channels_last", "non_dense", "offset"]))
+        tag = "seed %d case %d: %s %s pc=%s axis=%d q=(%d,%d,%d,%d) %s" % (seed, case, shape, dtype, per_channel, axis, qmin, qmax,
+                                                                         tmin, tmax, kind)
+        xt = _layout(rng, torch.from_numpy(x).to(dev), kind)
+        gt = torch.from_numpy(g).to(dev)
+        st, bt = torch.from_numpy(scale).to(dev), torch.from_numpy(shift).to(dev)
+        bias = 128 if qmax > 127 else 0
+        if per_channel:
+            outer, C_, inner = O.axis_to_ocl(shape, axis)
+            want_q = O.levels_pc(x, scale, shift, outer, C_, inner, qmin, qmax, tmin, tmax)
+            want_y = O.fwd_pc(x, scale, shift, outer, C_, inner, qmin, qmax, tmin, tmax)
+            r = O.bwd_pc(g, x, scale, shift, outer, C_, inner, qmin, qmax, tmin, tmax, True, 1.0, False, True, False)
+            y, q = ops.lsq_quantize_per_channel(xt, st, bt, axis, qmin, qmax, tmin, tmax, bias)
+            y2, mask = extension.hip_forward_per_channel(xt, st, bt, axis, qmin, qmax, tmin, tmax, True, 1.0, False, True, False,
+                                                         want_mask=True)
+            mn, mx = ops.lsq_minmax_per_channel(xt, axis)
+            mu, sd = ops.lsq_meanstd_per_channel(xt, axis)
+            moved = np.moveaxis(x, axis, 0).reshape(C, -1).astype(np.float64)
+            want_mu, want_sd = O.meanstd(x, outer, C_, inner)
+        else:
+            want_q = O.levels_pt(x, scale[0], shift[0], qmin, qmax, tmin, tmax)
+            want_y = O.fwd_pt(x, scale[0], shift[0], qmin, qmax, tmin, tmax)
+            r = O.bwd_pt(g, x, scale[0], shift[0], qmin, qmax, tmin, tmax, True, 1.0, False, True, False)
+            y, q = ops.lsq_quantize_per_tensor(xt, st, bt, qmin, qmax, tmin, tmax, bias)
+            y2, mask = extension.hip_forward_per_tensor(xt, st, bt, qmin, qmax, tmin, tmax, True, 1.0, False, True, False,
+                                                        want_mask=True)
+            mn, mx = ops.lsq_minmax_per_tensor(xt)
+            mu, sd = ops.lsq_meanstd_per_tensor(xt)
+            moved = x.reshape(1, -1).astype(np.float64)
+            want_mu, want_sd = O.meanstd(x, 1, 1, n)
+        assert q.dtype == torch.int8 and q.shape == xt.shape
+        assert np.array_equal(q.cpu().numpy().astype(np.int32) + bias, want_q.reshape(shape)), tag + " levels"
+        assert_bits_equal(y.cpu().numpy(), want_y, tag + " y (quantize op)")
+        assert_bits_equal(y2.cpu().numpy(), want_y, tag + " y (masked forward)")
+        dx = ops.lsq_backward_from_mask(gt, mask)
+        assert_bits_equal(dx.cpu().numpy(), r.dx, tag + " dx from mask")
+        assert np.array_equal(mn.cpu().numpy().reshape(-1).astype(np.float64), moved.min(axis=1)), tag + " min"
+        assert np.array_equal(mx.cpu().numpy().reshape(-1).astype(np.float64), moved.max(axis=1)), tag + " max"
+        rtol = 1e-12 if dtype == torch.float64 else 1e-6
+        spread = float(np.abs(moved).max()) + 1e-30
+        np.testing.assert_allclose(mu.cpu().numpy().reshape(-1), want_mu, rtol=rtol, atol=rtol * spread, err_msg=tag + " mean")
+        np.testing.assert_allclose(sd.cpu().numpy().reshape(-1), want_sd, rtol=rtol, atol=0, equal_nan=True, err_msg=tag + " std")
