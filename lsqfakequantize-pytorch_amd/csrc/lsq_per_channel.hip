@@ -482,13 +482,34 @@ __global__ __launch_bounds__(kBlock) void fwd_seg_kernel(const void* __restrict_
     }
 }
 
+// Segment mode with ONE workgroup per channel (segs == osplits == 1: every conv / linear weight whose channel row is
+// not worth splitting -- the usual weight quantizer): the workgroup's sums ARE the channel's sums, so the kernel
+// rounds and stores d_scale / d_shift itself and the finalize launch (3-4 us, a third of the backward of a
+// BASELINE-config-3-sized weight) disappears.  ds == nullptr selects the partials + finalize route.
+template <typename T>
+struct SegDirect {
+    T* ds;
+    T* db;
+    double* wide;
+    T sym_term;
+    __device__ __forceinline__ void write(int64_t c, int64_t C, double ts, double tb) const {
+        ds[c] = static_cast<T>(ts);
+        db[c] = static_cast<T>(tb);
+        if (wide) {
+            wide[c] = ts;
+            wide[C + c] = tb;
+        }
+    }
+};
+
 template <typename IO, int V, bool SYM, bool INIT, bool EVAL, int UNROLL, bool NTL, bool NTS>
 __global__ __launch_bounds__(kBlock) void bwd_seg_kernel(const void* __restrict__ grad, const void* __restrict__ x,
                                                          void* __restrict__ dx, SegGeom g,
                                                          const typename IO::arith* __restrict__ scale,
                                                          const typename IO::arith* __restrict__ shift,
                                                          Range<typename IO::arith> r, typename IO::arith grad_scaler,
-                                                         double2* __restrict__ partials) {
+                                                         double2* __restrict__ partials,
+                                                         SegDirect<typename IO::arith> direct) {
     using T = typename IO::arith;
     using E = typename IO::elem;
     __shared__ double2 wave_tot[kBlock / 64];
@@ -538,7 +559,10 @@ __global__ __launch_bounds__(kBlock) void bwd_seg_kernel(const void* __restrict_
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) emit(e[u], gi[u], xi[u], ok[u]);
     }
-    if (EVAL) return;
+    if (EVAL) {
+        if (direct.ds && threadIdx.x == 0) direct.write(w.c, g.C, 0.0, 0.0);   // d_scale = d_shift = 0 (lsq_kernel.h:142-144)
+        return;
+    }
     acc_s = wave_sum(acc_s);
     acc_b = wave_sum(acc_b);
     if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = make_double2(acc_s, acc_b);
@@ -547,7 +571,12 @@ __global__ __launch_bounds__(kBlock) void bwd_seg_kernel(const void* __restrict_
         double ts = 0.0, tb = 0.0;
 #pragma unroll
         for (int k = 0; k < kBlock / 64; ++k) { ts += wave_tot[k].x; tb += wave_tot[k].y; }
-        partials[static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = make_double2(ts, tb);
+        if (direct.ds) {   // this workgroup holds the channel's only partial: finish here, no finalize launch
+            if (SYM) tb = 0.0 + static_cast<double>(direct.sym_term);
+            direct.write(w.c, g.C, ts, tb);
+        } else {
+            partials[static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = make_double2(ts, tb);
+        }
     }
 }
 
@@ -730,13 +759,13 @@ static hipError_t launch_bwd_pc(const void* grad, const void* x, void* dx, const
 template <typename IO, bool SYM, bool INIT, bool EVAL>
 static hipError_t launch_bwd_seg(const void* grad, const void* x, void* dx, const SegGeom& g, const void* scale,
                                  const void* shift, const lsq_params& p, typename IO::arith gs, double2* partials,
-                                 const Variant& v, hipStream_t stream) {
+                                 const SegDirect<typename IO::arith>& direct, const Variant& v, hipStream_t stream) {
     using T = typename IO::arith;
     const Range<T> r = make_range<T>(p);
     const dim3 grid(static_cast<unsigned>(g.C * g.segs), static_cast<unsigned>(g.osplits));
 #define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                         \
     hipLaunchKernelGGL((bwd_seg_kernel<IO, IO::VEC, SYM, INIT, EVAL, U, NTLF, NTSF>), grid, dim3(kBlock), 0, stream, grad, x, dx, \
-                       g, static_cast<const T*>(scale), static_cast<const T*>(shift), r, gs, partials)
+                       g, static_cast<const T*>(scale), static_cast<const T*>(shift), r, gs, partials, direct)
     LSQ_DISPATCH_VARIANT(false, 4, v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH
     return hipGetLastError();
@@ -769,8 +798,8 @@ static hipError_t bwd_pc_modes(const void* grad, const void* x, void* dx, const 
 template <typename IO>
 static hipError_t bwd_seg_modes(const void* grad, const void* x, void* dx, const SegGeom& g, const void* scale,
                                 const void* shift, const lsq_params& p, typename IO::arith gs, double2* partials,
-                                const Variant& v, hipStream_t stream) {
-#define LSQ_CASE(S, I, E) launch_bwd_seg<IO, S, I, E>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream)
+                                const SegDirect<typename IO::arith>& direct, const Variant& v, hipStream_t stream) {
+#define LSQ_CASE(S, I, E) launch_bwd_seg<IO, S, I, E>(grad, x, dx, g, scale, shift, p, gs, partials, direct, v, stream)
     LSQ_MODE_SWITCH(LSQ_CASE);
 #undef LSQ_CASE
 }
@@ -801,8 +830,10 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
         if (!grid_fits(sg)) return hipErrorInvalidConfiguration;
         const size_t need = static_cast<size_t>(channels) * sg.segs * sg.osplits * sizeof(double2);
         if (!p.eval_mode && workspace_bytes < need) return hipErrorInvalidValue;
-        hipError_t e = bwd_seg_modes<IO>(grad, x, dx, sg, scale, shift, p, gs, partials, v, stream);
-        if (e != hipSuccess) return e;
+        const bool one_partial = sg.segs == 1 && sg.osplits == 1;
+        const SegDirect<T> direct{one_partial ? static_cast<T*>(ds) : nullptr, static_cast<T*>(db), wide, sym_term};
+        hipError_t e = bwd_seg_modes<IO>(grad, x, dx, sg, scale, shift, p, gs, partials, direct, v, stream);
+        if (e != hipSuccess || one_partial) return e;
         hipLaunchKernelGGL((finalize_seg_kernel<T>), dim3(fgrid_w), dim3(kBlock), 0, stream, partials, sg,
                            p.eval_mode ? 1 : 0, p.sym ? 1 : 0, sym_term, static_cast<T*>(ds), static_cast<T*>(db), wide);
         return hipGetLastError();
