@@ -87,7 +87,20 @@ size_t lsq_hip_backward_per_tensor_workspace(int dtype, int64_t n) {
 
 size_t lsq_hip_backward_per_channel_workspace(int dtype, int64_t outer, int64_t channels, int64_t inner) {
     if (!dtype_ok(dtype) || outer <= 0 || channels <= 0 || inner <= 0) return 256;
-    return lsq::bwd_pc_workspace_bytes(io_vec(dtype), outer, channels, inner);
+    // The size is the maximum over every launch geometry the tuning range allows (a few dozen candidate geometries).
+    // Callers ask once per backward with the same few shapes: remember the last answers of this thread.
+    struct Memo { int dtype; int64_t outer, channels, inner; size_t bytes; };
+    constexpr int kMemo = 8;
+    thread_local Memo memo[kMemo] = {};
+    thread_local int next = 0;
+    for (int i = 0; i < kMemo; ++i)
+        if (memo[i].bytes && memo[i].dtype == dtype && memo[i].outer == outer && memo[i].channels == channels &&
+            memo[i].inner == inner)
+            return memo[i].bytes;
+    const size_t bytes = lsq::bwd_pc_workspace_bytes(io_vec(dtype), outer, channels, inner);
+    memo[next] = Memo{dtype, outer, channels, inner, bytes};
+    next = (next + 1) % kMemo;
+    return bytes;
 }
 
 int lsq_hip_forward_per_tensor_ex(int dtype, const void* x, void* y, int64_t n, const void* scale, const void* shift,

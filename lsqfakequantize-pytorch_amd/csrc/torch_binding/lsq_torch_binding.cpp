@@ -259,27 +259,28 @@ class LsqNode : public torch::autograd::Function<LsqNode> {
         const Scalars s{qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode};
         auto [y, mask] = forward_impl(x, scale, shift, per_channel, axis, s, masked);
         ctx->save_for_backward({masked ? mask : x, scale, shift});
-        auto& d = ctx->saved_data;
-        d["qmin"] = qmin; d["qmax"] = qmax; d["tmin"] = tmin; d["tmax"] = tmax; d["axis"] = axis;
-        d["use_gs"] = use_gs; d["gs"] = gs; d["sym"] = sym; d["per_channel"] = per_channel;
-        d["eval_mode"] = eval_mode; d["init_mode"] = init_mode; d["masked"] = masked;
+        // two map entries instead of twelve: the integers and flags as one list, the scaler as a double
+        const int64_t flags = (use_gs ? 1 : 0) | (sym ? 2 : 0) | (per_channel ? 4 : 0) | (eval_mode ? 8 : 0) |
+                              (init_mode ? 16 : 0) | (masked ? 32 : 0);
+        ctx->saved_data["cfg"] = c10::IValue(std::vector<int64_t>{qmin, qmax, tmin, tmax, axis, flags});
+        ctx->saved_data["gs"] = gs;
         return y;
     }
 
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx,
                                                    const torch::autograd::variable_list& grads) {
         const auto saved = ctx->get_saved_variables();
-        auto& d = ctx->saved_data;
+        const std::vector<int64_t> cfg = ctx->saved_data["cfg"].toIntVector();
+        const int64_t flags = cfg[5];
         Tensor dx, ds, db;
-        if (d["masked"].toBool()) {
+        if (flags & 32) {   // masked: saved[0] is the inside mask, d_scale = d_shift = 0
             dx = backward_from_mask(grads[0], saved[0]);
             ds = at::zeros_like(saved[1]);
             db = at::zeros_like(saved[2]);
         } else {
-            const Scalars s{d["qmin"].toInt(), d["qmax"].toInt(), d["tmin"].toInt(), d["tmax"].toInt(), d["use_gs"].toBool(),
-                            d["gs"].toDouble(), d["sym"].toBool(), d["eval_mode"].toBool(), d["init_mode"].toBool()};
-            std::tie(dx, ds, db) = backward_impl(grads[0], saved[0], saved[1], saved[2], d["per_channel"].toBool(),
-                                                 d["axis"].toInt(), s);
+            const Scalars s{cfg[0], cfg[1], cfg[2], cfg[3], (flags & 1) != 0, ctx->saved_data["gs"].toDouble(),
+                            (flags & 2) != 0, (flags & 8) != 0, (flags & 16) != 0};
+            std::tie(dx, ds, db) = backward_impl(grads[0], saved[0], saved[1], saved[2], (flags & 4) != 0, cfg[4], s);
         }
         torch::autograd::variable_list out(14);
         out[0] = dx; out[1] = ds; out[2] = db;
