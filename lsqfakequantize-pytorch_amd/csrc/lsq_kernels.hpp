@@ -45,6 +45,7 @@ constexpr int kDefaultPcFwdVariant = encode_variant(4, true, true, 16);
 constexpr int kDefaultPcBwdWideVariant = encode_variant(4, true, true, 16);   // fp32 / fp64 storage
 constexpr int kDefaultPcBwdNarrowVariant = encode_variant(1, true, true, 4) | (1 << 10);  // bf16 / fp16 storage (bit 10: pipelined)
 constexpr int kDefaultPcSegVariant = encode_variant(4, true, true, 16);
+constexpr int kDefaultPcSegNarrowVariant = encode_variant(1, true, true, 16);   // bf16 / fp16 storage
 
 inline Variant decode_variant(int code, int dflt) {
     if (code == 0) code = dflt;

@@ -466,20 +466,27 @@ __global__ __launch_bounds__(kBlock) void fwd_seg_kernel(const void* __restrict_
             if (LEVELS) lv.store(levels + e);
         }
     };
-    for (int64_t it = 0; it < w.n_it; it += UNROLL) {
-        E in[UNROLL][V];
-        int64_t e[UNROLL];
-        bool ok[UNROLL];
+    // n_it = full groups of UNROLL + (if left) one group of UNROLL/2 + ... + one single iteration: every slot of
+    // every group is a real iteration (a padded last group would load and compute for nothing; a weight channel has
+    // only a handful of iterations, so that was up to half of the kernel's work)
+    auto group = [&](int64_t it, auto width) {
+        constexpr int H = decltype(width)::value;
+        E in[H][V];
+        int64_t e[H];
+        bool ok[H];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int64_t k = it + u < w.n_it ? it + u : w.n_it - 1;
-            e[u] = site(k, ok[u]);
-            ok[u] = ok[u] && (it + u < w.n_it);
+        for (int u = 0; u < H; ++u) {
+            e[u] = site(it + u, ok[u]);
             load_elems<IO, V, NTL>(x, e[u], in[u]);
         }
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) emit(e[u], in[u], ok[u]);
-    }
+        for (int u = 0; u < H; ++u) emit(e[u], in[u], ok[u]);
+    };
+    int64_t it = 0;
+    for (; it + UNROLL <= w.n_it; it += UNROLL) group(it, std::integral_constant<int, UNROLL>{});
+    if constexpr (UNROLL >= 8) if (it + 4 <= w.n_it) { group(it, std::integral_constant<int, 4>{}); it += 4; }
+    if constexpr (UNROLL >= 4) if (it + 2 <= w.n_it) { group(it, std::integral_constant<int, 2>{}); it += 2; }
+    if constexpr (UNROLL >= 2) if (it < w.n_it) group(it, std::integral_constant<int, 1>{});
 }
 
 // Segment mode with ONE workgroup per channel (segs == osplits == 1: every conv / linear weight whose channel row is
@@ -544,21 +551,25 @@ __global__ __launch_bounds__(kBlock) void bwd_seg_kernel(const void* __restrict_
         }
         if (valid) store_elems<IO, V, NTS>(dx, e, out);
     };
-    for (int64_t it = 0; it < w.n_it; it += UNROLL) {
-        E gi[UNROLL][V], xi[UNROLL][V];
-        int64_t e[UNROLL];
-        bool ok[UNROLL];
+    auto group = [&](int64_t it, auto width) {     // see fwd_seg_kernel: groups of UNROLL, then UNROLL/2, ..., 1
+        constexpr int H = decltype(width)::value;
+        E gi[H][V], xi[H][V];
+        int64_t e[H];
+        bool ok[H];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int64_t k = it + u < w.n_it ? it + u : w.n_it - 1;
-            e[u] = site(k, ok[u]);
-            ok[u] = ok[u] && (it + u < w.n_it);
+        for (int u = 0; u < H; ++u) {
+            e[u] = site(it + u, ok[u]);
             load_elems<IO, V, NTL>(grad, e[u], gi[u]);
             load_elems<IO, V, NTL>(x, e[u], xi[u]);
         }
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) emit(e[u], gi[u], xi[u], ok[u]);
-    }
+        for (int u = 0; u < H; ++u) emit(e[u], gi[u], xi[u], ok[u]);
+    };
+    int64_t it = 0;
+    for (; it + UNROLL <= w.n_it; it += UNROLL) group(it, std::integral_constant<int, UNROLL>{});
+    if constexpr (UNROLL >= 8) if (it + 4 <= w.n_it) { group(it, std::integral_constant<int, 4>{}); it += 4; }
+    if constexpr (UNROLL >= 4) if (it + 2 <= w.n_it) { group(it, std::integral_constant<int, 2>{}); it += 2; }
+    if constexpr (UNROLL >= 2) if (it < w.n_it) group(it, std::integral_constant<int, 1>{});
     if (EVAL) {
         if (direct.ds && threadIdx.x == 0) direct.write(w.c, g.C, 0.0, 0.0);   // d_scale = d_shift = 0 (lsq_kernel.h:142-144)
         return;
@@ -619,6 +630,11 @@ __global__ __launch_bounds__(kBlock) void finalize_seg_kernel(const double2* __r
 // =================================================================================================
 // host-side launchers
 // =================================================================================================
+// Packets in flight per lane in the segment kernels (profiles/r01_segment_sweep.txt, typical weight shapes): 4 for
+// 4/8-byte storage; 16-bit storage (twice the arithmetic and registers per packet, half the packets per channel --
+// [4096, 4096] in bf16 is two packets per lane) runs best at 1: [32000, 4096] bf16 backward 125 us vs 143 us at 4.
+template <typename IO>
+constexpr int kSegUnroll = sizeof(typename IO::elem) < 4 ? 1 : 4;
 static inline int pick_cpl(int vec, int64_t inner) {
     if (vec == 1 || inner % vec == 0) return 1;
     return inner >= vec ? 2 : vec;
@@ -668,7 +684,8 @@ static hipError_t launch_fwd_seg(const void* x, void* y, int8_t* levels, int bia
 #define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                      \
     hipLaunchKernelGGL((fwd_seg_kernel<IO, IO::VEC, INIT, LEVELS, U, NTLF, NTSF>), grid, dim3(kBlock), 0, stream, x, y, levels, \
                        bias, aux_kind, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r)
-    LSQ_DISPATCH_VARIANT(false, 4, v, LSQ_LAUNCH);
+    [[maybe_unused]] constexpr bool kFull = !INIT && !LEVELS && (std::is_same<IO, io_f32>::value || std::is_same<IO, io_bf16>::value);
+    LSQ_DISPATCH_VARIANT(kFull, kSegUnroll<IO>, v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH
     return hipGetLastError();
 }
@@ -695,7 +712,8 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
     const bool aligned = is_aligned16(x) && is_aligned16(y) && (!levels || (reinterpret_cast<uintptr_t>(levels) & 7u) == 0);
     const int vec = pick_vec(IO::VEC, channels * inner, aligned);
     const bool seg = pick_segment_mode(vec, outer, channels, inner);
-    const Variant v = decode_variant(variant, seg ? kDefaultPcSegVariant : kDefaultPcFwdVariant);
+    const Variant v = decode_variant(variant, seg ? (sizeof(typename IO::elem) >= 4 ? kDefaultPcSegVariant : kDefaultPcSegNarrowVariant)
+                                                  : kDefaultPcFwdVariant);
     const int target = dev.cu_count * v.blocks_per_cu;
     if (seg) {
         const SegGeom sg = make_seg_geom(outer, channels, inner, vec, target);
@@ -766,7 +784,8 @@ static hipError_t launch_bwd_seg(const void* grad, const void* x, void* dx, cons
 #define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                         \
     hipLaunchKernelGGL((bwd_seg_kernel<IO, IO::VEC, SYM, INIT, EVAL, U, NTLF, NTSF>), grid, dim3(kBlock), 0, stream, grad, x, dx, \
                        g, static_cast<const T*>(scale), static_cast<const T*>(shift), r, gs, partials, direct)
-    LSQ_DISPATCH_VARIANT(false, 4, v, LSQ_LAUNCH);
+    [[maybe_unused]] constexpr bool kFull = !INIT && !EVAL && (std::is_same<IO, io_f32>::value || std::is_same<IO, io_bf16>::value);
+    LSQ_DISPATCH_VARIANT(kFull, kSegUnroll<IO>, v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH
     return hipGetLastError();
 }
@@ -814,7 +833,7 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
     const bool aligned = is_aligned16(grad) && is_aligned16(x) && is_aligned16(dx);
     const int vec = pick_vec(IO::VEC, channels * inner, aligned);
     const bool seg = pick_segment_mode(vec, outer, channels, inner);
-    const Variant v = decode_variant(variant, seg ? kDefaultPcSegVariant
+    const Variant v = decode_variant(variant, seg ? (sizeof(typename IO::elem) >= 4 ? kDefaultPcSegVariant : kDefaultPcSegNarrowVariant)
                                                   : (sizeof(typename IO::elem) >= 4 ? kDefaultPcBwdWideVariant
                                                                                     : kDefaultPcBwdNarrowVariant));
     const int target = dev.cu_count * v.blocks_per_cu;
