@@ -154,28 +154,26 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
         }
     };
 
+    // rows = full groups of UNROLL (every load issued before the first use) + one group of UNROLL/2 + ... + one
+    // single row: no padded slots (a lane walks only a handful of rows at the BASELINE shapes)
+    auto group = [&](int64_t i0, auto width) {
+        constexpr int H = decltype(width)::value;
+        E in[H][V];
+#pragma unroll
+        for (int u = 0; u < H; ++u) load_elems<IO, V, NTL>(x, walk.row(i0 + u) * g.L + site.p0, in[u]);
+#pragma unroll
+        for (int u = 0; u < H; ++u) emit_row(walk.row(i0 + u), in[u], true);
+    };
     int64_t i = 0;
     if (first_full) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) emit_row(walk.row(u), first[u], true);
         i = UNROLL;
     }
-    for (; i + UNROLL <= walk.n_rows; i += UNROLL) {   // full groups: every load issued before the first use
-        E in[UNROLL][V];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) load_elems<IO, V, NTL>(x, walk.row(i + u) * g.L + site.p0, in[u]);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) emit_row(walk.row(i + u), in[u], true);
-    }
-    if (i < walk.n_rows) {                             // ragged end: clamped (re-read) addresses, masked effects
-        E in[UNROLL][V];
-        const int64_t last = walk.n_rows - 1;
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-            load_elems<IO, V, NTL>(x, walk.row(i + u < last ? i + u : last) * g.L + site.p0, in[u]);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) emit_row(walk.row(i + u < last ? i + u : last), in[u], i + u <= last);
-    }
+    for (; i + UNROLL <= walk.n_rows; i += UNROLL) group(i, std::integral_constant<int, UNROLL>{});
+    if constexpr (UNROLL >= 8) if (i + 4 <= walk.n_rows) { group(i, std::integral_constant<int, 4>{}); i += 4; }
+    if constexpr (UNROLL >= 4) if (i + 2 <= walk.n_rows) { group(i, std::integral_constant<int, 2>{}); i += 2; }
+    if constexpr (UNROLL >= 2) if (i < walk.n_rows) group(i, std::integral_constant<int, 1>{});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -318,20 +316,27 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
             }
         }
     } else {
+        // plain loop: full groups of UNROLL, then one group of UNROLL/2, ..., one single row -- no padded slots
+        auto group = [&](int64_t i0, auto width) {
+            constexpr int H = decltype(width)::value;
+            E gi[H][V], xi[H][V];
+#pragma unroll
+            for (int u = 0; u < H; ++u) {
+                const int64_t e = walk.row(i0 + u) * g.L + site.p0;
+                load_elems<IO, V, NTL>(grad, e, gi[u]);
+                load_elems<IO, V, NTL>(x, e, xi[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < H; ++u) emit_row(walk.row(i0 + u), gi[u], xi[u], true);
+        };
         if (first_full) {
             emit_full(0, first_g, first_x);
             i = UNROLL;
         }
-        for (; i + UNROLL <= walk.n_rows; i += UNROLL) {
-            E gi[UNROLL][V], xi[UNROLL][V];
-            load_group(gi, xi, i);
-            emit_full(i, gi, xi);
-        }
-        if (i < walk.n_rows) {
-            E gi[UNROLL][V], xi[UNROLL][V];
-            load_group(gi, xi, i);
-            emit_ragged(i, gi, xi);
-        }
+        for (; i + UNROLL <= walk.n_rows; i += UNROLL) group(i, std::integral_constant<int, UNROLL>{});
+        if constexpr (UNROLL >= 8) if (i + 4 <= walk.n_rows) { group(i, std::integral_constant<int, 4>{}); i += 4; }
+        if constexpr (UNROLL >= 4) if (i + 2 <= walk.n_rows) { group(i, std::integral_constant<int, 2>{}); i += 2; }
+        if constexpr (UNROLL >= 2) if (i < walk.n_rows) group(i, std::integral_constant<int, 1>{});
     }
     if (EVAL) return;
 
