@@ -15,11 +15,20 @@ __device__ __forceinline__ int64_t udiv(int64_t a, int64_t b, bool fits32) {
     return fits32 ? static_cast<int64_t>(static_cast<uint32_t>(a) / static_cast<uint32_t>(b)) : a / b;
 }
 
+// V elements per lane: one element, a full 16-byte packet (V == IO::VEC), or -- 16-bit storage only -- half a
+// packet (V == 4, one global_load/store_dwordx2).
 template <typename IO, int V, bool NTL>
 __device__ __forceinline__ void load_elems(const void* base, int64_t e, typename IO::elem (&out)[V]) {
+    using E = typename IO::elem;
     if constexpr (V == 1) {
-        out[0] = static_cast<const typename IO::elem*>(base)[e];
+        out[0] = static_cast<const E*>(base)[e];
+    } else if constexpr (V * sizeof(E) == 8) {
+        using V2 = __attribute__((ext_vector_type(2))) unsigned int;
+        const V2* src = reinterpret_cast<const V2*>(static_cast<const E*>(base) + e);
+        const V2 raw = NTL ? __builtin_nontemporal_load(src) : *src;
+        __builtin_memcpy(&out[0], &raw, 8);
     } else {
+        static_assert(V == IO::VEC, "a lane moves 1 element, 8 bytes or 16 bytes");
         const Packet<IO> pk = NTL ? load_packet_nt<IO>(base, e) : load_packet<IO>(base, e);
 #pragma unroll
         for (int j = 0; j < V; ++j) out[j] = pk.v[j];
@@ -28,9 +37,17 @@ __device__ __forceinline__ void load_elems(const void* base, int64_t e, typename
 
 template <typename IO, int V, bool NTS>
 __device__ __forceinline__ void store_elems(void* base, int64_t e, const typename IO::elem (&in)[V]) {
+    using E = typename IO::elem;
     if constexpr (V == 1) {
-        static_cast<typename IO::elem*>(base)[e] = in[0];
+        static_cast<E*>(base)[e] = in[0];
+    } else if constexpr (V * sizeof(E) == 8) {
+        using V2 = __attribute__((ext_vector_type(2))) unsigned int;
+        V2 raw;
+        __builtin_memcpy(&raw, &in[0], 8);
+        V2* dst = reinterpret_cast<V2*>(static_cast<E*>(base) + e);
+        if (NTS) __builtin_nontemporal_store(raw, dst); else *dst = raw;
     } else {
+        static_assert(V == IO::VEC, "a lane moves 1 element, 8 bytes or 16 bytes");
         Packet<IO> pk;
 #pragma unroll
         for (int j = 0; j < V; ++j) pk.v[j] = in[j];

@@ -638,6 +638,12 @@ __global__ __launch_bounds__(kBlock) void finalize_seg_kernel(const double2* __r
 // Packets in flight per lane in the segment kernels (profiles/r01_segment_sweep.txt, typical weight shapes): 4 for
 // 4/8-byte storage; 16-bit storage (twice the arithmetic and registers per packet, half the packets per channel --
 // [4096, 4096] in bf16 is two packets per lane) runs best at 1: [32000, 4096] bf16 backward 125 us vs 143 us at 4.
+// Elements per lane per row in the window-mode backward.  Half packets (4 elements, 8 bytes per lane) for 16-bit
+// storage were measured: 103 instead of 156 VGPRs, but no faster at BASELINE config 5 (best 35.0 us vs 36.3 us, within
+// the run-to-run spread: the dx-only kernel shows the access pattern itself tops out near 5.3 TB/s there), so every
+// storage type moves full packets; load_elems / store_elems keep the 8-byte path.
+template <typename IO>
+constexpr int kWindowBwdVec = IO::VEC;
 template <typename IO>
 constexpr int kSegUnroll = sizeof(typename IO::elem) < 4 ? 1 : 4;
 static inline int pick_cpl(int vec, int64_t inner) {
@@ -647,12 +653,12 @@ static inline int pick_cpl(int vec, int64_t inner) {
 size_t bwd_pc_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64_t inner) {
     const DeviceInfo& dev = device_info();
     size_t need = 0;
-    const int vecs[2] = {io_vec, 1};
-    for (int vi = 0; vi < 2; ++vi) {
+    const int vecs[3] = {io_vec, 1, 4};   // full packets, single elements, half packets (16-bit window backward)
+    for (int vi = 0; vi < 3; ++vi) {
         for (int bpc = 1; bpc <= kMaxBlocksPerCU; ++bpc) {
             const PcGeom g = make_geom(outer, channels, inner, vecs[vi], dev.cu_count * bpc);
             need = std::max(need, static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2));
-            if (pick_segment_mode(vecs[vi], outer, channels, inner)) {
+            if (vi < 2 && pick_segment_mode(vecs[vi], outer, channels, inner)) {
                 const SegGeom sgm = make_seg_geom(outer, channels, inner, vecs[vi], dev.cu_count * bpc);
                 need = std::max(need, static_cast<size_t>(channels) * sgm.segs * sgm.osplits * sizeof(double2));
             }
@@ -863,16 +869,18 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
         return hipGetLastError();
     }
 
-    const int cpl = pick_cpl(vec, inner);
-    const PcGeom g = make_geom(outer, channels, inner, vec, target);
+    constexpr int VB = kWindowBwdVec<IO>;
+    const int vecw = pick_vec(VB, channels * inner, aligned);
+    const int cpl = pick_cpl(vecw, inner);
+    const PcGeom g = make_geom(outer, channels, inner, vecw, target);
     if (!grid_fits(g)) return hipErrorInvalidConfiguration;
     const size_t need = static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2);
     if (!p.eval_mode && workspace_bytes < need) return hipErrorInvalidValue;
     hipError_t e;
-    if (vec == 1) e = bwd_pc_modes<IO, 1, 1>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
-    else if (cpl == 1) e = bwd_pc_modes<IO, IO::VEC, 1>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
-    else if (cpl == 2) e = bwd_pc_modes<IO, IO::VEC, 2>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
-    else e = bwd_pc_modes<IO, IO::VEC, IO::VEC>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
+    if (vecw == 1) e = bwd_pc_modes<IO, 1, 1>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
+    else if (cpl == 1) e = bwd_pc_modes<IO, VB, 1>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
+    else if (cpl == 2) e = bwd_pc_modes<IO, VB, 2>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
+    else e = bwd_pc_modes<IO, VB, VB>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((finalize_pc_kernel<T>), dim3(fgrid_w), dim3(kBlock), 0, stream, partials, g, p.eval_mode ? 1 : 0,
                        p.sym ? 1 : 0, sym_term, static_cast<T*>(ds), static_cast<T*>(db), wide);
