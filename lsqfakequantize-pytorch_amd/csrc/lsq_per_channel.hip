@@ -382,19 +382,43 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
 
 // Finalize (window mode): folds, in a fixed order, every (split, window) partial that can hold a piece
 // of a channel (the reference's `ds_buffer.sum(axes != axis)`, lsq_cpu.cpp:287-292).  A workgroup
-// handles kFinCh channels x kFinParts interleaved slices of the split axis, so each lane issues only
-// splits/kFinParts INDEPENDENT loads (a one-lane-per-channel loop serialised `splits` dependent
-// HBM latencies); the kFinParts slices are then combined through LDS, again in a fixed order.
-constexpr int kFinCh = 32;
-constexpr int kFinParts = kBlock / kFinCh;
+// handles fin_ch channels x (256 / fin_ch) interleaved slices of a channel's partials, so each lane issues only
+// a few INDEPENDENT loads (a one-lane-per-channel loop serialised `splits` dependent HBM latencies); the
+// slices are then combined through LDS by a fixed-order tree.
+constexpr int kFinCh = 32;   // channels per finalize workgroup when there are at least that many
+
+// Channels per finalize workgroup: 32, or fewer when the tensor has fewer channels (RGB inputs, a handful of
+// very long rows): then more of the 256 lanes share one channel's partials, which can be thousands.
+static inline int fin_channels(int64_t C) {
+    int ch = 1;
+    while (ch < kFinCh && ch < C) ch <<= 1;
+    return ch;
+}
+
+// fixed-order tree over the `parts` slices of every channel (parts = kBlock / fin_ch, a power of two); result in slice 0
+__device__ __forceinline__ double2 combine_parts(double2* part_sum, int fin_ch, int lane_c, int part, double s, double b) {
+    part_sum[part * fin_ch + lane_c] = make_double2(s, b);
+    __syncthreads();
+    for (int half = (kBlock / fin_ch) >> 1; half >= 1; half >>= 1) {
+        if (part < half) {
+            const double2 o = part_sum[(part + half) * fin_ch + lane_c];
+            double2& m = part_sum[part * fin_ch + lane_c];
+            m.x += o.x;
+            m.y += o.y;
+        }
+        __syncthreads();
+    }
+    return part_sum[lane_c];
+}
 
 template <typename T>
-__global__ __launch_bounds__(kBlock) void finalize_pc_kernel(const double2* __restrict__ partials, PcGeom g,
+__global__ __launch_bounds__(kBlock) void finalize_pc_kernel(const double2* __restrict__ partials, PcGeom g, int fin_ch,
                                                              int eval_mode, int sym, T sym_term, T* __restrict__ ds,
                                                              T* __restrict__ db, double* __restrict__ wide) {
-    __shared__ double2 part_sum[kFinParts][kFinCh];
-    const int lane_c = threadIdx.x % kFinCh, part = threadIdx.x / kFinCh;
-    const int64_t c = static_cast<int64_t>(blockIdx.x) * kFinCh + lane_c;
+    __shared__ double2 part_sum[kBlock];
+    const int parts = kBlock / fin_ch;
+    const int lane_c = threadIdx.x % fin_ch, part = threadIdx.x / fin_ch;
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * fin_ch + lane_c;
     double s = 0.0, b = 0.0;
     if (!eval_mode && c < g.C) {
         int64_t w_lo = 0, w_hi = 0;
@@ -402,24 +426,24 @@ __global__ __launch_bounds__(kBlock) void finalize_pc_kernel(const double2* __re
             w_lo = (c * g.inner) / g.wpos;
             w_hi = ((c + 1) * g.inner - 1) / g.wpos;
         }
-        for (int64_t w = w_lo; w <= w_hi; ++w) {
-            const int64_t c_lo = (g.R == 1) ? (w * g.wpos) / g.inner : 0;
-            const double2* col = partials + w * g.k_slots + (c - c_lo);
-            const int64_t stride = g.n_windows * g.k_slots;
+        // the (window, split) pairs holding a piece of channel c, flattened and dealt out to the `parts` lanes of c
+        const int64_t total = (w_hi - w_lo + 1) * g.splits;
+        const int64_t stride = g.n_windows * g.k_slots;
+        const bool idx32 = total < 0x7fffffffLL;
 #pragma unroll 4
-            for (int32_t sy = part; sy < g.splits; sy += kFinParts) {
-                const double2 v = col[static_cast<int64_t>(sy) * stride];
-                s += v.x;
-                b += v.y;
-            }
+        for (int64_t idx = part; idx < total; idx += parts) {
+            const int64_t wi = udiv(idx, g.splits, idx32);
+            const int64_t w = w_lo + wi;
+            const int64_t sy = idx - wi * g.splits;
+            const int64_t c_lo = (g.R == 1) ? (w * g.wpos) / g.inner : 0;
+            const double2 v = partials[sy * stride + w * g.k_slots + (c - c_lo)];
+            s += v.x;
+            b += v.y;
         }
     }
-    part_sum[part][lane_c] = make_double2(s, b);
-    __syncthreads();
+    const double2 t = combine_parts(part_sum, fin_ch, lane_c, part, s, b);
     if (part == 0 && c < g.C) {
-        double ts = 0.0, tb = 0.0;
-#pragma unroll
-        for (int k = 0; k < kFinParts; ++k) { ts += part_sum[k][lane_c].x; tb += part_sum[k][lane_c].y; }
+        double ts = t.x, tb = t.y;
         if (!eval_mode && sym) tb = 0.0 + static_cast<double>(sym_term);
         ds[c] = static_cast<T>(ts);
         db[c] = static_cast<T>(tb);
@@ -596,32 +620,30 @@ __global__ __launch_bounds__(kBlock) void bwd_seg_kernel(const void* __restrict_
     }
 }
 
-// Finalize (segment mode): kFinCh channels x kFinParts interleaved slices of the (osplit, seg) partials.
+// Finalize (segment mode): fin_ch channels x (256 / fin_ch) interleaved slices of the (osplit, seg) partials.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void finalize_seg_kernel(const double2* __restrict__ partials, SegGeom g,
+__global__ __launch_bounds__(kBlock) void finalize_seg_kernel(const double2* __restrict__ partials, SegGeom g, int fin_ch,
                                                               int eval_mode, int sym, T sym_term, T* __restrict__ ds,
                                                               T* __restrict__ db, double* __restrict__ wide) {
-    __shared__ double2 part_sum[kFinParts][kFinCh];
-    const int lane_c = threadIdx.x % kFinCh, part = threadIdx.x / kFinCh;
-    const int64_t c = static_cast<int64_t>(blockIdx.x) * kFinCh + lane_c;
+    __shared__ double2 part_sum[kBlock];
+    const int parts = kBlock / fin_ch;
+    const int lane_c = threadIdx.x % fin_ch, part = threadIdx.x / fin_ch;
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * fin_ch + lane_c;
     double s = 0.0, b = 0.0;
     if (!eval_mode && c < g.C) {
         const int64_t gx = g.C * g.segs;
         const int32_t total = g.osplits * g.segs;
 #pragma unroll 4
-        for (int32_t sl = part; sl < total; sl += kFinParts) {
+        for (int32_t sl = part; sl < total; sl += parts) {
             const int32_t oy = sl / g.segs, sg = sl - oy * g.segs;
             const double2 v = partials[static_cast<int64_t>(oy) * gx + c * g.segs + sg];
             s += v.x;
             b += v.y;
         }
     }
-    part_sum[part][lane_c] = make_double2(s, b);
-    __syncthreads();
+    const double2 t = combine_parts(part_sum, fin_ch, lane_c, part, s, b);
     if (part == 0 && c < g.C) {
-        double ts = 0.0, tb = 0.0;
-#pragma unroll
-        for (int k = 0; k < kFinParts; ++k) { ts += part_sum[k][lane_c].x; tb += part_sum[k][lane_c].y; }
+        double ts = t.x, tb = t.y;
         if (!eval_mode && sym) tb = 0.0 + static_cast<double>(sym_term);
         ds[c] = static_cast<T>(ts);
         db[c] = static_cast<T>(tb);
@@ -853,7 +875,8 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
     const T gs = grad_scaler_per_channel<T>(n4s, p.quant_max, channels, p.use_grad_scaling != 0, p.grad_scaler);
     const T sym_term = static_cast<T>(0) * gs;
     double2* partials = static_cast<double2*>(workspace);
-    const unsigned fgrid_w = static_cast<unsigned>((channels + kFinCh - 1) / kFinCh);
+    const int fin_ch = fin_channels(channels);
+    const unsigned fgrid_w = static_cast<unsigned>((channels + fin_ch - 1) / fin_ch);
 
     if (seg) {
         const SegGeom sg = make_seg_geom(outer, channels, inner, vec, target);
@@ -864,7 +887,7 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
         const SegDirect<T> direct{one_partial ? static_cast<T*>(ds) : nullptr, static_cast<T*>(db), wide, sym_term};
         hipError_t e = bwd_seg_modes<IO>(grad, x, dx, sg, scale, shift, p, gs, partials, direct, v, stream);
         if (e != hipSuccess || one_partial) return e;
-        hipLaunchKernelGGL((finalize_seg_kernel<T>), dim3(fgrid_w), dim3(kBlock), 0, stream, partials, sg,
+        hipLaunchKernelGGL((finalize_seg_kernel<T>), dim3(fgrid_w), dim3(kBlock), 0, stream, partials, sg, fin_ch,
                            p.eval_mode ? 1 : 0, p.sym ? 1 : 0, sym_term, static_cast<T*>(ds), static_cast<T*>(db), wide);
         return hipGetLastError();
     }
@@ -882,7 +905,7 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
     else if (cpl == 2) e = bwd_pc_modes<IO, VB, 2>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
     else e = bwd_pc_modes<IO, VB, VB>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((finalize_pc_kernel<T>), dim3(fgrid_w), dim3(kBlock), 0, stream, partials, g, p.eval_mode ? 1 : 0,
+    hipLaunchKernelGGL((finalize_pc_kernel<T>), dim3(fgrid_w), dim3(kBlock), 0, stream, partials, g, fin_ch, p.eval_mode ? 1 : 0,
                        p.sym ? 1 : 0, sym_term, static_cast<T*>(ds), static_cast<T*>(db), wide);
     return hipGetLastError();
 }
