@@ -666,6 +666,7 @@ __global__ __launch_bounds__(kBlock) void finalize_seg_kernel(const double2* __r
 // storage type moves full packets; load_elems / store_elems keep the 8-byte path.
 template <typename IO>
 constexpr int kWindowBwdVec = IO::VEC;
+constexpr int kLastAxisBwdBlocksPerCU = 2;
 template <typename IO>
 constexpr int kSegUnroll = sizeof(typename IO::elem) < 4 ? 1 : 4;
 static inline int pick_cpl(int vec, int64_t inner) {
@@ -701,7 +702,7 @@ static hipError_t launch_fwd_pc(const void* x, void* y, int8_t* levels, int bias
 #define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                       \
     hipLaunchKernelGGL((fwd_pc_kernel<IO, V, CPL, INIT, LEVELS, U, NTLF, NTSF>), grid, dim3(kBlock), lds, stream, x, y, levels, \
                        bias, aux_kind, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r)
-    [[maybe_unused]] constexpr bool kFull = !INIT && !LEVELS && V > 1 && CPL <= 2 && !std::is_same<IO, io_f64>::value &&
+    [[maybe_unused]] constexpr bool kFull = !INIT && !LEVELS && V > 1 && !std::is_same<IO, io_f64>::value &&
                                             !std::is_same<IO, io_f16>::value;
     LSQ_DISPATCH_VARIANT(kFull, 4, v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH
@@ -776,13 +777,15 @@ static hipError_t launch_bwd_pc(const void* grad, const void* x, void* dx, const
     const Range<T> r = make_range<T>(p);
     const dim3 grid(static_cast<unsigned>(g.n_windows), static_cast<unsigned>(g.splits));
     const size_t lds = static_cast<size_t>(g.k_slots) * (sizeof(QSlot<T>) + 2 * sizeof(double));
-    [[maybe_unused]] constexpr bool kFull = !SYM && !INIT && !EVAL && V > 1 && CPL <= 2 && !std::is_same<IO, io_f64>::value &&
+    [[maybe_unused]] constexpr bool kFull = !SYM && !INIT && !EVAL && V > 1 && !std::is_same<IO, io_f64>::value &&
                                             !std::is_same<IO, io_f16>::value;
     // 16-bit storage: unroll 1 + the software-pipelined loop (profiles/r01_pc_pipeline_sweep.txt: 36.3 us against
     // 38.5 us for the best plain variant at BASELINE config 5); 4/8-byte storage gains nothing from it (55.6 vs 55.9 us)
     // and keeps the plain loop at unroll 4.
+    // CPL == V (inner < V: the quantized axis is the last or nearly the last one -- [tokens, features], NHWC): 16-bit
+    // storage runs the pipelined loop at unroll 2 there (profiles/r01_lastaxis_sweep.txt).
     constexpr bool kNarrow = sizeof(typename IO::elem) < 4;
-    constexpr int kDefU = kNarrow ? 1 : 4;
+    constexpr int kDefU = kNarrow ? ((CPL == V && V > 1) ? 2 : 1) : 4;
 #define LSQ_LAUNCH_P(U, NTLF, NTSF, PIPEF)                                                                                 \
     hipLaunchKernelGGL((bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, U, NTLF, NTSF, PIPEF>), grid, dim3(kBlock), lds, stream, grad, \
                        x, dx, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r, gs, partials)
@@ -895,7 +898,12 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
     constexpr int VB = kWindowBwdVec<IO>;
     const int vecw = pick_vec(VB, channels * inner, aligned);
     const int cpl = pick_cpl(vecw, inner);
-    const PcGeom g = make_geom(outer, channels, inner, vecw, target);
+    // One channel per packet component (inner < V): a window spans 256 x V channels, so every workgroup ends with a
+    // long epilogue and a 16-byte partial per slot, and the finalize has `splits` of them to fold per channel.  Fewer,
+    // fatter workgroups win there in every shape swept (profiles/r01_lastaxis_sweep.txt: 2 per CU; [8192, 4096] fp32
+    // 82 us against 100 us at 16 per CU, [200704, 256] 133 against 205).
+    const int target_w = (variant == 0 && vecw > 1 && cpl == vecw) ? dev.cu_count * kLastAxisBwdBlocksPerCU : target;
+    const PcGeom g = make_geom(outer, channels, inner, vecw, target_w);
     if (!grid_fits(g)) return hipErrorInvalidConfiguration;
     const size_t need = static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2);
     if (!p.eval_mode && workspace_bytes < need) return hipErrorInvalidValue;
