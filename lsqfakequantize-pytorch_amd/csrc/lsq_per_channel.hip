@@ -387,11 +387,13 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
 // slices are then combined through LDS by a fixed-order tree.
 constexpr int kFinCh = 32;   // channels per finalize workgroup when there are at least that many
 
-// Channels per finalize workgroup: 32, or fewer when the tensor has fewer channels (RGB inputs, a handful of
-// very long rows): then more of the 256 lanes share one channel's partials, which can be thousands.
+// Channels per finalize workgroup: a power of two, at most 32, chosen so that the finalize grid still has ~256
+// workgroups when the channel count allows it: with few channels (RGB inputs; 768 features x 512 row slabs) the
+// lanes of a workgroup share a channel's partials -- there can be thousands -- instead of 24 workgroups walking
+// them one lane per channel.
 static inline int fin_channels(int64_t C) {
     int ch = 1;
-    while (ch < kFinCh && ch < C) ch <<= 1;
+    while (ch < kFinCh && static_cast<int64_t>(ch) * 2 * 256 <= C) ch <<= 1;
     return ch;
 }
 
