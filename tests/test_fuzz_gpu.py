@@ -5,6 +5,8 @@ quantization range, parameter values (negative, zero and tiny scales included), 
 layer, and checks the bars of the parity tests: y, dx bit-exact; d_scale / d_shift within 1e-6 of sum|terms|.
 The draws are deterministic (numpy Generator with fixed seeds), so a failure names its case.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -46,7 +48,10 @@ def _layout(rng, t, kind):
     return t
 
 
-@pytest.mark.parametrize("seed", range(12))
+N_SEEDS = int(os.environ.get("LSQ_FUZZ_SEEDS", "12"))      # a longer soak: LSQ_FUZZ_SEEDS=200 python -m pytest tests/test_fuzz_gpu.py -m gpu
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_cases_against_the_oracle(seed):
     assert torch.cuda.is_available()
     import torchlsq  # noqa: F401
@@ -131,7 +136,7 @@ def test_random_cases_against_the_oracle(seed):
     assert ran == 30
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(max(6, N_SEEDS // 2)))
 def test_random_cases_of_the_side_outputs(seed):
     """Same draws for the ops beside the reference's four: integer levels (int8, bit-exact against the oracle's
     rne(clamp(x/s + zp))), the eval-mode mask + backward_from_mask, one-pass min/max (exact) and mean/std (1e-6)."""
