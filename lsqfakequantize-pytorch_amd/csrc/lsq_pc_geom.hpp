@@ -83,8 +83,11 @@ static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec,
         g.n_windows = 1;
         g.k_slots = static_cast<int32_t>(C);
     }
-    // keep the partial-sum traffic (16 B per slot per workgroup) below ~5 % of the streamed bytes
-    const int64_t min_rows = std::max<int64_t>(g.R, (27 * static_cast<int64_t>(g.k_slots) + W - 1) / W * g.R);
+    // keep the partial-sum traffic (16 B per slot per workgroup) below ~5 % of the streamed bytes -- except for small
+    // tensors (< 2 M elements), which are latency- not traffic-bound: there a workgroup takes as few rows as the grid
+    // target allows ([128, 768]: 128 workgroups of one row instead of 7 walking 21 rows one group after the other)
+    const bool small = outer * g.L < (int64_t{1} << 21);
+    const int64_t min_rows = small ? g.R : std::max<int64_t>(g.R, (27 * static_cast<int64_t>(g.k_slots) + W - 1) / W * g.R);
     int64_t want_splits = std::max<int64_t>(1, (target_blocks + g.n_windows - 1) / g.n_windows);
     int64_t rows = (outer + want_splits - 1) / want_splits;
     rows = std::max<int64_t>(rows, min_rows);

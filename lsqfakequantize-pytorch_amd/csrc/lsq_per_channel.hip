@@ -397,27 +397,33 @@ static inline int fin_channels(int64_t C) {
     return ch;
 }
 
-// fixed-order tree over the `parts` slices of every channel (parts = kBlock / fin_ch, a power of two); result in slice 0
-__device__ __forceinline__ double2 combine_parts(double2* part_sum, int fin_ch, int lane_c, int part, double s, double b) {
-    part_sum[part * fin_ch + lane_c] = make_double2(s, b);
-    __syncthreads();
-    for (int half = (kBlock / fin_ch) >> 1; half >= 1; half >>= 1) {
-        if (part < half) {
-            const double2 o = part_sum[(part + half) * fin_ch + lane_c];
-            double2& m = part_sum[part * fin_ch + lane_c];
-            m.x += o.x;
-            m.y += o.y;
-        }
-        __syncthreads();
+// Fixed-order combination of the kBlock / fin_ch slices of every channel (fin_ch a power of two <= 32, thread t holds
+// channel t % fin_ch): a wave64 butterfly over the lane bits above the channel bits, then the four wave results
+// through LDS -- one barrier.  Threads 0 .. fin_ch-1 return their channel's total.
+__device__ __forceinline__ double2 combine_parts(double2* wave_part, int fin_ch, double s, double b) {
+    for (int m = 32; m >= fin_ch; m >>= 1) {
+        s += shfl_xor_f64(s, m);
+        b += shfl_xor_f64(b, m);
     }
-    return part_sum[lane_c];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < fin_ch) wave_part[wave * kFinCh + lane] = make_double2(s, b);
+    __syncthreads();
+    double2 t = make_double2(0.0, 0.0);
+    if (threadIdx.x < fin_ch) {
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) {
+            t.x += wave_part[w * kFinCh + threadIdx.x].x;
+            t.y += wave_part[w * kFinCh + threadIdx.x].y;
+        }
+    }
+    return t;
 }
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void finalize_pc_kernel(const double2* __restrict__ partials, PcGeom g, int fin_ch,
                                                              int eval_mode, int sym, T sym_term, T* __restrict__ ds,
                                                              T* __restrict__ db, double* __restrict__ wide) {
-    __shared__ double2 part_sum[kBlock];
+    __shared__ double2 wave_part[(kBlock / 64) * kFinCh];
     const int parts = kBlock / fin_ch;
     const int lane_c = threadIdx.x % fin_ch, part = threadIdx.x / fin_ch;
     const int64_t c = static_cast<int64_t>(blockIdx.x) * fin_ch + lane_c;
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(kBlock) void finalize_pc_kernel(const double2* __re
             b += v.y;
         }
     }
-    const double2 t = combine_parts(part_sum, fin_ch, lane_c, part, s, b);
+    const double2 t = combine_parts(wave_part, fin_ch, s, b);
     if (part == 0 && c < g.C) {
         double ts = t.x, tb = t.y;
         if (!eval_mode && sym) tb = 0.0 + static_cast<double>(sym_term);
@@ -627,7 +633,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void finalize_seg_kernel(const double2* __restrict__ partials, SegGeom g, int fin_ch,
                                                               int eval_mode, int sym, T sym_term, T* __restrict__ ds,
                                                               T* __restrict__ db, double* __restrict__ wide) {
-    __shared__ double2 part_sum[kBlock];
+    __shared__ double2 wave_part[(kBlock / 64) * kFinCh];
     const int parts = kBlock / fin_ch;
     const int lane_c = threadIdx.x % fin_ch, part = threadIdx.x / fin_ch;
     const int64_t c = static_cast<int64_t>(blockIdx.x) * fin_ch + lane_c;
@@ -643,7 +649,7 @@ __global__ __launch_bounds__(kBlock) void finalize_seg_kernel(const double2* __r
             b += v.y;
         }
     }
-    const double2 t = combine_parts(part_sum, fin_ch, lane_c, part, s, b);
+    const double2 t = combine_parts(wave_part, fin_ch, s, b);
     if (part == 0 && c < g.C) {
         double ts = t.x, tb = t.y;
         if (!eval_mode && sym) tb = 0.0 + static_cast<double>(sym_term);
