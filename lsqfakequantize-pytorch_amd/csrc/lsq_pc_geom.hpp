@@ -67,7 +67,10 @@ struct PcGeom {
     int32_t fits32;          // L < 2^31: index divisions in 32 bits
 };
 
-static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec, int target_blocks) {
+// per_slot_rows: rows a workgroup should walk per (slot / lane-position) of per-workgroup overhead.  27 for the
+// kernels that write a 16-byte partial per slot (backward, statistics); the forward only rebuilds its channel
+// table per workgroup and passes 4.
+static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec, int target_blocks, int per_slot_rows = 27) {
     PcGeom g;
     g.outer = outer; g.C = C; g.inner = inner; g.L = C * inner; g.vec = vec;
     g.fits32 = (g.L + static_cast<int64_t>(kBlock) * vec) < 0x7fffffffLL ? 1 : 0;
@@ -87,7 +90,7 @@ static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec,
     // tensors (< 2 M elements), which are latency- not traffic-bound: there a workgroup takes as few rows as the grid
     // target allows ([128, 768]: 128 workgroups of one row instead of 7 walking 21 rows one group after the other)
     const bool small = outer * g.L < (int64_t{1} << 21);
-    const int64_t min_rows = small ? g.R : std::max<int64_t>(g.R, (27 * static_cast<int64_t>(g.k_slots) + W - 1) / W * g.R);
+    const int64_t min_rows = small ? g.R : std::max<int64_t>(g.R, (per_slot_rows * static_cast<int64_t>(g.k_slots) + W - 1) / W * g.R);
     int64_t want_splits = std::max<int64_t>(1, (target_blocks + g.n_windows - 1) / g.n_windows);
     int64_t rows = (outer + want_splits - 1) / want_splits;
     rows = std::max<int64_t>(rows, min_rows);

@@ -675,6 +675,13 @@ __global__ __launch_bounds__(kBlock) void finalize_seg_kernel(const double2* __r
 template <typename IO>
 constexpr int kWindowBwdVec = IO::VEC;
 constexpr int kLastAxisBwdBlocksPerCU = 2;
+// Rows a forward workgroup walks at least, per unit of its per-workgroup overhead (make_geom): that overhead is only
+// the channel-table build -- VEC channels per lane when the quantized axis is the last one, so twice as heavy per
+// streamed byte for 16-bit storage.  ([64,197,768] fp32 forward 17.8 -> 13.7 us, bf16 13.8 -> 11.4 us against the
+// backward's bound of 27.)  A variant without the table (every lane computing its own channels' constants, no LDS,
+// no barrier) was measured too and is slower: its scale/shift loads are strided by VEC across the lanes.
+template <typename IO>
+constexpr int kFwdPerSlotRows = sizeof(typename IO::elem) < 4 ? 12 : 4;
 template <typename IO>
 constexpr int kSegUnroll = sizeof(typename IO::elem) < 4 ? 1 : 4;
 static inline int pick_cpl(int vec, int64_t inner) {
@@ -768,7 +775,7 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
                       : launch_fwd_seg<IO, false, false>(x, y, levels, bias, aux_kind, sg, scale, shift, p, v, stream);
     }
     const int cpl = pick_cpl(vec, inner);
-    const PcGeom g = make_geom(outer, channels, inner, vec, target);
+    const PcGeom g = make_geom(outer, channels, inner, vec, target, kFwdPerSlotRows<IO>);
     if (!grid_fits(g)) return hipErrorInvalidConfiguration;
     if (vec == 1) return fwd_pc_modes<IO, 1, 1>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream);
     if (cpl == 1) return fwd_pc_modes<IO, IO::VEC, 1>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream);
