@@ -24,9 +24,10 @@
 //    per workgroup, its constants computed in registers, reduction = wave64 butterfly + 4 partials
 //    through LDS -> one partial per workgroup -> fixed-order finalize.
 //
-// Loads are never predicated (a predicated version serialised them behind s_waitcnt): the ragged end
-// of a walk re-reads the last valid packet (clamped address, served by L2) and masks its effects.
-// No global atomics, no zero-initialised buffers.
+// Loads are never predicated (a predicated version serialised them behind s_waitcnt) and no slot of a load group
+// is padding: a walk of n rows is cut into groups of UNROLL, then UNROLL/2, ..., 1 rows.  Only the software-pipelined
+// loop of the 16-bit backward, whose prefetch can run past the end, re-reads the last row (clamped address, served
+// by L2) and masks its effects.  No global atomics, no zero-initialised buffers.
 #include "lsq_kernels.hpp"
 #include "lsq_pc_geom.hpp"
 
