@@ -897,3 +897,40 @@ def test_concurrent_threads_and_streams(dev):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+LARGE_PC = [((32, 256, 56, 56), 1), ((8192, 1024), 1), ((64, 197, 768), 2), ((64, 56, 56, 64), 3), ((4, 8, 262144), 1),
+            ((1, 3, 1000, 1250), 1), ((2048, 2304), 0), ((40000, 96), 1)]
+
+
+@pytest.mark.parametrize("shape,axis", LARGE_PC)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_large_per_channel_shapes(dev, shape, axis, dtype):
+    """Per-channel shapes above the small-tensor geometry (>= 2 M elements), one per decomposition: window mode with one /
+    two / VEC channels per lane, rows folded into a tile, long rows split into many windows, segment mode with few
+    and with many channels -- the launch geometries the small fixed cases and the fuzz test (<= 0.6 M elements) do
+    not reach.  Same bars: y, dx bit-exact, d_scale / d_shift within 1e-6 of sum|terms| (16-bit storage: the fp32
+    result rounded to the storage type)."""
+    from torchlsq import synth
+    n = int(np.prod(shape))
+    C = shape[axis]
+    x32 = synth.normal_like(n, 401, 0.4, 1.0, dtype=dtype).view(shape).to(torch.float32)     # values representable in `dtype`
+    g32 = synth.normal_like(n, 402, 0.0, 1e-3, dtype=dtype).view(shape).to(torch.float32)
+    scale = synth.uniform_like(C, 403, 0.02, 0.08)
+    shift = synth.normal_like(C, 404, 0.0, 0.1)
+    p = (0, 127, 0, 255)
+    ops = torch.ops.torchlsq
+    xd, gd = x32.to(dev).to(dtype), g32.to(dev).to(dtype)
+    y = ops.lsq_forward_per_channel(xd, scale.to(dev), shift.to(dev), axis, *p, True, 1.0, False, False, False)
+    dx, ds, db = ops.lsq_backward_per_channel(gd, xd, scale.to(dev), shift.to(dev), axis, *p, True, 1.0, False, False, False)
+    outer, C_, inner = O.axis_to_ocl(shape, axis)
+    oy = O.fwd_pc(x32.numpy(), scale.numpy(), shift.numpy(), outer, C_, inner, *p)
+    r = O.bwd_pc(g32.numpy(), x32.numpy(), scale.numpy(), shift.numpy(), outer, C_, inner, *p, True, 1.0, False)
+    if dtype == torch.float32:
+        assert_bits_equal(y.cpu().numpy(), oy, "y")
+        assert_bits_equal(dx.cpu().numpy(), r.dx, "dx")
+    else:
+        assert torch.equal(y.cpu().view(torch.int16), torch.from_numpy(oy).to(dtype).view(torch.int16)), "y"
+        assert torch.equal(dx.cpu().view(torch.int16), torch.from_numpy(r.dx).to(dtype).view(torch.int16)), "dx"
+    assert_reduction_close(ds.cpu().numpy(), r.ds_wide, r.abs_ds, "ds")
+    assert_reduction_close(db.cpu().numpy(), r.db_wide, r.abs_db, "db")
