@@ -504,7 +504,9 @@ def test_more_than_2_pow_31_elements(dev):
 
 MM_SHAPES = [((7,), None), ((4099,), None), ((3, 1 << 20), None), ((4, 8, 6, 6), 1), ((8, 4, 3, 3), 0), ((5, 16), 1),
              ((3, 5, 7), 1), ((2, 2048, 7, 7), 1), ((33, 1000), 1), ((1000, 33), 0), ((300, 16), 1), ((129, 4096), 1),
-             ((4, 3, 224, 224), 1), ((64, 64, 3, 3), 0), ((1, 7), 1), ((257, 3), 1), ((9, 2050, 3), 1), ((512, 4608), 0)]
+             ((4, 3, 224, 224), 1), ((64, 64, 3, 3), 0), ((1, 7), 1), ((257, 3), 1), ((9, 2050, 3), 1), ((512, 4608), 0),
+             # above the small-tensor geometry (>= 2 M elements): window mode with 1 / VEC channels per lane, folded rows
+             ((16, 256, 56, 56), 1), ((8192, 1024), 1), ((40000, 96), 1), ((16, 197, 768), 2)]
 
 
 @pytest.mark.parametrize("shape,axis", MM_SHAPES)
