@@ -192,28 +192,25 @@ __global__ __launch_bounds__(kBlock) void minmax_pc_kernel(const void* __restric
             if (valid) r[j].push(v);
         }
     };
+    // rows = full groups of UNROLL + one group of UNROLL/2 + ... + one single row (no padded slots, see lsq_per_channel.hip)
+    auto group = [&](int64_t i0, auto width) {
+        constexpr int H = decltype(width)::value;
+        E in[H][V];
+#pragma unroll
+        for (int u = 0; u < H; ++u) load_elems<IO, V, true>(x, walk.row(i0 + u) * g.L + site.p0, in[u]);
+#pragma unroll
+        for (int u = 0; u < H; ++u) absorb(in[u], true);
+    };
     int64_t i = 0;
     if (first_full) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) absorb(first[u], true);
         i = UNROLL;
     }
-    for (; i + UNROLL <= walk.n_rows; i += UNROLL) {
-        E in[UNROLL][V];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) load_elems<IO, V, true>(x, walk.row(i + u) * g.L + site.p0, in[u]);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) absorb(in[u], true);
-    }
-    if (i < walk.n_rows) {
-        E in[UNROLL][V];
-        const int64_t last = walk.n_rows - 1;
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-            load_elems<IO, V, true>(x, walk.row(i + u < last ? i + u : last) * g.L + site.p0, in[u]);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) absorb(in[u], i + u <= last);
-    }
+    for (; i + UNROLL <= walk.n_rows; i += UNROLL) group(i, std::integral_constant<int, UNROLL>{});
+    if constexpr (UNROLL >= 8) if (i + 4 <= walk.n_rows) { group(i, std::integral_constant<int, 4>{}); i += 4; }
+    if constexpr (UNROLL >= 4) if (i + 2 <= walk.n_rows) { group(i, std::integral_constant<int, 2>{}); i += 2; }
+    if constexpr (UNROLL >= 2) if (i < walk.n_rows) group(i, std::integral_constant<int, 1>{});
     if (site.live && walk.n_rows > 0) {
 #pragma unroll
         for (int j = 0; j < V; ++j) {
@@ -297,22 +294,23 @@ __global__ __launch_bounds__(kBlock) void minmax_seg_kernel(const void* __restri
         valid = pos < g.inner;
         return ((w.o_begin + oi) * g.C + w.c) * g.inner + (valid ? pos : q_last);
     };
-    for (int64_t it = 0; it < w.n_it; it += UNROLL) {
-        E in[UNROLL][V];
-        bool ok[UNROLL];
+    auto group = [&](int64_t it, auto width) {     // groups of UNROLL, then UNROLL/2, ..., 1: no padded slots
+        constexpr int H = decltype(width)::value;
+        E in[H][V];
+        bool ok[H];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int64_t k = it + u < w.n_it ? it + u : w.n_it - 1;
-            const int64_t e = site(k, ok[u]);
-            ok[u] = ok[u] && (it + u < w.n_it);
-            load_elems<IO, V, true>(x, e, in[u]);
-        }
+        for (int u = 0; u < H; ++u) load_elems<IO, V, true>(x, site(it + u, ok[u]), in[u]);
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
+        for (int u = 0; u < H; ++u)
 #pragma unroll
             for (int j = 0; j < V; ++j)
                 if (ok[u]) r.push(static_cast<T>(in[u][j]));
-    }
+    };
+    int64_t it = 0;
+    for (; it + UNROLL <= w.n_it; it += UNROLL) group(it, std::integral_constant<int, UNROLL>{});
+    if constexpr (UNROLL >= 8) if (it + 4 <= w.n_it) { group(it, std::integral_constant<int, 4>{}); it += 4; }
+    if constexpr (UNROLL >= 4) if (it + 2 <= w.n_it) { group(it, std::integral_constant<int, 2>{}); it += 2; }
+    if constexpr (UNROLL >= 2) if (it < w.n_it) group(it, std::integral_constant<int, 1>{});
     const MinMaxPartial<T> res = block_minmax<T>(r);
     if (threadIdx.x == 0) partials[static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = res;
 }
@@ -495,28 +493,25 @@ __global__ __launch_bounds__(kBlock) void moments_pc_kernel(const void* __restri
         for (int j = 0; j < V; ++j)
             if (valid) r[j].push(static_cast<double>(static_cast<T>(in[j])), pivot[j]);
     };
+    // rows = full groups of UNROLL + one group of UNROLL/2 + ... + one single row (no padded slots, see lsq_per_channel.hip)
+    auto group = [&](int64_t i0, auto width) {
+        constexpr int H = decltype(width)::value;
+        E in[H][V];
+#pragma unroll
+        for (int u = 0; u < H; ++u) load_elems<IO, V, true>(x, walk.row(i0 + u) * g.L + site.p0, in[u]);
+#pragma unroll
+        for (int u = 0; u < H; ++u) absorb(in[u], true);
+    };
     int64_t i = 0;
     if (first_full) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) absorb(first[u], true);
         i = UNROLL;
     }
-    for (; i + UNROLL <= walk.n_rows; i += UNROLL) {
-        E in[UNROLL][V];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) load_elems<IO, V, true>(x, walk.row(i + u) * g.L + site.p0, in[u]);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) absorb(in[u], true);
-    }
-    if (i < walk.n_rows) {
-        E in[UNROLL][V];
-        const int64_t last = walk.n_rows - 1;
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-            load_elems<IO, V, true>(x, walk.row(i + u < last ? i + u : last) * g.L + site.p0, in[u]);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) absorb(in[u], i + u <= last);
-    }
+    for (; i + UNROLL <= walk.n_rows; i += UNROLL) group(i, std::integral_constant<int, UNROLL>{});
+    if constexpr (UNROLL >= 8) if (i + 4 <= walk.n_rows) { group(i, std::integral_constant<int, 4>{}); i += 4; }
+    if constexpr (UNROLL >= 4) if (i + 2 <= walk.n_rows) { group(i, std::integral_constant<int, 2>{}); i += 2; }
+    if constexpr (UNROLL >= 2) if (i < walk.n_rows) group(i, std::integral_constant<int, 1>{});
     if (site.live && walk.n_rows > 0) {
 #pragma unroll
         for (int j = 0; j < V; ++j) {
@@ -587,22 +582,23 @@ __global__ __launch_bounds__(kBlock) void moments_seg_kernel(const void* __restr
         valid = pos < g.inner;
         return ((w.o_begin + oi) * g.C + w.c) * g.inner + (valid ? pos : q_last);
     };
-    for (int64_t it = 0; it < w.n_it; it += UNROLL) {
-        E in[UNROLL][V];
-        bool ok[UNROLL];
+    auto group = [&](int64_t it, auto width) {     // groups of UNROLL, then UNROLL/2, ..., 1: no padded slots
+        constexpr int H = decltype(width)::value;
+        E in[H][V];
+        bool ok[H];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int64_t k = it + u < w.n_it ? it + u : w.n_it - 1;
-            const int64_t e = site(k, ok[u]);
-            ok[u] = ok[u] && (it + u < w.n_it);
-            load_elems<IO, V, true>(x, e, in[u]);
-        }
+        for (int u = 0; u < H; ++u) load_elems<IO, V, true>(x, site(it + u, ok[u]), in[u]);
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
+        for (int u = 0; u < H; ++u)
 #pragma unroll
             for (int j = 0; j < V; ++j)
                 if (ok[u]) r.push(static_cast<double>(static_cast<T>(in[u][j])), pivot);
-    }
+    };
+    int64_t it = 0;
+    for (; it + UNROLL <= w.n_it; it += UNROLL) group(it, std::integral_constant<int, UNROLL>{});
+    if constexpr (UNROLL >= 8) if (it + 4 <= w.n_it) { group(it, std::integral_constant<int, 4>{}); it += 4; }
+    if constexpr (UNROLL >= 4) if (it + 2 <= w.n_it) { group(it, std::integral_constant<int, 2>{}); it += 2; }
+    if constexpr (UNROLL >= 2) if (it < w.n_it) group(it, std::integral_constant<int, 1>{});
     const double2 res = block_sum2(r.s1, r.s2);
     if (threadIdx.x == 0) partials[static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = res;
 }
