@@ -1,0 +1,101 @@
+"""GPU, world_size 2 over gloo on ONE device: torchlsq.distributed on the HIP kernels.
+
+Two processes share cuda:0 (the 1-GPU test box; the RCCL transport itself cannot be exercised there -- RCCL refuses two
+ranks on one device -- so the collective runs over gloo, which stages the 16-byte fp64 pair through the host).  What this
+pins on the device: the `*_wide` ops (un-rounded fp64 sums, global element count in the gradient scaler), the single
+all-reduce, and that the sharded result equals the unsharded op on the concatenated tensor: y, dx bit-exact per shard;
+d_scale / d_shift to 1e-6.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, per_channel, dtype_name, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
+    import torchlsq  # noqa: F401
+    from torchlsq import extension, synth
+    from torchlsq.distributed import lsq_sharded
+    from torchlsq.functional import lsq
+    extension._assert_has_ops()
+    dev = torch.device("cuda:0")
+    dtype = getattr(torch, dtype_name)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = {"n": 0}
+        real_all_reduce = dist.all_reduce
+
+        def counting_all_reduce(*a, **k):
+            calls["n"] += 1
+            return real_all_reduce(*a, **k)
+        dist.all_reduce = counting_all_reduce
+
+        shape = (64, 48, 14, 14)
+        n = int(np.prod(shape))
+        x = synth.normal_like(n, 71, 0.3, 1.0, dtype=dtype, device=dev).view(shape)
+        g = synth.normal_like(n, 72, 0.0, 1e-2, dtype=dtype, device=dev).view(shape).abs()     # no cancellation: plain rtol
+        if per_channel:
+            scale = synth.uniform_like(48, 73, 0.05, 0.3, device=dev)
+            shift = synth.normal_like(48, 74, 0.0, 0.1, device=dev)
+            kw = dict(quant_min=-8, quant_max=7, type_min=-128, type_max=127, axis=1, is_perchannel=True)
+        else:
+            scale, shift = torch.tensor([0.03], device=dev), torch.tensor([0.05], device=dev)
+            kw = dict(quant_min=0, quant_max=127, type_min=0, type_max=255)
+        xf = x.clone().requires_grad_(True)
+        sf = scale.clone().requires_grad_(True)
+        bf = shift.clone().requires_grad_(True)
+        lsq(xf, sf, bf, **kw).backward(g)                       # the unsharded op on the whole batch
+        yf = lsq(xf.detach(), scale, shift, **kw)
+        h = shape[0] // world
+        sl = slice(rank * h, (rank + 1) * h)
+        xs = x[sl].clone().requires_grad_(True)
+        ss = scale.clone().requires_grad_(True)
+        bs = shift.clone().requires_grad_(True)
+        ys = lsq_sharded(xs, ss, bs, **kw)
+        ys.backward(g[sl])
+        torch.cuda.synchronize()
+        err_s = float(((ss.grad - sf.grad).abs() / sf.grad.abs().clamp_min(1e-30)).max())
+        err_b = float(((bs.grad - bf.grad).abs() / bf.grad.abs().clamp_min(1e-30)).max())
+        ok = (torch.equal(ys, yf[sl]) and torch.equal(xs.grad, xf.grad[sl]) and err_s <= 2e-6 and err_b <= 2e-6
+              and calls["n"] == 1)
+        out_q.put((rank, bool(ok), calls["n"], err_s, err_b))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("per_channel", [False, True])
+@pytest.mark.parametrize("dtype_name", ["float32", "bfloat16"])
+def test_sharded_equals_unsharded_on_the_gpu(per_channel, dtype_name):
+    assert torch.cuda.is_available()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, per_channel, dtype_name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok, ncalls, err_s, err_b in res:
+        assert ok, "rank %d: sharded != unsharded (all_reduce calls %d, rel err ds %g db %g)" % (rank, ncalls, err_s, err_b)
