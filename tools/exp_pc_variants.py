@@ -30,10 +30,15 @@ def timeit(fn, reps=20):
             ts.append(e0.elapsed_time(e1) / reps * 1e3)
     return sorted(ts)[len(ts) // 2]
 
+# usage: exp_pc_variants.py [outer C inner]   (default: BASELINE config 5 = 256 2048 49)
+GEOM = tuple(int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (256, 2048, 49)
 for dt, code in ((torch.float32, 0), (torch.bfloat16, 2)):
-    c = synth.CONFIGS["cfg5"]
-    x, g, scale, shift = synth.make_inputs(c, device=dev, dtype=dt)
-    outer, C, inner = 256, 2048, 49
+    outer, C, inner = GEOM
+    n_ = outer * C * inner
+    x = synth.normal_like(n_, 1, 0.0, 1.0, device=dev, dtype=dt)
+    g = synth.normal_like(n_, 2, 0.0, 1e-3, device=dev, dtype=dt)
+    scale = synth.uniform_like(C, 3, 0.05, 0.35, device=dev)
+    shift = synth.normal_like(C, 4, 0.0, 0.1, device=dev)
     y = torch.empty_like(x); dx = torch.empty_like(x)
     ds = torch.empty(C, device=dev); db = torch.empty(C, device=dev)
     ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
