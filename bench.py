@@ -213,6 +213,27 @@ def main():
                                  "bytes_per_launch": BYTES_FWD * n_local},
                          "step_achieved": round(step_gbs, 1), "step_frac": round(step_gbs / HBM_PEAK_GBS, 4)},
         }
+        if world == 1:
+            # Context for the roofline fraction, measured live on THIS box after the timed region: the framework's /
+            # vendor's own kernels on the same two traffic shapes (ATen's vectorised add = 2 reads : 1 write like the
+            # backward; its copy = 1 read : 1 write like the forward).  Not part of `value`.
+            try:
+                def _gbs(fn, bytes_per_elem, reps=5):
+                    fn()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(reps):
+                        fn()
+                    e1.record()
+                    e1.synchronize()
+                    return round(bytes_per_elem * n_local / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9, 1)
+                scratch = torch.empty_like(x)
+                line["roofline"]["same_box_reference_kernels"] = {
+                    "aten_add_2r1w_GBps": _gbs(lambda: torch.add(g, x, out=scratch), BYTES_BWD),
+                    "aten_copy_1r1w_GBps": _gbs(lambda: scratch.copy_(x), BYTES_FWD)}
+                del scratch
+            except Exception as e:      # context only: never let it break the bench line
+                line["roofline"]["same_box_reference_kernels"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             sample = [max(1, shape[0] // 8)] + shape[1:]
             line["cpu_baseline"] = cpu_baseline(sample, reps=5)
