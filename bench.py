@@ -1,34 +1,44 @@
 #!/usr/bin/env python3
 """bench.py -- GElem/s of the LSQ fake-quantize hot path (forward op + backward op) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg1|cfg3|cfg4|cfg5|cfg5_bf16|cfg5_axis0]
 
-One "step" = one `lsq_forward_per_tensor` + one `lsq_backward_per_tensor` (training mode) over one
-batch of synthetic input already resident in HBM: BASELINE.json config 2, per-tensor quint8,
-fp32 [128,512,56,56] (205.5 M elements, 822 MB per tensor) PER GPU.  With N > 1 the batch is sharded
-across the ranks (weak scaling: every rank owns a [128,512,56,56] shard of a [128*N,512,56,56] batch),
-the backward uses the GLOBAL element count in the gradient scaler and ONE RCCL all-reduce of the
-packed fp64 [d_scale, d_shift] pair per step -- inside the timed region.
+One "step" = one forward op + one backward op (training mode) over one batch of synthetic input already resident
+in HBM.  The default workload is BASELINE.json config 2 -- per-tensor quint8, fp32 [128,512,56,56] (205.5 M elements,
+822 MB per tensor) PER GPU; the per-channel half of the path has its own workloads (cfg3, cfg5, cfg5_bf16).
+
+`--gpus N` with N > 1: when the process was not started by a launcher (no WORLD_SIZE in the environment) bench.py
+starts the N ranks itself -- fresh child processes, one per GPU, created before anything in this process touches the
+GPU -- and exits non-zero if fewer than N devices are visible; it never degrades to a smaller run.  Under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it is one of the ranks.  With N > 1 the batch
+is sharded across the ranks (weak scaling: every rank owns a full-size shard; `--workload cfg4` is the strong-scaled
+[1024,1024,14,14] / N), the backward uses the GLOBAL element count in the gradient scaler and ONE RCCL all-reduce of the
+packed fp64 [d_scale, d_shift] sums per step -- inside the timed region.
 
 Rank 0 prints ONE JSON line; `value` is the whole-job aggregate: (elements of all ranks * K) / time,
 time = max over ranks of the K-step wall time bracketed by barrier + synchronize.
 
 Extra objects on the same line:
-  roofline      HBM roofline of the dominant kernel (the fused backward, 12 algorithmic bytes/element:
-                read grad + read x + write dx), from its average launch duration measured live with
-                HIP events on the launch stream inside the timed region.  `fwd` carries the same for
-                the forward kernel (8 B/element) and `step_frac` the 20 B/element fwd+bwd figure
-                BASELINE.md quotes the 70 % target on.
-  cpu_baseline  the reference's own CPU csrc (oracle/_ref/libtorchlsq_ref_ops.so, kind "reference") --
-                or, if that build is absent, the C restatement (kind "port") -- timed on this box's
-                host cores on a bounded sample, rank 0 at N = 1 only.  A reported baseline, not the target.
+  roofline      HBM roofline of the dominant kernel (the fused backward: read grad + read x + write dx = 3 storage
+                elements per element), from its average launch duration measured live with HIP events on the launch
+                stream inside the timed region.  `fwd` carries the same for the forward kernel and `step_frac` the
+                fwd+bwd figure BASELINE.md quotes the 70 % target on.  `traffic` = HBM bytes per backward launch from
+                the FETCH_SIZE / WRITE_SIZE counters: measured by this run (two `rocprofv3 --pmc` child passes of this
+                same command, `--measure-traffic`, default at N = 1) or carried from profiles/ -- `traffic_source` says which.
+  cpu_baseline  the reference's own CPU csrc (oracle/_ref/libtorchlsq_ref_ops.so, kind "reference") -- or, if that
+                build is absent, the C restatement (kind "port") -- timed on this box's host cores on the workload's
+                full shape, at all cores and at 1 thread, rank 0 at N = 1 only.  A reported baseline, not the target.
 """
 import argparse
+import glob
 import json
 import os
+import shutil
+import socket
+import sqlite3
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -36,15 +46,96 @@ sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-BYTES_FWD, BYTES_BWD = 8, 12   # algorithmic bytes per fp32 element
+METRIC = "GElem/s fake-quant fwd+bwd, per-tensor int8, 1/2/4/8 MI355X; % HBM roofline"   # BASELINE.json
+
+# workload -> (synth config, storage dtype, channel axis override)
+WORKLOADS = {
+    "cfg1": ("cfg1", "float32", None),
+    "cfg2": ("cfg2", "float32", None),
+    "cfg3": ("cfg3", "float32", None),
+    "cfg4": ("cfg4", "float32", None),
+    "cfg5": ("cfg5", "float32", None),
+    "cfg5_bf16": ("cfg5", "bfloat16", None),
+    "cfg5_axis0": ("cfg5", "float32", 0),
+}
 
 
-def cpu_baseline(sample_shape, reps):
-    """Time the reference CPU path (or the port) on a bounded sample of the same workload."""
-    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--shape",
-           ",".join(str(s) for s in sample_shape), "--reps", str(reps)]
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
+                    help="cfg2 (default; weak-scaled per GPU) | cfg4 (strong: [1024,1024,14,14] split over the ranks) | "
+                         "cfg1 | cfg3, cfg5, cfg5_bf16, cfg5_axis0 (per-channel)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--measure-traffic", dest="measure_traffic", action="store_true", default=None,
+                    help="measure roofline.traffic in this run with two rocprofv3 --pmc child passes (default at N = 1)")
+    ap.add_argument("--no-measure-traffic", dest="measure_traffic", action="store_false")
+    ap.add_argument("--no-yardstick", action="store_true", help="skip the ATen add / copy rates measured after the timed region")
+    ap.add_argument("--host-binding", default="auto", choices=["auto", "native", "ctypes"],
+                    help="host layer above the C ABI: the C++ torch binding (_lsq_torch.so) or the Python/ctypes one")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a HIP graph (GPU-side rate of latency-bound workloads; N = 1 only)")
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)            # "gloo" + --single-device: smoke-test
+    ap.add_argument("--single-device", action="store_true", help=argparse.SUPPRESS)  # the N>1 control flow on a 1-GPU box
+    ap.add_argument("--variant-fwd", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--variant-bwd", type=int, default=0, help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(a):
+    """Start `--gpus` rank processes of this script (one per GPU) and relay rank 0's JSON line.
+
+    Nothing here initialises the GPU: the device count comes from torch.cuda.device_count() (which does not create a
+    HIP context on this image) and every rank is a fresh child process."""
+    import torch
+    visible = torch.cuda.device_count()
+    if not a.single_device and visible < a.gpus:
+        sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) are visible; refusing to run a smaller job\n"
+                         % (a.gpus, visible))
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this pool
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True if r == 0 else None))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: rank exit codes %s\n" % bad)
+        return 1
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# side measurements
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(shape, workload):
+    """Time the reference CPU path (or the port) on the workload's shape: all cores and one thread."""
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--shape", ",".join(str(s) for s in shape),
+           "--workload", workload]
     try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         for line in reversed(out.stdout.strip().splitlines()):
             if line.startswith("{"):
                 return json.loads(line)
@@ -53,20 +144,74 @@ def cpu_baseline(sample_shape, reps):
         return {"error": repr(e)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg2", help="cfg2 (default, weak-scaled per GPU) | cfg4 (strong: "
-                    "[1024,1024,14,14] split over the ranks) | cfg1")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)            # "gloo" + --single-device: smoke-test
-    ap.add_argument("--single-device", action="store_true", help=argparse.SUPPRESS)  # the N>1 control flow on a 1-GPU box
-    ap.add_argument("--variant-fwd", type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument("--variant-bwd", type=int, default=0, help=argparse.SUPPRESS)
-    a = ap.parse_args()
+def _pmc_mean(db_dir, counter, kernel_substr):
+    dbs = sorted(glob.glob(os.path.join(db_dir, "**", "*.db"), recursive=True))
+    if not dbs:
+        return None
+    cur = sqlite3.connect(dbs[-1]).cursor()
+    q = ("select s.display_name, avg(e.value), count(*) from rocpd_pmc_event e "
+         "join rocpd_info_pmc p on e.pmc_id = p.id join rocpd_kernel_dispatch d on e.event_id = d.event_id "
+         "join rocpd_info_kernel_symbol s on d.kernel_id = s.id where p.name = ? group by s.display_name")
+    for name, val, cnt in cur.execute(q, (counter,)):
+        if kernel_substr in name:
+            return float(val), int(cnt), name
+    return None
 
+
+def measure_traffic(a, kernel_substr):
+    """HBM bytes per backward launch from the PMC counters, collected as MI355X_MICROARCH.md prescribes: separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (with --kernel-trace only) over a short run of this same
+    command in a child process; units KiB; gfx950 correction: FETCH_SIZE tallies the 128-byte requests of a wide
+    coalesced read at 64 bytes, so it is doubled (calibrated on known-size probe kernels: profiles/r01_pmc_calibration.txt)."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    raw = {}
+    tmp = tempfile.mkdtemp(prefix="lsq_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [rocprof, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "bench", "--", sys.executable,
+                   os.path.abspath(__file__), "--workload", a.workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                   "--no-measure-traffic", "--no-yardstick", "--host-binding", a.host_binding]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd="/tmp", env=env)
+            got = _pmc_mean(d, ctr, kernel_substr)
+            if got is None:
+                return None, "%s pass produced no counter rows for %s (exit %d): %s" % (ctr, kernel_substr, r.returncode,
+                                                                                       (r.stderr or "")[-200:])
+            raw[ctr] = got
+    except Exception as e:
+        return None, repr(e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch_kib, write_kib = raw["FETCH_SIZE"][0], raw["WRITE_SIZE"][0]
+    info = {"fetch_size_kib_raw": round(fetch_kib, 1), "write_size_kib": round(write_kib, 1),
+            "dispatches_averaged": raw["FETCH_SIZE"][1], "kernel": raw["FETCH_SIZE"][2][:120],
+            "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024"}
+    return int(round((2.0 * fetch_kib + write_kib) * 1024.0)), info
+
+
+def carried_traffic(workload, n_local):
+    """The committed PMC measurement of this workload (profiles/traffic_latest.json), when this run does not measure."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(tpath) as f:
+            tj = json.load(f)
+        entries = tj["workloads"] if "workloads" in tj else {tj.get("workload"): tj}
+        e = entries.get(workload)
+        if e and e.get("n_local") == n_local:
+            return e.get("bwd_hbm_bytes_per_launch"), "carried from profiles/traffic_latest.json (%s); not measured in this run" % \
+                e.get("source", "rocprofv3 --pmc passes of an earlier run of this command")
+    except Exception:
+        pass
+    return None, "not measured"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------------------
+def run_rank(a):
     # multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise); the
     # launcher normally exports it already
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -80,8 +225,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus != world and world > 1:
+    if a.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if not a.single_device and torch.cuda.device_count() <= local_rank:
+        raise SystemExit("rank %d: no GPU %d on this node (%d visible)" % (rank, local_rank, torch.cuda.device_count()))
     dev = torch.device("cuda", 0 if a.single_device else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
@@ -91,38 +238,66 @@ def main():
         else:
             dist.init_process_group(backend=a.backend)
 
-    c = synth.CONFIGS[a.workload]
+    if a.host_binding == "native":
+        extension.set_host_binding("native")
+    elif a.host_binding == "ctypes":
+        extension.set_host_binding("ctypes")
+    binding = extension.host_binding()
+    # the ops of the hot path on the chosen host layer: torch.ops.torchlsq_native.* (C++ binding) or torch.ops.torchlsq.*
+    # (Python torch.library registration over ctypes); both end in the same C-ABI call
+    ops = torch.ops.torchlsq_native if binding == "native" else torch.ops.torchlsq
+
+    cfg_name, dtype_name, axis_override = WORKLOADS[a.workload]
+    c = dict(synth.CONFIGS[cfg_name])
+    if axis_override is not None:
+        c["axis"] = axis_override
+    dt = getattr(torch, dtype_name)
+    esz = 2 if dt in (torch.bfloat16, torch.float16) else 4
+    per_channel = c["per_channel"]
     shape = list(c["shape"])
     scaling = "weak"
     if a.workload == "cfg4":           # strong scaling: fixed global batch split over the ranks
         assert shape[0] % world == 0
         shape[0] //= world
         scaling = "strong"
-    x, g, scale, shift = synth.make_inputs(a.workload, device=dev, dtype=torch.float32, shape=shape)
+    if world > 1 and per_channel and c["axis"] == 0:
+        raise SystemExit("workload %s quantises along dim 0, the sharded dim: a weight is replicated under data "
+                         "parallelism, there is nothing to shard -- run it with --gpus 1" % a.workload)
+    if a.graph and world > 1:
+        raise SystemExit("--graph is a 1-GPU measurement")
+    x, g, scale, shift = synth.make_inputs(c, device=dev, dtype=dt, shape=shape)
     n_local = x.numel()
     n_global = n_local * world
-    ops = torch.ops.torchlsq
     q = (c["qmin"], c["qmax"], c["tmin"], c["tmax"])
     sym = not c["affine"]
+    axis = c["axis"]
+    tail = q + (True, 1.0, sym, False, False)
 
     def fwd():
-        if a.variant_fwd == 0:     # the registered op: dispatcher -> ctypes -> C ABI -> kernel
-            return ops.lsq_forward_per_tensor(x, scale, shift, *q, True, 1.0, sym, False, False)
-        return extension.hip_forward_per_tensor(x, scale, shift, *q, True, 1.0, sym, False, False, variant=a.variant_fwd)
+        if a.variant_fwd:
+            if per_channel:
+                return extension.hip_forward_per_channel(x, scale, shift, axis, *tail, variant=a.variant_fwd)
+            return extension.hip_forward_per_tensor(x, scale, shift, *tail, variant=a.variant_fwd)
+        if per_channel:
+            return ops.lsq_forward_per_channel(x, scale, shift, axis, *tail)
+        return ops.lsq_forward_per_tensor(x, scale, shift, *tail)
 
     pending = []   # N > 1: the previous step's in-flight all-reduce (RCCL runs it on its own stream)
 
     def bwd():
         if world == 1:
-            if a.variant_bwd == 0:
-                return ops.lsq_backward_per_tensor(g, x, scale, shift, *q, True, 1.0, sym, False, False)
-            return extension.hip_backward_per_tensor(g, x, scale, shift, *q, True, 1.0, sym, False, False,
-                                                     variant=a.variant_bwd)
+            if a.variant_bwd:
+                if per_channel:
+                    return extension.hip_backward_per_channel(g, x, scale, shift, axis, *tail, variant=a.variant_bwd)
+                return extension.hip_backward_per_tensor(g, x, scale, shift, *tail, variant=a.variant_bwd)
+            if per_channel:
+                return ops.lsq_backward_per_channel(g, x, scale, shift, axis, *tail)
+            return ops.lsq_backward_per_tensor(g, x, scale, shift, *tail)
         # batch-sharded: local fused backward with the GLOBAL numel in the gradient scaler, then ONE
-        # all-reduce of the packed fp64 [d_scale, d_shift] pair.  The collective is issued async and
+        # all-reduce of the packed fp64 [d_scale, d_shift] sums.  The collective is issued async and
         # consumed one step later (d_scale/d_shift are only needed by the optimizer), so its latency
         # hides behind the next step's kernels; every reduction is completed inside the timed region.
-        dx, wide, work = sharded_backward(g, x, scale, shift, *q, 1, True, 1.0, c["affine"], False, False, False,
+        dx, wide, work = sharded_backward(g, x, scale, shift, *q, axis, True, 1.0, c["affine"], per_channel, False, False,
                                           None, n_global, async_op=True)
         drain()
         pending.append((wide, work))
@@ -135,38 +310,62 @@ def main():
             ds_db = wide.to(torch.float32)                # the rounding to the parameter type
         return None
 
+    step_graph = None
+    if a.graph:
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            fwd(); bwd()
+            step_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(step_graph, stream=st):
+                y = fwd()
+                r = bwd()
+        torch.cuda.synchronize()
+
     for _ in range(a.warmup):
-        y = fwd()
-        r = bwd()
+        if step_graph is not None:
+            step_graph.replay()
+        else:
+            y = fwd()
+            r = bwd()
     drain()
     torch.cuda.synchronize()
 
     # HIP events bracket the forward and the backward op on every `stride`-th step of the timed region (an
     # event record drains the queue, so bracketing every op of every step would itself cost a few % of a
-    # 0.7 ms step); at least 10 steps are sampled.
+    # 0.7 ms step); at least 10 steps are sampled.  (Under --graph the ops are nodes of one graph launch, so the
+    # per-op split comes from a second, un-timed pass of eager launches.)
     stride = max(1, min(4, a.steps // 10))
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] if i % stride == 0 else None for i in range(a.steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        e = ev[i]
-        if e is None:
-            y = fwd()
-            r = bwd()
-        else:
-            e[0].record()
-            y = fwd()
-            e[1].record()
-            r = bwd()
-            e[2].record()
+    if step_graph is not None:
+        for i in range(a.steps):
+            step_graph.replay()
+    else:
+        for i in range(a.steps):
+            e = ev[i]
+            if e is None:
+                y = fwd()
+                r = bwd()
+            else:
+                e[0].record()
+                y = fwd()
+                e[1].record()
+                r = bwd()
+                e[2].record()
     drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if step_graph is not None:
+        for e in ev:
+            if e is not None:
+                e[0].record(); y = fwd(); e[1].record(); r = bwd(); e[2].record()
+        torch.cuda.synchronize()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -179,45 +378,69 @@ def main():
     bwd_avg = sum(bwd_ms) / len(bwd_ms)
 
     if rank == 0:
+        bytes_fwd, bytes_bwd = 2 * esz, 3 * esz   # algorithmic bytes per element: R x + W y; R grad + R x + W dx
         value = n_global * a.steps / elapsed_max / 1e9
-        bwd_gbs = BYTES_BWD * n_local / (bwd_avg * 1e-3) / 1e9
-        fwd_gbs = BYTES_FWD * n_local / (fwd_avg * 1e-3) / 1e9
-        step_gbs = (BYTES_FWD + BYTES_BWD) * n_local / ((fwd_avg + bwd_avg) * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.isfile(tpath):
-            try:
-                with open(tpath) as f:
-                    tj = json.load(f)
-                if tj.get("workload") == a.workload and tj.get("n_local") == n_local:
-                    traffic = tj.get("bwd_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        bwd_gbs = bytes_bwd * n_local / (bwd_avg * 1e-3) / 1e9
+        fwd_gbs = bytes_fwd * n_local / (fwd_avg * 1e-3) / 1e9
+        step_gbs = (bytes_fwd + bytes_bwd) * n_local / ((fwd_avg + bwd_avg) * 1e-3) / 1e9
+        io = {"float32": "io_f32", "bfloat16": "io_bf16"}[dtype_name]
+        if per_channel:
+            outer = 1
+            for d_ in shape[:axis]:
+                outer *= d_
+            inner = 1
+            for d_ in shape[axis + 1:]:
+                inner *= d_
+            seg = outer < 8 and inner % (16 // esz) == 0 and inner >= 256 * (16 // esz)    # lsq_pc_geom.hpp pick_segment_mode
+            kb, kf = ("bwd_seg_kernel", "fwd_seg_kernel") if seg else ("bwd_pc_kernel", "fwd_pc_kernel")
+            what = "per-channel %s (qmin,qmax=%d,%d; axis %d: [outer,C,inner]=[%d,%d,%d], %s mode)" % (
+                "qint8" if c["qmin"] < 0 else "quint8", c["qmin"], c["qmax"], axis, outer, shape[axis], inner,
+                "segment" if seg else "window")
+            opnames = "lsq_forward_per_channel + lsq_backward_per_channel"
+        else:
+            kb, kf = "bwd_pt_kernel", "fwd_pt_kernel"
+            what = "per-tensor quint8 (qmin,qmax=%d,%d)" % (c["qmin"], c["qmax"])
+            opnames = "lsq_forward_per_tensor + lsq_backward_per_tensor"
+        traffic, traffic_source = None, "not measured"
+        want_pmc = a.measure_traffic if a.measure_traffic is not None else (world == 1 and not a.graph)
+        if want_pmc and world == 1:
+            traffic, info = measure_traffic(a, "lsq::" + kb)
+            if traffic is not None:
+                traffic_source = dict(info, how="measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child "
+                                                "passes (separate, --kernel-trace only) over 3 steps of this same command")
+            else:
+                carried, src = carried_traffic(a.workload, n_local)
+                traffic, traffic_source = carried, "live PMC passes failed (%s); %s" % (info, src)
+        else:
+            traffic, traffic_source = carried_traffic(a.workload, n_local)
+        metric = METRIC if not per_channel else METRIC.replace("per-tensor int8", "per-channel (%s workload, not the BASELINE headline)" % a.workload)
         line = {
-            "metric": "GElem/s fake-quant fwd+bwd, per-tensor int8, 1/2/4/8 MI355X; % HBM roofline",
+            "metric": metric,
             "value": round(value, 3), "unit": "GElem/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed_max / a.steps * 1e3, 5), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: per-tensor quint8 (qmin,qmax=%d,%d) fp32 %s per GPU, lsq_forward_per_tensor + "
-                                   "lsq_backward_per_tensor%s" % (a.workload, c["qmin"], c["qmax"], shape,
-                                                                  "" if world == 1 else ", batch-sharded, 1 RCCL all-reduce of fp64 [ds,db] per step"),
+            "config": {"workload": "%s: %s %s %s per GPU, %s%s" % (a.workload, what, dtype_name, shape, opnames,
+                                                                    "" if world == 1 else ", batch-sharded, 1 RCCL all-reduce of fp64 [ds,db] per step"),
+                       "storage": dtype_name, "arithmetic": "float32",
                        "elements_per_gpu": n_local, "global_elements": n_global,
-                       "parallelism": "dp%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "lsq::bwd_pt_kernel<io_f32> (fused dx + d_scale/d_shift reduction)",
+                       "parallelism": "dp%d" % world, "host_binding": binding,
+                       "launch": "hip-graph replay" if a.graph else "eager"},
+            "roofline": {"bound": "hbm", "kernel": "lsq::%s<%s> (fused dx + d_scale/d_shift reduction)" % (kb, io),
                          "achieved": round(bwd_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(bwd_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "bytes_per_launch": BYTES_BWD * n_local, "avg_launch_ms": round(bwd_avg, 5), "launches_timed": len(bwd_ms),
+                         "frac": round(bwd_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_over_algorithmic": (round(traffic / float(bytes_bwd * n_local), 5) if traffic else None),
+                         "bytes_per_launch": bytes_bwd * n_local, "avg_launch_ms": round(bwd_avg, 5), "launches_timed": len(bwd_ms),
                          "median_launch_ms": round(bwd_ms[len(bwd_ms) // 2], 5),
-                         "fwd": {"kernel": "lsq::fwd_pt_kernel<io_f32>", "achieved": round(fwd_gbs, 1),
+                         "fwd": {"kernel": "lsq::%s<%s>" % (kf, io), "achieved": round(fwd_gbs, 1),
                                  "frac": round(fwd_gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(fwd_avg, 5),
-                                 "bytes_per_launch": BYTES_FWD * n_local},
+                                 "bytes_per_launch": bytes_fwd * n_local},
                          "step_achieved": round(step_gbs, 1), "step_frac": round(step_gbs / HBM_PEAK_GBS, 4),
-                         # the read-only variant next to the all-traffic figure -- 12 of the 20
-                         # algorithmic bytes per element are reads (4 forward + 8 backward), so it is 0.6 x step_frac
-                         "step_reads_only_achieved": round(step_gbs * 12.0 / 20.0, 1),
-                         "step_reads_only_frac": round(step_gbs * 12.0 / 20.0 / HBM_PEAK_GBS, 4)},
+                         # the read-only variant next to the all-traffic figure -- 3 of the 5
+                         # algorithmic storage elements per element are reads (1 forward + 2 backward), so it is 0.6 x step_frac
+                         "step_reads_only_achieved": round(step_gbs * 0.6, 1),
+                         "step_reads_only_frac": round(step_gbs * 0.6 / HBM_PEAK_GBS, 4)},
         }
-        if world == 1:
+        if world == 1 and not a.no_yardstick:
             # Context for the roofline fraction, measured live on THIS box after the timed region: the framework's /
             # vendor's own kernels on the same two traffic shapes (ATen's vectorised add = 2 reads : 1 write like the
             # backward; its copy = 1 read : 1 write like the forward).  Not part of `value`.
@@ -233,17 +456,26 @@ def main():
                     return round(bytes_per_elem * n_local / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9, 1)
                 scratch = torch.empty_like(x)
                 line["roofline"]["same_box_reference_kernels"] = {
-                    "aten_add_2r1w_GBps": _gbs(lambda: torch.add(g, x, out=scratch), BYTES_BWD),
-                    "aten_copy_1r1w_GBps": _gbs(lambda: scratch.copy_(x), BYTES_FWD)}
+                    "aten_add_2r1w_GBps": _gbs(lambda: torch.add(g, x, out=scratch), bytes_bwd),
+                    "aten_copy_1r1w_GBps": _gbs(lambda: scratch.copy_(x), bytes_fwd)}
                 del scratch
             except Exception as e:      # context only: never let it break the bench line
                 line["roofline"]["same_box_reference_kernels"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
-            sample = [max(1, shape[0] // 8)] + shape[1:]
-            line["cpu_baseline"] = cpu_baseline(sample, reps=5)
+            line["cpu_baseline"] = cpu_baseline(shape, a.workload)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    a = parse_args()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))      # no launcher: this process only starts the ranks (it never touches the GPU)
+    sys.exit(run_rank(a))
 
 
 if __name__ == "__main__":

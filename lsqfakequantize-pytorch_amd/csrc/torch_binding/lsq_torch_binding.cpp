@@ -58,7 +58,7 @@ int32_t narrow(int64_t v, const char* name) {
     return static_cast<int32_t>(v);
 }
 
-lsq_params pack(const Scalars& s) {
+lsq_params pack(const Scalars& s, int64_t numel_for_scaler = 0) {
     lsq_params p;
     p.quant_min = narrow(s.qmin, "quant_min");
     p.quant_max = narrow(s.qmax, "quant_max");
@@ -69,15 +69,25 @@ lsq_params pack(const Scalars& s) {
     p.eval_mode = s.eval_mode;
     p.init_mode = s.init_mode;
     p.grad_scaler = s.gs;
-    p.numel_for_scaler = 0;
+    p.numel_for_scaler = numel_for_scaler;   // <= 0: this call's own element count (the reference behaviour)
     return p;
 }
 
 void status(int rc, const char* what) { TORCH_CHECK(rc == 0, what, " failed (", rc, "): ", lsq_hip_last_error()); }
 
+// every tensor of a call lives on the GPU the kernel is launched on (the first tensor's): raw pointers of another
+// device would only work by accident of peer access
 void require_gpu(const char* what, std::initializer_list<const Tensor*> ts) {
-    for (const Tensor* t : ts)
+    const Tensor* first = *ts.begin();
+    for (const Tensor* t : ts) {
         TORCH_CHECK(t->is_cuda(), what, ": expected a tensor on the GPU (HIP device) but got device ", t->device());
+        TORCH_CHECK(t->device() == first->device(), what, ": expected all tensors on ", first->device(), " but got one on ",
+                    t->device());
+    }
+}
+
+void require_param(const char* what, const Tensor& scale, const Tensor& shift) {
+    TORCH_CHECK(scale.numel() >= 1 && shift.numel() >= 1, what, ": scale and shift need at least one element");
 }
 
 void check_forward_types(const Tensor& x, const Tensor& scale, const Tensor& shift) {
@@ -144,12 +154,14 @@ std::tuple<Tensor, Tensor> forward_impl(const Tensor& x, const Tensor& scale, co
                                         int64_t axis, const Scalars& s, bool want_mask) {
     check_forward_types(x, scale, shift);
     if (per_channel) check_channel_args(x, scale, shift, axis);
-    require_gpu(per_channel ? "lsq_forward_per_channel" : "lsq_forward_per_tensor", {&x, &scale, &shift});
+    const char* what = per_channel ? "lsq_forward_per_channel" : "lsq_forward_per_tensor";
+    require_gpu(what, {&x, &scale, &shift});
     const Tensor xd = dense(x);
     Tensor y = at::empty_like(xd);
     Tensor mask;
     if (want_mask) mask = at::empty_strided(xd.sizes(), xd.strides(), xd.options().dtype(at::kChar));
     if (xd.numel() == 0) return {y, mask};
+    require_param(what, scale, shift);
     const lsq_params p = pack(s);
     const lsq_fwd_extras ex{want_mask ? mask.data_ptr() : nullptr, 0, 1};
     const Tensor sc = scale.contiguous(), sh = shift.contiguous();
@@ -168,37 +180,56 @@ std::tuple<Tensor, Tensor> forward_impl(const Tensor& x, const Tensor& scale, co
     return {y, mask};
 }
 
-std::tuple<Tensor, Tensor, Tensor> backward_impl(const Tensor& grad, const Tensor& x, const Tensor& scale,
-                                                 const Tensor& shift, bool per_channel, int64_t axis, const Scalars& s) {
+// `want_wide`: also return the un-rounded fp64 sums ([2] per-tensor, [2, C] per-channel; d_scale sums first) -- what
+// the batch-sharded path all-reduces -- and use `numel_for_scaler` (the GLOBAL element count) in the gradient scaler.
+struct BackwardOut {
+    Tensor dx, ds, db, wide;
+};
+
+BackwardOut backward_impl(const Tensor& grad, const Tensor& x, const Tensor& scale, const Tensor& shift, bool per_channel,
+                          int64_t axis, const Scalars& s, int64_t numel_for_scaler = 0, bool want_wide = false) {
     check_backward_types(grad, x, scale, shift);
     if (per_channel) check_channel_args(x, scale, shift, axis);
-    if (x.numel() <= 0) return {x.clone(), scale.clone(), shift.clone()};  // lsq_cpu.cpp:76-78,221-223
-    require_gpu(per_channel ? "lsq_backward_per_channel" : "lsq_backward_per_tensor", {&grad, &x, &scale, &shift});
+    if (x.numel() <= 0) {   // lsq_cpu.cpp:76-78,221-223 return (x, scale, shift) themselves
+        Tensor wide;
+        if (want_wide) {
+            const auto dopt = x.options().dtype(at::kDouble);
+            wide = per_channel ? at::zeros({2, scale.numel()}, dopt) : at::zeros({2}, dopt);
+        }
+        return {x.clone(), scale.clone(), shift.clone(), wide};
+    }
+    const char* what = per_channel ? "lsq_backward_per_channel" : "lsq_backward_per_tensor";
+    require_gpu(what, {&x, &grad, &scale, &shift});
+    require_param(what, scale, shift);
     const Tensor xd = dense(x);
     const Tensor gd = like_layout(grad, xd);
     Tensor dx = at::empty_like(xd);
-    const lsq_params p = pack(s);
+    const lsq_params p = pack(s, numel_for_scaler);
     const Tensor sc = scale.contiguous(), sh = shift.contiguous();
     const int code = dtype_code(x.scalar_type(), "lsq_backward");
     const auto popt = x.options().dtype(param_type(x.scalar_type()));
     c10::DeviceGuard guard(x.device());
+    Tensor wide;
     if (per_channel) {
         const Geometry g = geometry(xd, axis);
         Tensor ds = at::empty({g.channels}, popt), db = at::empty({g.channels}, popt);
+        if (want_wide) wide = at::empty({2, g.channels}, x.options().dtype(at::kDouble));
         const Tensor ws = byte_workspace(x, lsq_hip_backward_per_channel_workspace(code, g.outer, g.channels, g.inner));
         status(lsq_hip_backward_per_channel(code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(), ds.data_ptr(), db.data_ptr(),
-                                            nullptr, g.outer, g.channels, g.inner, sc.data_ptr(), sh.data_ptr(), &p,
-                                            ws.data_ptr(), static_cast<size_t>(ws.numel()), stream_of(x)),
+                                            want_wide ? wide.data_ptr<double>() : nullptr, g.outer, g.channels, g.inner,
+                                            sc.data_ptr(), sh.data_ptr(), &p, ws.data_ptr(), static_cast<size_t>(ws.numel()),
+                                            stream_of(x)),
                "lsq_hip_backward_per_channel");
-        return {dx, ds, db};
+        return {dx, ds, db, wide};
     }
     Tensor ds = at::empty({1}, popt), db = at::empty({1}, popt);
+    if (want_wide) wide = at::empty({2}, x.options().dtype(at::kDouble));
     const Tensor ws = byte_workspace(x, lsq_hip_backward_per_tensor_workspace(code, xd.numel()));
-    status(lsq_hip_backward_per_tensor(code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(), ds.data_ptr(), db.data_ptr(), nullptr,
-                                       xd.numel(), sc.data_ptr(), sh.data_ptr(), &p, ws.data_ptr(),
-                                       static_cast<size_t>(ws.numel()), stream_of(x)),
+    status(lsq_hip_backward_per_tensor(code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(), ds.data_ptr(), db.data_ptr(),
+                                       want_wide ? wide.data_ptr<double>() : nullptr, xd.numel(), sc.data_ptr(), sh.data_ptr(), &p,
+                                       ws.data_ptr(), static_cast<size_t>(ws.numel()), stream_of(x)),
            "lsq_hip_backward_per_tensor");
-    return {dx, ds, db};
+    return {dx, ds, db, wide};
 }
 
 Tensor backward_from_mask(const Tensor& grad, const Tensor& mask) {
@@ -230,7 +261,8 @@ std::tuple<Tensor, Tensor, Tensor> backward_per_tensor(const Tensor& grad, const
                                                        const Tensor& shift, int64_t qmin, int64_t qmax, int64_t tmin,
                                                        int64_t tmax, bool use_gs, double gs, bool sym, bool eval_mode,
                                                        bool init_mode) {
-    return backward_impl(grad, x, scale, shift, false, 0, {qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode});
+    BackwardOut o = backward_impl(grad, x, scale, shift, false, 0, {qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode});
+    return {o.dx, o.ds, o.db};
 }
 
 Tensor forward_per_channel(const Tensor& x, const Tensor& scale, const Tensor& shift, int64_t axis, int64_t qmin,
@@ -243,7 +275,26 @@ std::tuple<Tensor, Tensor, Tensor> backward_per_channel(const Tensor& grad, cons
                                                         const Tensor& shift, int64_t axis, int64_t qmin, int64_t qmax,
                                                         int64_t tmin, int64_t tmax, bool use_gs, double gs, bool sym,
                                                         bool eval_mode, bool init_mode) {
-    return backward_impl(grad, x, scale, shift, true, axis, {qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode});
+    BackwardOut o = backward_impl(grad, x, scale, shift, true, axis, {qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode});
+    return {o.dx, o.ds, o.db};
+}
+
+// The batch-sharded backward (torchlsq/distributed.py): dx and the un-rounded fp64 sums, with the GLOBAL element count
+// in the gradient scaler.  No reference counterpart.
+std::tuple<Tensor, Tensor> backward_per_tensor_wide(const Tensor& grad, const Tensor& x, const Tensor& scale, const Tensor& shift,
+                                                    int64_t qmin, int64_t qmax, int64_t tmin, int64_t tmax, bool use_gs, double gs,
+                                                    bool sym, bool eval_mode, bool init_mode, int64_t numel_for_scaler) {
+    BackwardOut o = backward_impl(grad, x, scale, shift, false, 0, {qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode},
+                                  numel_for_scaler, true);
+    return {o.dx, o.wide};
+}
+
+std::tuple<Tensor, Tensor> backward_per_channel_wide(const Tensor& grad, const Tensor& x, const Tensor& scale, const Tensor& shift,
+                                                     int64_t axis, int64_t qmin, int64_t qmax, int64_t tmin, int64_t tmax, bool use_gs,
+                                                     double gs, bool sym, bool eval_mode, bool init_mode, int64_t numel_for_scaler) {
+    BackwardOut o = backward_impl(grad, x, scale, shift, true, axis, {qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode},
+                                  numel_for_scaler, true);
+    return {o.dx, o.wide};
 }
 
 // ---- autograd node: LSQPerTensorFunction / LSQPerChannelFunction of lsq_autograd.cpp:16-74,111-173 in one ----
@@ -280,7 +331,8 @@ class LsqNode : public torch::autograd::Function<LsqNode> {
         } else {
             const Scalars s{cfg[0], cfg[1], cfg[2], cfg[3], (flags & 1) != 0, ctx->saved_data["gs"].toDouble(),
                             (flags & 2) != 0, (flags & 8) != 0, (flags & 16) != 0};
-            std::tie(dx, ds, db) = backward_impl(grads[0], saved[0], saved[1], saved[2], (flags & 4) != 0, cfg[4], s);
+            BackwardOut o = backward_impl(grads[0], saved[0], saved[1], saved[2], (flags & 4) != 0, cfg[4], s);
+            dx = o.dx; ds = o.ds; db = o.db;
         }
         torch::autograd::variable_list out(14);
         out[0] = dx; out[1] = ds; out[2] = db;
@@ -315,6 +367,10 @@ TORCH_LIBRARY(torchlsq_native, m) {
     m.def("lsq_forward_per_channel(Tensor x, Tensor scale, Tensor shift, int axis, " LSQ_TAIL ") -> Tensor");
     m.def("lsq_backward_per_channel(Tensor grad, Tensor x, Tensor scale, Tensor shift, int axis, " LSQ_TAIL
           ") -> (Tensor, Tensor, Tensor)");
+    m.def("lsq_backward_per_tensor_wide(Tensor grad, Tensor x, Tensor scale, Tensor shift, " LSQ_TAIL
+          ", int numel_for_scaler) -> (Tensor, Tensor)");
+    m.def("lsq_backward_per_channel_wide(Tensor grad, Tensor x, Tensor scale, Tensor shift, int axis, " LSQ_TAIL
+          ", int numel_for_scaler) -> (Tensor, Tensor)");
     m.def("lsq_backward_from_mask(Tensor grad, Tensor mask) -> Tensor");
     // composite (autograd handled by the node inside), like the reference's front op
     m.def("lsq(Tensor x, Tensor scale, Tensor shift, int quant_min, int quant_max, int type_min, int type_max, int axis, "
@@ -328,5 +384,7 @@ TORCH_LIBRARY_IMPL(torchlsq_native, CUDA, m) {  // PyTorch-ROCm dispatches HIP t
     m.impl("lsq_backward_per_tensor", &backward_per_tensor);
     m.impl("lsq_forward_per_channel", &forward_per_channel);
     m.impl("lsq_backward_per_channel", &backward_per_channel);
+    m.impl("lsq_backward_per_tensor_wide", &backward_per_tensor_wide);
+    m.impl("lsq_backward_per_channel_wide", &backward_per_channel_wide);
     m.impl("lsq_backward_from_mask", &backward_from_mask);
 }

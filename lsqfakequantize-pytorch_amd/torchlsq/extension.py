@@ -388,9 +388,19 @@ def _workspace(device, nbytes):
 
 
 def _require_gpu(what, *tensors):
+    """Every tensor of a call lives on the GPU the kernel is launched on (the first tensor's): raw pointers of
+    another device would only work by accident of peer access."""
+    dev = tensors[0].device
     for t in tensors:
         if not t.is_cuda:
             raise RuntimeError("%s: expected a tensor on the GPU (HIP device) but got device %s" % (what, t.device))
+        if t.device != dev:
+            raise RuntimeError("%s: expected all tensors on %s but got one on %s" % (what, dev, t.device))
+
+
+def _require_param(what, scale, shift):
+    if scale.numel() < 1 or shift.numel() < 1:
+        raise RuntimeError("%s: scale and shift need at least one element" % what)
 
 
 def _aux_output(xd, levels_bias, want_mask):
@@ -413,6 +423,7 @@ def hip_forward_per_tensor(x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, 
     has_aux = levels_bias is not None or want_mask
     if n == 0:
         return (y, torch.empty(x.shape, dtype=torch.int8, device=x.device)) if has_aux else y
+    _require_param("lsq_forward_per_tensor", scale, shift)
     lv, ex = _aux_output(xd, levels_bias, want_mask)
     _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
     scale_c, shift_c = scale.contiguous(), shift.contiguous()
@@ -432,7 +443,8 @@ def hip_backward_per_tensor(grad, x, scale, shift, qmin, qmax, tmin, tmax, use_g
         if want_wide:
             return x.clone(), torch.zeros(2, dtype=torch.float64, device=x.device)
         return x.clone(), scale.clone(), shift.clone()
-    _require_gpu("lsq_backward_per_tensor", grad, x, scale, shift)
+    _require_gpu("lsq_backward_per_tensor", x, grad, scale, shift)
+    _require_param("lsq_backward_per_tensor", scale, shift)
     xd, _ = _dense(x)
     gd = _like_layout(grad, xd)
     dx = torch.empty_like(xd)
@@ -520,7 +532,7 @@ def hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax
         if want_wide:
             return x.clone(), torch.zeros(2, scale.numel(), dtype=torch.float64, device=x.device)
         return x.clone(), scale.clone(), shift.clone()
-    _require_gpu("lsq_backward_per_channel", grad, x, scale, shift)
+    _require_gpu("lsq_backward_per_channel", x, grad, scale, shift)
     xd, order = _dense(x)
     gd = _like_layout(grad, xd)
     dx = torch.empty_like(xd)

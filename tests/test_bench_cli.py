@@ -1,0 +1,49 @@
+"""bench.py's launcher behaviour: `--gpus N` starts N ranks itself or exits non-zero -- never a smaller run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_more_gpus_than_visible_is_refused():
+    """No launcher and fewer devices than --gpus: non-zero exit, no JSON line (here: no GPU at all; on the GPU box: 1)."""
+    r = _run(["--gpus", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "refusing" in r.stderr
+
+
+@pytest.mark.gpu
+def test_self_spawned_ranks_on_one_device():
+    """`--gpus 2` without a launcher: bench.py starts both ranks (here sharing the one GPU, collective over gloo
+    because RCCL refuses two ranks on one device) and rank 0 reports n_gpus = 2 and twice the elements."""
+    r = _run(["--gpus", "2", "--backend", "gloo", "--single-device", "--workload", "cfg1", "--steps", "6", "--warmup", "2",
+              "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["global_elements"] == 2 * out["config"]["elements_per_gpu"]
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["cfg3", "cfg5_bf16"])
+def test_per_channel_workloads_report_their_kernel(workload):
+    r = _run(["--workload", workload, "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-measure-traffic"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and "per-channel" in out["config"]["workload"]
+    assert ("bwd_seg_kernel" if workload == "cfg3" else "bwd_pc_kernel") in out["roofline"]["kernel"]
+    assert out["roofline"]["traffic_source"]
