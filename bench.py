@@ -116,6 +116,14 @@ def spawn_ranks(a):
         env.setdefault("OMP_NUM_THREADS", "1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True if r == 0 else None))
+    # a rank that dies early would leave the others waiting in the rendezvous: watch them all, stop the rest on a failure
+    while all(p.poll() is None for p in procs):
+        time.sleep(0.2)
+    if any(p.poll() not in (None, 0) for p in procs):
+        time.sleep(2.0)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                     # exactly the children started above
     out0, _ = procs[0].communicate()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
     sys.stdout.write(out0)
