@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define LSQ_HIP_ABI_VERSION 1
+#define LSQ_HIP_ABI_VERSION 2
 
 /* Storage type of x / grad / y / dx.  Arithmetic is fp32 for F32, BF16 and F16 storage and fp64
  * for F64 (reference CPU path: AT_DISPATCH_FLOATING_TYPES, lsq_cpu.cpp:37,92,182,243).
@@ -84,6 +84,18 @@ typedef struct lsq_fwd_extras {
     int32_t aux_kind;
 } lsq_fwd_extras;
 
+/* Optional extra of the backward: a TICKET, LSQ_TICKET_BYTES of device memory owned by the caller that outlives the
+ * call.  With a ticket the backward is ONE launch: the workgroup that finishes last (an agent-scope atomic counter in
+ * the ticket tells it so) folds the per-workgroup partial sums -- in their fixed index order, so d_scale / d_shift stay
+ * bit-reproducible -- and stores d_scale / d_shift itself; without one (extras or ticket NULL) a second, tiny launch
+ * does that (2-4 us on a small tensor: half of the backward of a BASELINE-config-1-sized activation).
+ * Contract: all zero before its first use; every launch leaves it all zero again (the counters wrap), so it is reused
+ * as is; launches that may run CONCURRENTLY (different streams) must not share a ticket -- keep one per stream. */
+#define LSQ_TICKET_BYTES 4096
+typedef struct lsq_bwd_extras {
+    void* ticket;
+} lsq_bwd_extras;
+
 /* ---- library / build information -------------------------------------------------------- */
 
 /* LSQ_HIP_ABI_VERSION the library was built with. */
@@ -114,15 +126,15 @@ int lsq_hip_forward_per_tensor(int dtype, const void* x, void* y, int64_t n, con
                                const void* shift, const lsq_params* p, const lsq_fwd_extras* extras,
                                void* stream);
 
-/* dx, ds[1], db[1] from grad and x in ONE pass over HBM (+ a tiny finalize launch).
+/* dx, ds[1], db[1] from grad and x in ONE pass over HBM (+ a tiny finalize launch when no ticket is given).
  * Replaces lsq_backward_per_tensor_impl, lsq_cuda.cu:64-143 (three elementwise kernels, three
  * N-sized temporaries and two at::sum; CPU twin lsq_cpu.cpp:56-141).
  * dsdb_wide (optional, NULL ok): double[2] = {sum ds terms, sum db terms} before rounding to the
  * parameter type -- what the sharded path all-reduces. */
 int lsq_hip_backward_per_tensor(int dtype, const void* grad, const void* x, void* dx, void* ds,
                                 void* db, double* dsdb_wide, int64_t n, const void* scale,
-                                const void* shift, const lsq_params* p, void* workspace,
-                                size_t workspace_bytes, void* stream);
+                                const void* shift, const lsq_params* p, const lsq_bwd_extras* extras,
+                                void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- per-channel ------------------------------------------------------------------------ */
 
@@ -141,8 +153,8 @@ int lsq_hip_forward_per_channel(int dtype, const void* x, void* y, int64_t outer
 int lsq_hip_backward_per_channel(int dtype, const void* grad, const void* x, void* dx, void* ds,
                                  void* db, double* dsdb_wide, int64_t outer, int64_t channels,
                                  int64_t inner, const void* scale, const void* shift,
-                                 const lsq_params* p, void* workspace, size_t workspace_bytes,
-                                 void* stream);
+                                 const lsq_params* p, const lsq_bwd_extras* extras, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 
 /* ---- eval-mode backward from the saved mask ---------------------------------------------------- */
 

@@ -89,16 +89,19 @@ size_t lsq_hip_backward_per_channel_workspace(int dtype, int64_t outer, int64_t 
     if (!dtype_ok(dtype) || outer <= 0 || channels <= 0 || inner <= 0) return 256;
     // The size is the maximum over every launch geometry the tuning range allows (a few dozen candidate geometries).
     // Callers ask once per backward with the same few shapes: remember the last answers of this thread.
-    struct Memo { int dtype; int64_t outer, channels, inner; size_t bytes; };
+    // (The answer depends on the CU count of the current device, so the device ordinal is part of the key.)
+    struct Memo { int dtype, device; int64_t outer, channels, inner; size_t bytes; };
     constexpr int kMemo = 8;
     thread_local Memo memo[kMemo] = {};
     thread_local int next = 0;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
     for (int i = 0; i < kMemo; ++i)
-        if (memo[i].bytes && memo[i].dtype == dtype && memo[i].outer == outer && memo[i].channels == channels &&
-            memo[i].inner == inner)
+        if (memo[i].bytes && memo[i].dtype == dtype && memo[i].device == device && memo[i].outer == outer &&
+            memo[i].channels == channels && memo[i].inner == inner)
             return memo[i].bytes;
     const size_t bytes = lsq::bwd_pc_workspace_bytes(io_vec(dtype), outer, channels, inner);
-    memo[next] = Memo{dtype, outer, channels, inner, bytes};
+    memo[next] = Memo{dtype, device, outer, channels, inner, bytes};
     next = (next + 1) % kMemo;
     return bytes;
 }
@@ -123,8 +126,8 @@ int lsq_hip_forward_per_tensor(int dtype, const void* x, void* y, int64_t n, con
 
 int lsq_hip_backward_per_tensor_ex(int dtype, const void* grad, const void* x, void* dx, void* ds, void* db,
                                    double* dsdb_wide, int64_t n, const void* scale, const void* shift,
-                                   const lsq_params* p, void* workspace, size_t workspace_bytes, void* stream,
-                                   int variant) {
+                                   const lsq_params* p, const lsq_bwd_extras* extras, void* workspace,
+                                   size_t workspace_bytes, void* stream, int variant) {
     if (int rc = check_common(dtype, p)) return rc;
     if (n <= 0) return fail(LSQ_EINVAL, "backward_per_tensor: element count must be positive (the caller handles the "
                                         "empty case, reference lsq_cpu.cpp:76-78)");
@@ -133,16 +136,19 @@ int lsq_hip_backward_per_tensor_ex(int dtype, const void* grad, const void* x, v
         return fail(LSQ_EWORKSPACE, "backward_per_tensor: workspace of %zu bytes, need %zu", workspace_bytes,
                     lsq::bwd_pt_workspace_bytes());
     if (reinterpret_cast<uintptr_t>(workspace) & 15u) return fail(LSQ_EWORKSPACE, "workspace must be 16-byte aligned");
+    uint32_t* ticket = extras ? static_cast<uint32_t*>(extras->ticket) : nullptr;
+    if (reinterpret_cast<uintptr_t>(ticket) & 3u) return fail(LSQ_EINVAL, "ticket must be 4-byte aligned");
     hipError_t e = hipSuccess;
     LSQ_DISPATCH_IO(dtype, e = lsq::backward_per_tensor<IO>(grad, x, dx, ds, db, dsdb_wide, n, scale, shift, *p,
-                                                             workspace, variant, static_cast<hipStream_t>(stream)));
+                                                             workspace, ticket, variant, static_cast<hipStream_t>(stream)));
     return hip_status(e, "lsq_hip_backward_per_tensor");
 }
 
 int lsq_hip_backward_per_tensor(int dtype, const void* grad, const void* x, void* dx, void* ds, void* db,
                                 double* dsdb_wide, int64_t n, const void* scale, const void* shift,
-                                const lsq_params* p, void* workspace, size_t workspace_bytes, void* stream) {
-    return lsq_hip_backward_per_tensor_ex(dtype, grad, x, dx, ds, db, dsdb_wide, n, scale, shift, p, workspace,
+                                const lsq_params* p, const lsq_bwd_extras* extras, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    return lsq_hip_backward_per_tensor_ex(dtype, grad, x, dx, ds, db, dsdb_wide, n, scale, shift, p, extras, workspace,
                                           workspace_bytes, stream, 0);
 }
 
@@ -175,8 +181,9 @@ int lsq_hip_forward_per_channel(int dtype, const void* x, void* y, int64_t outer
 
 int lsq_hip_backward_per_channel_ex(int dtype, const void* grad, const void* x, void* dx, void* ds, void* db,
                                     double* dsdb_wide, int64_t outer, int64_t channels, int64_t inner,
-                                    const void* scale, const void* shift, const lsq_params* p, void* workspace,
-                                    size_t workspace_bytes, void* stream, int variant) {
+                                    const void* scale, const void* shift, const lsq_params* p,
+                                    const lsq_bwd_extras* extras, void* workspace, size_t workspace_bytes, void* stream,
+                                    int variant) {
     if (int rc = check_common(dtype, p)) return rc;
     if (int rc = check_ocl(outer, channels, inner)) return rc;
     if (outer == 0 || inner == 0)
@@ -184,9 +191,11 @@ int lsq_hip_backward_per_channel_ex(int dtype, const void* grad, const void* x, 
     if (!grad || !x || !dx || !ds || !db || !scale || !shift) return fail(LSQ_EINVAL, "backward_per_channel: NULL buffer");
     if (!workspace) return fail(LSQ_EWORKSPACE, "backward_per_channel: NULL workspace");
     if (reinterpret_cast<uintptr_t>(workspace) & 15u) return fail(LSQ_EWORKSPACE, "workspace must be 16-byte aligned");
+    uint32_t* ticket = extras ? static_cast<uint32_t*>(extras->ticket) : nullptr;
+    if (reinterpret_cast<uintptr_t>(ticket) & 3u) return fail(LSQ_EINVAL, "ticket must be 4-byte aligned");
     hipError_t e = hipSuccess;
     LSQ_DISPATCH_IO(dtype, e = lsq::backward_per_channel<IO>(grad, x, dx, ds, db, dsdb_wide, outer, channels, inner,
-                                                              scale, shift, *p, workspace, workspace_bytes, variant,
+                                                              scale, shift, *p, workspace, workspace_bytes, ticket, variant,
                                                               static_cast<hipStream_t>(stream)));
     if (e == hipErrorInvalidValue)
         return fail(LSQ_EWORKSPACE, "backward_per_channel: workspace of %zu bytes is too small (ask "
@@ -196,10 +205,10 @@ int lsq_hip_backward_per_channel_ex(int dtype, const void* grad, const void* x, 
 
 int lsq_hip_backward_per_channel(int dtype, const void* grad, const void* x, void* dx, void* ds, void* db,
                                  double* dsdb_wide, int64_t outer, int64_t channels, int64_t inner,
-                                 const void* scale, const void* shift, const lsq_params* p, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
+                                 const void* scale, const void* shift, const lsq_params* p,
+                                 const lsq_bwd_extras* extras, void* workspace, size_t workspace_bytes, void* stream) {
     return lsq_hip_backward_per_channel_ex(dtype, grad, x, dx, ds, db, dsdb_wide, outer, channels, inner, scale, shift,
-                                           p, workspace, workspace_bytes, stream, 0);
+                                           p, extras, workspace, workspace_bytes, stream, 0);
 }
 
 int lsq_hip_backward_from_mask(int dtype, const void* grad, const void* mask, void* dx, int64_t n, void* stream) {

@@ -13,15 +13,16 @@ int lsq_hip_forward_per_tensor_ex(int dtype, const void* x, void* y, int64_t n, 
                                   const lsq_params* p, const lsq_fwd_extras* extras, void* stream, int variant);
 int lsq_hip_backward_per_tensor_ex(int dtype, const void* grad, const void* x, void* dx, void* ds, void* db,
                                    double* dsdb_wide, int64_t n, const void* scale, const void* shift,
-                                   const lsq_params* p, void* workspace, size_t workspace_bytes, void* stream,
-                                   int variant);
+                                   const lsq_params* p, const lsq_bwd_extras* extras, void* workspace,
+                                   size_t workspace_bytes, void* stream, int variant);
 int lsq_hip_forward_per_channel_ex(int dtype, const void* x, void* y, int64_t outer, int64_t channels, int64_t inner,
                                    const void* scale, const void* shift, const lsq_params* p,
                                    const lsq_fwd_extras* extras, void* stream, int variant);
 int lsq_hip_backward_per_channel_ex(int dtype, const void* grad, const void* x, void* dx, void* ds, void* db,
                                     double* dsdb_wide, int64_t outer, int64_t channels, int64_t inner,
-                                    const void* scale, const void* shift, const lsq_params* p, void* workspace,
-                                    size_t workspace_bytes, void* stream, int variant);
+                                    const void* scale, const void* shift, const lsq_params* p,
+                                    const lsq_bwd_extras* extras, void* workspace, size_t workspace_bytes, void* stream,
+                                    int variant);
 /* tuning only: override the workgroups-per-CU of the observer-statistics kernels (0 = defaults) */
 void lsq_hip_debug_set_observe_wg_per_cu(int v);
 #ifdef __cplusplus

@@ -184,6 +184,29 @@ struct LevelPack {
     }
 };
 
+// ---- last-workgroup ticket (lsq_bwd_extras.ticket) ------------------------------------------------
+// "The workgroup that finishes last folds the partial sums": ONE lane per workgroup calls this after its partial
+// stores.  Producer side = agent-scope release fence + drained stores, then an agent-scope atomic increment that WRAPS to
+// zero at the `expected`-th arrival (global_atomic_inc), so the counter is back at zero when the launch ends and the
+// ticket needs no re-initialisation.  Returns true for the last arrival, after an agent-scope acquire fence; the caller
+// then broadcasts that through LDS + __syncthreads() and reads the other workgroups' partials with agent-scope loads
+// (per-CU L1 and per-XCD L2 are not coherent: cdna_hip_programming.md section 6, guideline 16).
+__device__ __forceinline__ bool ticket_arrive_is_last(uint32_t* counter, uint32_t expected) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t prev = atomicInc(counter, expected - 1u);   // old >= expected - 1 ? 0 : old + 1
+    const bool last = prev == expected - 1u;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return last;
+}
+// another workgroup's partial, read past the non-coherent caches
+__device__ __forceinline__ double2 load_partial_agent(const double2* p) {
+    double2 v;
+    v.x = __hip_atomic_load(&p->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.y = __hip_atomic_load(&p->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+
 // ---- entry points implemented in lsq_per_tensor.hip / lsq_per_channel.hip ------------------------
 size_t bwd_pt_workspace_bytes();
 size_t bwd_pc_workspace_bytes(int elem_bytes, int64_t outer, int64_t channels, int64_t inner);
@@ -194,7 +217,7 @@ hipError_t forward_per_tensor(const void* x, void* y, int64_t n, const void* sca
 template <typename IO>
 hipError_t backward_per_tensor(const void* grad, const void* x, void* dx, void* ds, void* db, double* wide,
                                int64_t n, const void* scale, const void* shift, const lsq_params& p,
-                               void* workspace, int variant, hipStream_t stream);
+                               void* workspace, uint32_t* ticket, int variant, hipStream_t stream);
 template <typename IO>
 hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t channels, int64_t inner,
                                const void* scale, const void* shift, const lsq_params& p,
@@ -203,7 +226,7 @@ template <typename IO>
 hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void* ds, void* db, double* wide,
                                 int64_t outer, int64_t channels, int64_t inner, const void* scale,
                                 const void* shift, const lsq_params& p, void* workspace, size_t workspace_bytes,
-                                int variant, hipStream_t stream);
+                                uint32_t* ticket, int variant, hipStream_t stream);
 
 template <typename IO>
 hipError_t backward_from_mask(const void* grad, const void* mask, void* dx, int64_t n, hipStream_t stream);

@@ -879,8 +879,9 @@ template <typename IO>
 hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void* ds, void* db, double* wide,
                                 int64_t outer, int64_t channels, int64_t inner, const void* scale,
                                 const void* shift, const lsq_params& p, void* workspace, size_t workspace_bytes,
-                                int variant, hipStream_t stream) {
+                                uint32_t* ticket, int variant, hipStream_t stream) {
     using T = typename IO::arith;
+    (void)ticket;
     const DeviceInfo& dev = device_info();
     const bool aligned = is_aligned16(grad) && is_aligned16(x) && is_aligned16(dx);
     const int vec = pick_vec(IO::VEC, channels * inner, aligned);
@@ -940,7 +941,7 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
                                                 hipStream_t);                                                        \
     template hipError_t backward_per_channel<IO>(const void*, const void*, void*, void*, void*, double*, int64_t,    \
                                                  int64_t, int64_t, const void*, const void*, const lsq_params&,      \
-                                                 void*, size_t, int, hipStream_t);
+                                                 void*, size_t, uint32_t*, int, hipStream_t);
 LSQ_INSTANTIATE(io_f32)
 LSQ_INSTANTIATE(io_f64)
 LSQ_INSTANTIATE(io_bf16)

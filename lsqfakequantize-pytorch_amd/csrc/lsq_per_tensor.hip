@@ -16,8 +16,10 @@
 //    the reference's ds_buffer/db_buffer values; summing them in fp64 keeps the result within a
 //    few 1e-8 of the exact sum, inside the 1e-6 parity budget that the reference's own fp32
 //    at::sum eats most of) -> wave64 butterfly (DPP/ds_bpermute shuffles) -> 4 partials through LDS
-//    -> one 16-byte partial per workgroup in the workspace -> fixed-order finalize.  No atomics:
-//    the result is bit-deterministic for a given size.
+//    -> one 16-byte partial per workgroup in the workspace -> fixed-order fold.  The fold is done by the workgroup
+//    that finishes last (a wrapping agent-scope arrival counter in the caller's ticket, lsq_bwd_extras) or, without
+//    a ticket, by a one-workgroup finalize launch; either way the partials are added in index order, so
+//    the result is bit-deterministic for a given size (the only atomic is the arrival counter).
 #include "lsq_kernels.hpp"
 
 namespace lsq {
@@ -140,9 +142,59 @@ struct BwdAcc {
     }
 };
 
-// workgroup reduction of (s, b): wave64 butterfly, then the 4 wave totals through LDS
-__device__ __forceinline__ void block_reduce_store(double s, double b, double2* __restrict__ partials) {
+// Where d_scale / d_shift go when the kernel finishes them itself (ticket != nullptr), see fold_partials.
+template <typename T>
+struct PtFold {
+    uint32_t* ticket;   // nullptr: leave the partials to finalize_pt_kernel
+    T* ds;
+    T* db;
+    double* wide;
+    T sym_term;         // the constant per-element d_shift term of the symmetric case, 0 * grad_scaler (lsq_kernel.h:118,122)
+    int sym;
+};
+
+// Fold the per-workgroup partials in a FIXED order (lane-strided, wave64 butterfly, the 4 wave totals in order) and
+// round once to the parameter type: the reference's `ds_buffer.sum().unsqueeze(0)`, lsq_cpu.cpp:138-139.  One
+// workgroup; shared by the last-arriving workgroup of the backward kernel (AGENT = true: the partials were written by
+// other workgroups of the same launch) and by finalize_pt_kernel, so both routes give the same bits.
+template <typename T, bool AGENT>
+__device__ __forceinline__ void fold_partials(const double2* partials, int n_partials, bool eval_mode, const PtFold<T>& f,
+                                              double2* wave_tot) {
+    double s = 0.0, b = 0.0;
+    if (!eval_mode) {
+        for (int i = threadIdx.x; i < n_partials; i += kBlock) {
+            const double2 v = AGENT ? load_partial_agent(partials + i) : partials[i];
+            s += v.x;
+            b += v.y;
+        }
+    }
+    s = wave_sum(s);
+    b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = make_double2(s, b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ts = 0.0, tb = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) {
+            ts += wave_tot[w].x;
+            tb += wave_tot[w].y;
+        }
+        if (!eval_mode && f.sym) tb = 0.0 + static_cast<double>(f.sym_term);  // sum of N copies of (0*gs): +0, or NaN
+        f.ds[0] = static_cast<T>(ts);
+        f.db[0] = static_cast<T>(tb);
+        if (f.wide) {
+            f.wide[0] = ts;
+            f.wide[1] = tb;
+        }
+    }
+}
+
+// workgroup reduction of (s, b): wave64 butterfly, then the 4 wave totals through LDS -> this workgroup's partial.
+// With a ticket, the workgroup that arrives last folds all partials and stores d_scale / d_shift.
+template <typename T>
+__device__ __forceinline__ void block_reduce_store(double s, double b, double2* __restrict__ partials, const PtFold<T>& f) {
     __shared__ double2 wave_tot[kBlock / 64];
+    __shared__ int is_last;
     s = wave_sum(s);
     b = wave_sum(b);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -156,6 +208,24 @@ __device__ __forceinline__ void block_reduce_store(double s, double b, double2* 
             tb += wave_tot[w].y;
         }
         partials[blockIdx.x] = make_double2(ts, tb);
+        if (f.ticket) is_last = ticket_arrive_is_last(f.ticket, gridDim.x) ? 1 : 0;
+    }
+    if (!f.ticket) return;
+    __syncthreads();
+    if (!is_last) return;
+    fold_partials<T, true>(partials, static_cast<int>(gridDim.x), false, f, wave_tot);
+}
+
+// eval mode with a ticket: nothing to reduce, d_scale = d_shift = 0 (lsq_kernel.h:142-144)
+template <typename T>
+__device__ __forceinline__ void eval_store_zero(const PtFold<T>& f) {
+    if (f.ticket && blockIdx.x == 0 && threadIdx.x == 0) {
+        f.ds[0] = static_cast<T>(0);
+        f.db[0] = static_cast<T>(0);
+        if (f.wide) {
+            f.wide[0] = 0.0;
+            f.wide[1] = 0.0;
+        }
     }
 }
 
@@ -165,7 +235,8 @@ __global__ __launch_bounds__(kBlock) void bwd_pt_kernel(const void* __restrict__
                                                         const typename IO::arith* __restrict__ scale,
                                                         const typename IO::arith* __restrict__ shift,
                                                         Range<typename IO::arith> r, typename IO::arith grad_scaler,
-                                                        double2* __restrict__ partials, int chunked) {
+                                                        double2* __restrict__ partials, PtFold<typename IO::arith> fold,
+                                                        int chunked) {
     using T = typename IO::arith;
     constexpr int VEC = IO::VEC;
     const QParams<T> q = make_qparams<T>(sanitize_scale_per_tensor<T>(scale[0]), shift[0], r);  // lsq_cpu.cpp:99-102
@@ -209,7 +280,8 @@ __global__ __launch_bounds__(kBlock) void bwd_pt_kernel(const void* __restrict__
         const int64_t i = n_packets * VEC + threadIdx.x;
         if (i < n) IO::store1(dx, i, acc.step(IO::load1(grad, i), IO::load1(x, i), q, r, grad_scaler));
     }
-    if (!EVAL) block_reduce_store(acc.s, acc.b, partials);
+    if (EVAL) eval_store_zero<T>(fold);
+    else block_reduce_store<T>(acc.s, acc.b, partials, fold);
 }
 
 template <typename IO, bool SYM, bool INIT, bool EVAL>
@@ -219,52 +291,25 @@ __global__ __launch_bounds__(kBlock) void bwd_pt_scalar_kernel(const void* __res
                                                                const typename IO::arith* __restrict__ shift,
                                                                Range<typename IO::arith> r,
                                                                typename IO::arith grad_scaler,
-                                                               double2* __restrict__ partials) {
+                                                               double2* __restrict__ partials,
+                                                               PtFold<typename IO::arith> fold) {
     using T = typename IO::arith;
     const QParams<T> q = make_qparams<T>(sanitize_scale_per_tensor<T>(scale[0]), shift[0], r);
     BwdAcc<T, SYM, INIT, EVAL> acc;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * kBlock)
         IO::store1(dx, i, acc.step(IO::load1(grad, i), IO::load1(x, i), q, r, grad_scaler));
-    if (!EVAL) block_reduce_store(acc.s, acc.b, partials);
+    if (EVAL) eval_store_zero<T>(fold);
+    else block_reduce_store<T>(acc.s, acc.b, partials, fold);
 }
 
-// Finalize: ONE workgroup folds the per-workgroup partials in a fixed order and rounds once to the
-// parameter type (the reference's `ds_buffer.sum().unsqueeze(0)`, lsq_cpu.cpp:138-139).
-// mode: 0 = train, 1 = eval (ds = db = 0, lsq_kernel.h:142-144).  `sym_term` is the constant
-// per-element d_shift term of the symmetric case, 0 * grad_scaler (lsq_kernel.h:118,122).
+// Finalize (the route without a ticket): ONE workgroup folds the per-workgroup partials, see fold_partials.
+// eval_mode: ds = db = 0 (lsq_kernel.h:142-144).
 template <typename T>
 __global__ __launch_bounds__(kBlock) void finalize_pt_kernel(const double2* __restrict__ partials, int n_partials,
-                                                             int eval_mode, int sym, T sym_term, T* __restrict__ ds,
-                                                             T* __restrict__ db, double* __restrict__ wide) {
+                                                             int eval_mode, PtFold<T> f) {
     __shared__ double2 wave_tot[kBlock / 64];
-    double s = 0.0, b = 0.0;
-    if (!eval_mode) {
-        for (int i = threadIdx.x; i < n_partials; i += kBlock) {
-            const double2 v = partials[i];
-            s += v.x;
-            b += v.y;
-        }
-    }
-    s = wave_sum(s);
-    b = wave_sum(b);
-    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = make_double2(s, b);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double ts = 0.0, tb = 0.0;
-#pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) {
-            ts += wave_tot[w].x;
-            tb += wave_tot[w].y;
-        }
-        if (!eval_mode && sym) tb = 0.0 + static_cast<double>(sym_term);  // sum of N copies of (0*gs): +0, or NaN
-        ds[0] = static_cast<T>(ts);
-        db[0] = static_cast<T>(tb);
-        if (wide) {
-            wide[0] = ts;
-            wide[1] = tb;
-        }
-    }
+    fold_partials<T, false>(partials, n_partials, eval_mode != 0, f, wave_tot);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -336,7 +381,7 @@ size_t bwd_pt_workspace_bytes() {
 template <typename IO, bool SYM, bool INIT, bool EVAL>
 static hipError_t launch_bwd_pt(const void* grad, const void* x, void* dx, void* ds, void* db, double* wide,
                                 int64_t n, const void* scale, const void* shift, const lsq_params& p,
-                                void* workspace, int variant, hipStream_t stream) {
+                                void* workspace, uint32_t* ticket, int variant, hipStream_t stream) {
     using T = typename IO::arith;
     const Range<T> r = make_range<T>(p);
     const T* sc = static_cast<const T*>(scale);
@@ -347,31 +392,31 @@ static hipError_t launch_bwd_pt(const void* grad, const void* x, void* dx, void*
     const bool aligned = is_aligned16(grad) && is_aligned16(x) && is_aligned16(dx);
     const Variant v = decode_variant(variant, kDefaultBwdVariant);
     const int grid = bwd_pt_grid(n, IO::VEC, v, aligned);
+    const T sym_term = static_cast<T>(0) * gs;
+    const PtFold<T> fold{ticket, static_cast<T*>(ds), static_cast<T*>(db), wide, sym_term, SYM ? 1 : 0};
     if (!aligned) {
         hipLaunchKernelGGL((bwd_pt_scalar_kernel<IO, SYM, INIT, EVAL>), dim3(grid), dim3(kBlock), 0, stream, grad, x,
-                           dx, n, sc, sh, r, gs, partials);
+                           dx, n, sc, sh, r, gs, partials, fold);
     } else {
 #define LSQ_LAUNCH_BWD(U, NTLF, NTSF)                                                                                    \
     hipLaunchKernelGGL((bwd_pt_kernel<IO, SYM, INIT, EVAL, U, NTLF, NTSF>), dim3(grid), dim3(kBlock), 0, stream, grad, x, dx, \
-                       n, sc, sh, r, gs, partials, v.chunked ? 1 : 0)
+                       n, sc, sh, r, gs, partials, fold, v.chunked ? 1 : 0)
         [[maybe_unused]] constexpr bool kFull = std::is_same<IO, io_f32>::value && !SYM && !INIT && !EVAL;
         LSQ_DISPATCH_VARIANT(kFull, 4, v, LSQ_LAUNCH_BWD);
 #undef LSQ_LAUNCH_BWD
     }
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    const T sym_term = static_cast<T>(0) * gs;
-    hipLaunchKernelGGL((finalize_pt_kernel<T>), dim3(1), dim3(kBlock), 0, stream, partials, grid, EVAL ? 1 : 0,
-                       SYM ? 1 : 0, sym_term, static_cast<T*>(ds), static_cast<T*>(db), wide);
+    if (e != hipSuccess || ticket) return e;   // with a ticket the last workgroup has stored d_scale / d_shift
+    hipLaunchKernelGGL((finalize_pt_kernel<T>), dim3(1), dim3(kBlock), 0, stream, partials, grid, EVAL ? 1 : 0, fold);
     return hipGetLastError();
 }
 
 template <typename IO>
 hipError_t backward_per_tensor(const void* grad, const void* x, void* dx, void* ds, void* db, double* wide,
                                int64_t n, const void* scale, const void* shift, const lsq_params& p,
-                               void* workspace, int variant, hipStream_t stream) {
+                               void* workspace, uint32_t* ticket, int variant, hipStream_t stream) {
 #define LSQ_BWD_CASE(S, I, E) \
-    return launch_bwd_pt<IO, S, I, E>(grad, x, dx, ds, db, wide, n, scale, shift, p, workspace, variant, stream)
+    return launch_bwd_pt<IO, S, I, E>(grad, x, dx, ds, db, wide, n, scale, shift, p, workspace, ticket, variant, stream)
     const bool sym = p.sym != 0, init = p.init_mode != 0;
     if (p.eval_mode) {
         if (init) LSQ_BWD_CASE(false, true, true);
@@ -448,7 +493,7 @@ hipError_t backward_from_mask(const void* grad, const void* mask, void* dx, int6
     template hipError_t forward_per_tensor<IO>(const void*, void*, int64_t, const void*, const void*,              \
                                                const lsq_params&, const lsq_fwd_extras*, int, hipStream_t);        \
     template hipError_t backward_per_tensor<IO>(const void*, const void*, void*, void*, void*, double*, int64_t,   \
-                                                const void*, const void*, const lsq_params&, void*, int, hipStream_t); \
+                                                const void*, const void*, const lsq_params&, void*, uint32_t*, int, hipStream_t); \
     template hipError_t backward_from_mask<IO>(const void*, const void*, void*, int64_t, hipStream_t);
 LSQ_INSTANTIATE(io_f32)
 LSQ_INSTANTIATE(io_f64)

@@ -21,8 +21,12 @@
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
 
+#include <hip/hip_runtime_api.h>
+
 #include <array>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <tuple>
 #include <vector>
 
@@ -148,6 +152,42 @@ Tensor byte_workspace(const Tensor& like, size_t nbytes) {
     return at::empty({static_cast<int64_t>(nbytes < 256 ? 256 : nbytes)}, like.options().dtype(at::kByte));
 }
 
+// ---- tickets (lsq_bwd_extras): persistent per-stream arrival counters that make the backward ONE launch ----
+// The C ABI wants LSQ_TICKET_BYTES of zero-initialised device memory that outlives the call and is never shared by
+// launches that can run concurrently.  One slab of kTicketSlots tickets per device is allocated (and zeroed) at the
+// first eager backward on that device; streams get a slot each on first use (host bookkeeping only, so a stream first
+// seen during graph capture still gets one as long as the slab exists; otherwise that call takes the two-launch route).
+constexpr int kTicketSlots = 64;
+struct TicketSlab {
+    Tensor storage;
+    char* base = nullptr;
+    int next = 0;
+};
+std::mutex g_ticket_mutex;
+std::map<int, TicketSlab> g_ticket_slabs;                    // device index -> slab
+std::map<std::pair<int, void*>, void*> g_tickets;            // (device index, stream) -> ticket
+
+void* ticket_for(const Tensor& x, void* stream) {
+    const int dev = x.device().index();
+    std::lock_guard<std::mutex> lock(g_ticket_mutex);
+    const auto key = std::make_pair(dev, stream);
+    const auto hit = g_tickets.find(key);
+    if (hit != g_tickets.end()) return hit->second;
+    TicketSlab& slab = g_ticket_slabs[dev];
+    if (!slab.base) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &st) != hipSuccess || st != hipStreamCaptureStatusNone)
+            return nullptr;                                   // no allocation inside a capture: two-launch route
+        slab.storage = at::zeros({kTicketSlots * LSQ_TICKET_BYTES / 4}, x.options().dtype(at::kInt));
+        c10::hip::getCurrentHIPStream(dev).synchronize();     // zeroed before any other stream may use a slot (one-off)
+        slab.base = static_cast<char*>(slab.storage.data_ptr());
+    }
+    if (slab.next >= kTicketSlots) return nullptr;            // more streams than slots: two-launch route for the rest
+    void* t = slab.base + static_cast<size_t>(slab.next++) * LSQ_TICKET_BYTES;
+    g_tickets.emplace(key, t);
+    return t;
+}
+
 // ---- the four kernels of the reference + the masked eval backward --------------------------------------
 
 std::tuple<Tensor, Tensor> forward_impl(const Tensor& x, const Tensor& scale, const Tensor& shift, bool per_channel,
@@ -209,6 +249,8 @@ BackwardOut backward_impl(const Tensor& grad, const Tensor& x, const Tensor& sca
     const int code = dtype_code(x.scalar_type(), "lsq_backward");
     const auto popt = x.options().dtype(param_type(x.scalar_type()));
     c10::DeviceGuard guard(x.device());
+    void* const stream = stream_of(x);
+    const lsq_bwd_extras extras{ticket_for(x, stream)};
     Tensor wide;
     if (per_channel) {
         const Geometry g = geometry(xd, axis);
@@ -217,8 +259,8 @@ BackwardOut backward_impl(const Tensor& grad, const Tensor& x, const Tensor& sca
         const Tensor ws = byte_workspace(x, lsq_hip_backward_per_channel_workspace(code, g.outer, g.channels, g.inner));
         status(lsq_hip_backward_per_channel(code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(), ds.data_ptr(), db.data_ptr(),
                                             want_wide ? wide.data_ptr<double>() : nullptr, g.outer, g.channels, g.inner,
-                                            sc.data_ptr(), sh.data_ptr(), &p, ws.data_ptr(), static_cast<size_t>(ws.numel()),
-                                            stream_of(x)),
+                                            sc.data_ptr(), sh.data_ptr(), &p, &extras, ws.data_ptr(),
+                                            static_cast<size_t>(ws.numel()), stream),
                "lsq_hip_backward_per_channel");
         return {dx, ds, db, wide};
     }
@@ -227,7 +269,7 @@ BackwardOut backward_impl(const Tensor& grad, const Tensor& x, const Tensor& sca
     const Tensor ws = byte_workspace(x, lsq_hip_backward_per_tensor_workspace(code, xd.numel()));
     status(lsq_hip_backward_per_tensor(code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(), ds.data_ptr(), db.data_ptr(),
                                        want_wide ? wide.data_ptr<double>() : nullptr, xd.numel(), sc.data_ptr(), sh.data_ptr(), &p,
-                                       ws.data_ptr(), static_cast<size_t>(ws.numel()), stream_of(x)),
+                                       &extras, ws.data_ptr(), static_cast<size_t>(ws.numel()), stream),
            "lsq_hip_backward_per_tensor");
     return {dx, ds, db, wide};
 }

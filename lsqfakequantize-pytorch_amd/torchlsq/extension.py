@@ -44,9 +44,18 @@ class LsqFwdExtras(ctypes.Structure):
     _fields_ = [("levels", ctypes.c_void_p), ("level_bias", ctypes.c_int32), ("aux_kind", ctypes.c_int32)]
 
 
+class LsqBwdExtras(ctypes.Structure):
+    """struct lsq_bwd_extras (include/lsq_hip.h)."""
+    _fields_ = [("ticket", ctypes.c_void_p)]
+
+
+LSQ_TICKET_BYTES = 4096
+ABI_VERSION = 2
+
 _vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
 _PP = ctypes.POINTER(LsqParams)
 _EP = ctypes.POINTER(LsqFwdExtras)
+_BP = ctypes.POINTER(LsqBwdExtras)
 
 # every symbol include/lsq_hip.h declares: (restype, argtypes)
 C_ABI = {
@@ -56,11 +65,11 @@ C_ABI = {
     "lsq_hip_grad_scaler": (ctypes.c_double, [_int, _int, _i64, ctypes.c_int32, _i64, ctypes.c_int32, ctypes.c_double]),
     "lsq_hip_backward_per_tensor_workspace": (_sz, [_int, _i64]),
     "lsq_hip_forward_per_tensor": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _PP, _EP, _vp]),
-    "lsq_hip_backward_per_tensor": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _PP, _vp, _sz, _vp]),
+    "lsq_hip_backward_per_tensor": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _PP, _BP, _vp, _sz, _vp]),
     "lsq_hip_backward_per_channel_workspace": (_sz, [_int, _i64, _i64, _i64]),
     "lsq_hip_forward_per_channel": (_int, [_int, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP, _EP, _vp]),
-    "lsq_hip_backward_per_channel": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP, _vp,
-                                            _sz, _vp]),
+    "lsq_hip_backward_per_channel": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP, _BP,
+                                            _vp, _sz, _vp]),
     "lsq_hip_backward_from_mask": (_int, [_int, _vp, _vp, _vp, _i64, _vp]),
     "lsq_hip_minmax_workspace": (_sz, [_int, _i64, _i64, _i64]),
     "lsq_hip_minmax_per_tensor": (_int, [_int, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
@@ -91,8 +100,8 @@ def _load_library():
             fn.restype = res
             fn.argtypes = args
     abi = lib.lsq_hip_abi_version()
-    if abi != 1:
-        raise ImportError("liblsq_hip.so has ABI version %d, this package needs 1" % abi)
+    if abi != ABI_VERSION:
+        raise ImportError("liblsq_hip.so has ABI version %d, this package needs %d" % (abi, ABI_VERSION))
     _LIB = lib
 
 
@@ -122,7 +131,7 @@ def _load_native_binding():
         return
     try:
         torch.ops.load_library(_NATIVE_PATH)
-        if int(torch.ops.torchlsq_native._abi_version()) != 1:
+        if int(torch.ops.torchlsq_native._abi_version()) != ABI_VERSION:
             raise OSError("_lsq_torch.so was built against another ABI version of liblsq_hip.so")
         _NATIVE_LSQ = torch.ops.torchlsq_native.lsq.default
     except (OSError, RuntimeError, AttributeError) as e:
@@ -387,6 +396,39 @@ def _workspace(device, nbytes):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+# ---- tickets (lsq_bwd_extras): persistent per-stream arrival counters that make the backward ONE launch -------------
+# The C ABI wants LSQ_TICKET_BYTES of zero-initialised device memory that outlives the call and is never shared by
+# launches that can run concurrently.  One slab of _TICKET_SLOTS tickets per device is allocated (and zeroed) at the
+# first eager backward on that device; streams get a slot each on first use (pure host bookkeeping, so a stream first
+# seen DURING graph capture still gets one -- as long as the slab exists; otherwise that call takes the two-launch
+# route).  Kernels of one stream are serialised by the stream, kernels captured from one stream by the graph.
+_TICKET_SLOTS = 64
+_TICKET_SLABS = {}     # device index -> (slab tensor, base pointer, [next free slot])
+_TICKETS = {}          # (device index, raw stream) -> byref(LsqBwdExtras)
+_TICKET_KEEP = []      # the structs behind the byrefs
+
+
+def _ticket(idx, stream):
+    key = (idx, stream)
+    hit = _TICKETS.get(key)
+    if hit is not None:
+        return hit
+    slab = _TICKET_SLABS.get(idx)
+    if slab is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None                                   # no allocation inside a capture: two-launch route
+        t = torch.zeros(_TICKET_SLOTS * LSQ_TICKET_BYTES // 4, dtype=torch.int32, device=torch.device("cuda", idx))
+        torch.cuda.current_stream(idx).synchronize()      # zeroed before any other stream may use a slot (one-off)
+        slab = _TICKET_SLABS[idx] = (t, t.data_ptr(), [0])
+    if slab[2][0] >= _TICKET_SLOTS:
+        return None                                       # more streams than slots: two-launch route for the rest
+    ex = LsqBwdExtras(slab[1] + slab[2][0] * LSQ_TICKET_BYTES)
+    slab[2][0] += 1
+    _TICKET_KEEP.append(ex)
+    hit = _TICKETS[key] = ctypes.byref(ex)
+    return hit
+
+
 def _require_gpu(what, *tensors):
     """Every tensor of a call lives on the GPU the kernel is launched on (the first tensor's): raw pointers of
     another device would only work by accident of peer access."""
@@ -436,7 +478,7 @@ def hip_forward_per_tensor(x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, 
 
 
 def hip_backward_per_tensor(grad, x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode,
-                            numel_for_scaler=0, want_wide=False, variant=0):
+                            numel_for_scaler=0, want_wide=False, variant=0, use_ticket=True):
     _assert_has_ops()
     check_backward_dtypes(grad, x, scale, shift)
     if x.numel() <= 0:  # lsq_cpu.cpp:76-78 returns (x, scale, shift) themselves
@@ -460,9 +502,11 @@ def hip_backward_per_tensor(grad, x, scale, shift, qmin, qmax, tmin, tmax, use_g
         _WS_BYTES_PT[0] = int(_LIB.lsq_hip_backward_per_tensor_workspace(code, xd.numel()))   # a constant
     ws = _workspace(dev, _WS_BYTES_PT[0])
     idx = dev.index
+    stream = _stream_of(idx)
     rc = _on_device(idx, _LIB.lsq_hip_backward_per_tensor_ex, code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(),
                     ds.data_ptr(), db.data_ptr(), wide.data_ptr() if want_wide else None, xd.numel(),
-                    scale_c.data_ptr(), shift_c.data_ptr(), pref, ws.data_ptr(), ws.numel(), _stream_of(idx), variant)
+                    scale_c.data_ptr(), shift_c.data_ptr(), pref, _ticket(idx, stream) if use_ticket else None,
+                    ws.data_ptr(), ws.numel(), stream, variant)
     if rc:
         _status(rc, "lsq_hip_backward_per_tensor")
     if want_wide:
@@ -524,7 +568,7 @@ _WS_BYTES_PC = {}
 
 
 def hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode,
-                             init_mode, numel_for_scaler=0, want_wide=False, variant=0):
+                             init_mode, numel_for_scaler=0, want_wide=False, variant=0, use_ticket=True):
     _assert_has_ops()
     check_backward_dtypes(grad, x, scale, shift)
     check_channel_args(x, scale, shift, axis, backward=True)
@@ -553,9 +597,11 @@ def hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax
         if len(_WS_BYTES_PC) < 4096:
             _WS_BYTES_PC[wkey] = nbytes
     ws = _workspace(dev, nbytes)
+    stream = _stream_of(idx)
     rc = _on_device(idx, _LIB.lsq_hip_backward_per_channel_ex, code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(),
                     ds.data_ptr(), db.data_ptr(), wide.data_ptr() if want_wide else None, outer, C, inner,
-                    scale_c.data_ptr(), shift_c.data_ptr(), pref, ws.data_ptr(), ws.numel(), _stream_of(idx), variant)
+                    scale_c.data_ptr(), shift_c.data_ptr(), pref, _ticket(idx, stream) if use_ticket else None,
+                    ws.data_ptr(), ws.numel(), stream, variant)
     if rc:
         _status(rc, "lsq_hip_backward_per_channel")
     if want_wide:

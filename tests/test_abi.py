@@ -36,7 +36,7 @@ def test_header_symbols_are_exported():
 def test_python_binding_table_matches_header():
     from torchlsq import extension as E
     assert sorted(E.C_ABI) == _declared()
-    assert E._HAS_OPS and E.library().lsq_hip_abi_version() == 1
+    assert E._HAS_OPS and E.library().lsq_hip_abi_version() == E.ABI_VERSION == 2
     assert E.library().lsq_hip_runtime_version() > 0
     import torch
     assert torch.ops.torchlsq._cuda_version() == E.library().lsq_hip_runtime_version()
@@ -77,8 +77,8 @@ def test_argument_validation_never_reaches_the_gpu():
     assert lib.lsq_hip_forward_per_tensor(0, None, None, 16, None, None, ctypes.byref(p), None, None) == -1   # NULL buffers
     assert b"NULL" in lib.lsq_hip_last_error()
     assert lib.lsq_hip_forward_per_tensor(0, None, None, 0, None, None, ctypes.byref(p), None, None) == 0     # empty: no-op
-    assert lib.lsq_hip_backward_per_tensor(0, None, None, None, None, None, None, 0, None, None, ctypes.byref(p), None, 0, None) == -1
-    assert lib.lsq_hip_backward_per_channel(0, None, None, None, None, None, None, 4, 0, 4, None, None, ctypes.byref(p), None, 0, None) == -1
+    assert lib.lsq_hip_backward_per_tensor(0, None, None, None, None, None, None, 0, None, None, ctypes.byref(p), None, None, 0, None) == -1
+    assert lib.lsq_hip_backward_per_channel(0, None, None, None, None, None, None, 4, 0, 4, None, None, ctypes.byref(p), None, None, 0, None) == -1
     assert lib.lsq_hip_forward_per_channel(0, None, None, 0, 8, 4, None, None, ctypes.byref(p), None, None) == 0
     assert lib.lsq_hip_backward_per_tensor_workspace(0, 1 << 20) >= 256 * 8 * 16
 
@@ -123,7 +123,7 @@ def test_cpp_torch_binding_uses_only_the_public_abi():
     assert ".hip_fatbin" not in sections and ".hipFatBinSegment" not in sections
     assert E.host_binding() == "native", E.native_error_str
     ns = torch.ops.torchlsq_native
-    assert int(ns._abi_version()) == 1
+    assert int(ns._abi_version()) == E.ABI_VERSION
     ref = torch.ops.torchlsq
     for op in ("lsq", "lsq_forward_per_tensor", "lsq_backward_per_tensor", "lsq_forward_per_channel", "lsq_backward_per_channel"):
         a = str(getattr(ns, op).default._schema).split("(", 1)[1]

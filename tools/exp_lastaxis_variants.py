@@ -48,7 +48,7 @@ for dt, code in ((torch.bfloat16, 2), (torch.float32, 0)):
                 def fwd(s):
                     assert lib.lsq_hip_forward_per_channel_ex(code, x.data_ptr(), y.data_ptr(), outer, C, 1, scale.data_ptr(), shift.data_ptr(), ctypes.byref(p), None, s, v) == 0
                 def bwd(s):
-                    assert lib.lsq_hip_backward_per_channel_ex(code, g.data_ptr(), x.data_ptr(), dx.data_ptr(), ds.data_ptr(), db.data_ptr(), None, outer, C, 1, scale.data_ptr(), shift.data_ptr(), ctypes.byref(p), ws.data_ptr(), ws.numel(), s, v) == 0
+                    assert lib.lsq_hip_backward_per_channel_ex(code, g.data_ptr(), x.data_ptr(), dx.data_ptr(), ds.data_ptr(), db.data_ptr(), None, outer, C, 1, scale.data_ptr(), shift.data_ptr(), ctypes.byref(p), None, ws.data_ptr(), ws.numel(), s, v) == 0
                 tf, tb = timeit(fwd), timeit(bwd)
                 v |= 1 << 10
                 tbp = timeit(bwd)

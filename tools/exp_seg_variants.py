@@ -51,7 +51,7 @@ for dt, code in ((torch.bfloat16, 2), (torch.float32, 0)):
                 def fwd(s):
                     assert lib.lsq_hip_forward_per_channel_ex(code, x.data_ptr(), y.data_ptr(), 1, C, inner, scale.data_ptr(), shift.data_ptr(), ctypes.byref(p), None, s, v) == 0
                 def bwd(s):
-                    assert lib.lsq_hip_backward_per_channel_ex(code, g.data_ptr(), x.data_ptr(), dx.data_ptr(), ds.data_ptr(), db.data_ptr(), None, 1, C, inner, scale.data_ptr(), shift.data_ptr(), ctypes.byref(p), ws.data_ptr(), ws.numel(), s, v) == 0
+                    assert lib.lsq_hip_backward_per_channel_ex(code, g.data_ptr(), x.data_ptr(), dx.data_ptr(), ds.data_ptr(), db.data_ptr(), None, 1, C, inner, scale.data_ptr(), shift.data_ptr(), ctypes.byref(p), None, ws.data_ptr(), ws.numel(), s, v) == 0
                 rows.append((unroll, bpc, round(timeit(fwd), 2), round(timeit(bwd), 2)))
         print(str(dt).replace("torch.", ""), shape, "fwd best:", sorted(rows, key=lambda r: r[2])[:3], "| bwd best:", sorted(rows, key=lambda r: r[3])[:3])
         print("    all (unroll, wg/CU, fwd_us, bwd_us):", rows)

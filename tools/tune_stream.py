@@ -78,8 +78,8 @@ def main():
 
     def bwd(v):
         rc = lib.lsq_hip_backward_per_tensor_ex(0, g.data_ptr(), x.data_ptr(), dx.data_ptr(), ds.data_ptr(), db.data_ptr(),
-                                                None, n, scale.data_ptr(), shift.data_ptr(), ctypes.byref(p), ws.data_ptr(),
-                                                ws.numel(), stream, v)
+                                                None, n, scale.data_ptr(), shift.data_ptr(), ctypes.byref(p), None,
+                                                ws.data_ptr(), ws.numel(), stream, v)
         assert rc == 0
 
     if a.calibrate:
