@@ -7,7 +7,10 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <mutex>
 #include <type_traits>
+#include <utility>
+#include <vector>
 
 #include "../../include/lsq_hip.h"
 #include "lsq_math.hpp"
@@ -111,6 +114,37 @@ inline const DeviceInfo& device_info() {
     return table[dev];
 }
 
+// Workgroups (kBlock threads = one wave64 per SIMD) of `kernel` that a CU holds at once, from the kernel's register
+// allocation: 512 VGPRs per SIMD lane, allocated in blocks of 8, at most 8 waves per SIMD.  0 = unknown.  (The HIP
+// occupancy API is one workgroup per CU too high for kernels with 81-112 SGPRs on this part, MI355X_MICROARCH.md, so the
+// count is derived from the register number instead.)  Immutable per kernel: cached after the first query.
+inline int resident_blocks_per_cu(const void* kernel) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, int>> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto& e : cache)
+        if (e.first == kernel) return e.second;
+    hipFuncAttributes attr;
+    int waves = 0;
+    if (hipFuncGetAttributes(&attr, kernel) == hipSuccess && attr.numRegs > 0) {
+        const int regs = (attr.numRegs + 7) & ~7;
+        waves = std::max(1, std::min(8, 512 / regs));
+    } else {
+        (void)hipGetLastError();
+    }
+    cache.emplace_back(kernel, waves);
+    return waves;
+}
+
+// what the last window-mode backward launch of this thread looked like (tools/ only: lsq_hip_debug_last_launch)
+struct LaunchNote {
+    int grid_x, grid_y, resident_per_cu, vgprs_hint;
+};
+inline LaunchNote& last_launch_note() {
+    thread_local LaunchNote note = {0, 0, 0, 0};
+    return note;
+}
+
 inline bool is_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <typename T>
@@ -185,19 +219,23 @@ struct LevelPack {
 };
 
 // ---- last-workgroup ticket (lsq_bwd_extras.ticket) ------------------------------------------------
-// "The workgroup that finishes last folds the partial sums": ONE lane per workgroup calls this after its partial
-// stores.  Producer side = agent-scope release fence + drained stores, then an agent-scope atomic increment that WRAPS to
-// zero at the `expected`-th arrival (global_atomic_inc), so the counter is back at zero when the launch ends and the
-// ticket needs no re-initialisation.  Returns true for the last arrival, after an agent-scope acquire fence; the caller
-// then broadcasts that through LDS + __syncthreads() and reads the other workgroups' partials with agent-scope loads
-// (per-CU L1 and per-XCD L2 are not coherent: cdna_hip_programming.md section 6, guideline 16).
+// "The workgroup that finishes last folds the partial sums."  Hand-off between workgroups of one launch, following
+// cdna_hip_programming.md section 6 guideline 16 (per-CU L1 and per-XCD L2 are not coherent with each other):
+//   producer: the partial is stored WRITE-THROUGH at agent scope (global_store ... sc1) by ONE lane, which then drains
+//             its stores (s_waitcnt vmcnt(0)) and bumps an agent-scope counter that WRAPS to zero at the `expected`-th
+//             arrival (global_atomic_inc) -- so the ticket is all zero again when the launch ends;
+//   consumer: the lane that saw the last arrival tells its workgroup through LDS + __syncthreads(), and the workgroup
+//             reads the partials with agent-scope loads (global_load ... sc1), which bypass the non-coherent caches.
+// No release / acquire FENCE: an agent-scope release writes the XCD's whole L2 back (buffer_wbl2 sc1) -- measured: +14 us
+// on a 53 us backward full of dirty dx lines (gpurun_out/r02b) -- and nothing but the 16-byte partial needs publishing.
+__device__ __forceinline__ void store_partial_agent(double2* p, double s, double b) {
+    __hip_atomic_store(&p->x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&p->y, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ bool ticket_arrive_is_last(uint32_t* counter, uint32_t expected) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this lane's write-through stores have completed
     const uint32_t prev = atomicInc(counter, expected - 1u);   // old >= expected - 1 ? 0 : old + 1
-    const bool last = prev == expected - 1u;
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return last;
+    return prev == expected - 1u;
 }
 // another workgroup's partial, read past the non-coherent caches
 __device__ __forceinline__ double2 load_partial_agent(const double2* p) {

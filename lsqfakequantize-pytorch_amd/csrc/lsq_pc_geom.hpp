@@ -59,7 +59,8 @@ struct PcGeom {
     int64_t outer, C, inner, L;
     int64_t wpos;            // positions per window (R == 1) or L (R > 1)
     int64_t n_windows;       // windows per row
-    int64_t rows_per_split;  // rows walked by one workgroup (multiple of R)
+    int64_t n_tiles;         // ceil(outer / R): row tiles, dealt out to the splits in balanced contiguous runs
+    int64_t rows_per_split;  // the most rows any workgroup walks (multiple of R)
     int32_t splits;          // workgroups along the row axis
     int32_t R;               // rows folded into one tile
     int32_t k_slots;         // channel slots per window (LDS table / partial row length)
@@ -70,7 +71,13 @@ struct PcGeom {
 // per_slot_rows: rows a workgroup should walk per (slot / lane-position) of per-workgroup overhead.  27 for the
 // kernels that write a 16-byte partial per slot (backward, statistics); the forward only rebuilds its channel
 // table per workgroup and passes 4.
-static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec, int target_blocks, int per_slot_rows = 27) {
+// resident_blocks: how many workgroups of THIS kernel the chip holds at once (CUs x the occupancy its registers allow),
+// 0 = unknown.  A kernel whose workgroups all take about the same time finishes in whole "rounds": 980 workgroups on a
+// chip that holds 768 take as long as 1536 would (the VALU-heavy 16-bit backward measured exactly that: two rounds of
+// ~19 us, the second three quarters empty).  With resident_blocks the split count is a multiple of what fits in one
+// round, floor(resident_blocks / n_windows), and the rows are dealt out evenly (RowWalk).
+static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec, int target_blocks, int per_slot_rows = 27,
+                               int resident_blocks = 0) {
     PcGeom g;
     g.outer = outer; g.C = C; g.inner = inner; g.L = C * inner; g.vec = vec;
     g.fits32 = (g.L + static_cast<int64_t>(kBlock) * vec) < 0x7fffffffLL ? 1 : 0;
@@ -86,17 +93,57 @@ static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec,
         g.n_windows = 1;
         g.k_slots = static_cast<int32_t>(C);
     }
+    g.n_tiles = (outer + g.R - 1) / g.R;
     // keep the partial-sum traffic (16 B per slot per workgroup) below ~5 % of the streamed bytes -- except for small
     // tensors (< 2 M elements), which are latency- not traffic-bound: there a workgroup takes as few rows as the grid
     // target allows ([128, 768]: 128 workgroups of one row instead of 7 walking 21 rows one group after the other)
     const bool small = outer * g.L < (int64_t{1} << 21);
-    const int64_t min_rows = small ? g.R : std::max<int64_t>(g.R, (per_slot_rows * static_cast<int64_t>(g.k_slots) + W - 1) / W * g.R);
-    int64_t want_splits = std::max<int64_t>(1, (target_blocks + g.n_windows - 1) / g.n_windows);
-    int64_t rows = (outer + want_splits - 1) / want_splits;
-    rows = std::max<int64_t>(rows, min_rows);
-    rows = (rows + g.R - 1) / g.R * g.R;
-    g.rows_per_split = rows;
-    g.splits = static_cast<int32_t>((outer + rows - 1) / rows);
+    const int64_t min_tiles = small ? 1 : std::max<int64_t>(1, (per_slot_rows * static_cast<int64_t>(g.k_slots) + W - 1) / W);
+    const int64_t max_splits = std::max<int64_t>(1, g.n_tiles / min_tiles);       // every split gets >= min_tiles tiles
+    int64_t splits = std::max<int64_t>(1, (target_blocks + g.n_windows - 1) / g.n_windows);
+    splits = std::min(splits, max_splits);
+    const int64_t per_round = resident_blocks > 0 ? resident_blocks / g.n_windows : 0;
+    if (per_round >= 1 && splits >= per_round) {
+        // whole rounds: the nearest multiple of per_round that the row count allows (at least one round)
+        int64_t k = std::max<int64_t>(1, (splits + per_round / 2) / per_round);
+        while (k > 1 && k * per_round > max_splits) --k;
+        if (k * per_round <= max_splits) splits = k * per_round;
+    }
+    splits = std::min<int64_t>(splits, 65535);
+    g.splits = static_cast<int32_t>(splits);
+    g.rows_per_split = (g.n_tiles + splits - 1) / splits * g.R;
+    return g;
+}
+
+// WAVE-WIDE windows for the case "the quantized axis is the last one" (inner == 1, position == channel): a window is
+// 64 lanes x V channels -- ONE wave wide -- and the four waves of a workgroup take four different rows of it (the row
+// tile is R = 4 rows: wave w owns row w of every tile), so a workgroup still has four wave64 streams in flight but only
+// 64 x V partial slots to flush, a quarter of the 256-lane window's.  ([8192, 4096] bf16: 768 workgroups write 6 MB of
+// partials instead of 25 MB.)  The lane's V channels are its own: their constants live in registers, there is no LDS
+// table, and the epilogue is a fixed-order sum of the four waves through LDS.
+static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_blocks, int min_rows, int resident_blocks) {
+    PcGeom g;
+    g.outer = outer; g.C = C; g.inner = 1; g.L = C; g.vec = vec;
+    g.fits32 = (g.L + static_cast<int64_t>(kBlock) * vec) < 0x7fffffffLL ? 1 : 0;
+    g.R = kBlock / 64;
+    g.wpos = 64 * static_cast<int64_t>(vec);
+    g.n_windows = (g.L + g.wpos - 1) / g.wpos;
+    g.k_slots = static_cast<int32_t>(g.wpos);
+    g.n_tiles = (outer + g.R - 1) / g.R;
+    const bool small = outer * g.L < (int64_t{1} << 21);
+    const int64_t min_tiles = small ? 1 : std::max<int64_t>(1, (min_rows + g.R - 1) / g.R);
+    const int64_t max_splits = std::max<int64_t>(1, g.n_tiles / min_tiles);
+    int64_t splits = std::max<int64_t>(1, (target_blocks + g.n_windows - 1) / g.n_windows);
+    splits = std::min(splits, max_splits);
+    const int64_t per_round = resident_blocks > 0 ? resident_blocks / g.n_windows : 0;
+    if (per_round >= 1 && splits >= per_round) {
+        int64_t k = std::max<int64_t>(1, (splits + per_round / 2) / per_round);
+        while (k > 1 && k * per_round > max_splits) --k;
+        if (k * per_round <= max_splits) splits = k * per_round;
+    }
+    splits = std::min<int64_t>(splits, 65535);
+    g.splits = static_cast<int32_t>(splits);
+    g.rows_per_split = (g.n_tiles + splits - 1) / splits * g.R;
     return g;
 }
 
@@ -126,12 +173,26 @@ __device__ __forceinline__ LaneSite lane_site(const PcGeom& g, int V) {
     return s;
 }
 
+__device__ __forceinline__ LaneSite lane_site_ww(const PcGeom& g, int V) {
+    LaneSite s;
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * g.wpos;
+    s.p0 = base + static_cast<int64_t>(threadIdx.x & 63) * V;
+    s.row_in_tile = static_cast<int32_t>(threadIdx.x >> 6);
+    s.live = s.p0 < g.L;
+    s.c_lo = base;     // inner == 1: position == channel
+    return s;
+}
+
 // The rows a lane walks: o_begin, o_begin + step, ... (n_rows of them)
 struct RowWalk {
     int64_t o_begin, step, n_rows;
     __device__ __forceinline__ RowWalk(const PcGeom& g, const LaneSite& site) {
-        o_begin = static_cast<int64_t>(blockIdx.y) * g.rows_per_split + site.row_in_tile;
-        const int64_t o_end = std::min<int64_t>(g.outer, static_cast<int64_t>(blockIdx.y + 1) * g.rows_per_split);
+        // split y of `splits` owns the row tiles [y * n_tiles / splits, (y + 1) * n_tiles / splits): sizes differ by at
+        // most one tile (a uniform ceil(n / splits) leaves the last workgroup a short remainder and the rest too much)
+        const int64_t t0 = static_cast<int64_t>(blockIdx.y) * g.n_tiles / g.splits;
+        const int64_t t1 = static_cast<int64_t>(blockIdx.y + 1) * g.n_tiles / g.splits;
+        o_begin = t0 * g.R + site.row_in_tile;
+        const int64_t o_end = std::min<int64_t>(g.outer, t1 * g.R);
         step = g.R;
         n_rows = (site.live && o_begin < o_end) ? (o_end - o_begin + step - 1) / step : 0;
     }
@@ -189,6 +250,6 @@ static inline bool pick_segment_mode(int vec, int64_t outer, int64_t C, int64_t 
 
 static inline bool grid_fits(const SegGeom& g) { return g.C * g.segs <= 0x7fffffffLL && g.osplits <= 65535; }
 static inline int pick_vec(int io_vec, int64_t L, bool aligned) { return (aligned && (L % io_vec) == 0) ? io_vec : 1; }
-static inline bool grid_fits(const PcGeom& g) { return g.n_windows <= 0x7fffffffLL && g.splits <= 65535; }
+static inline bool grid_fits(const PcGeom& g) { return g.n_windows <= 0x7fffffffLL && g.splits <= 65535 && g.splits >= 1; }
 
 }  // namespace lsq

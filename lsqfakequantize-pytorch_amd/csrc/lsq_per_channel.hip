@@ -208,7 +208,9 @@ __device__ __forceinline__ void segmented_wave_accumulate(int key, double s, dou
     }
 }
 
-template <typename IO, int V, int CPL, bool SYM, bool INIT, bool EVAL, int UNROLL, bool NTL, bool NTS, bool PIPE>
+// WW: wave-wide windows (make_geom_ww: inner == 1, CPL == V) -- the lane's channels are its own, their constants are
+// computed from global memory into registers (no LDS table) and the epilogue sums the four waves in a fixed order.
+template <typename IO, int V, int CPL, bool SYM, bool INIT, bool EVAL, int UNROLL, bool NTL, bool NTS, bool PIPE, bool WW = false>
 __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__ grad, const void* __restrict__ x,
                                                         void* __restrict__ dx, PcGeom g,
                                                         const typename IO::arith* __restrict__ scale,
@@ -219,11 +221,12 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
     using E = typename IO::elem;
     using LC = LaneChannels<T, V, CPL>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    static_assert(!WW || (CPL == V && V > 1), "wave-wide windows: one channel per packet component");
     QSlot<T>* table = reinterpret_cast<QSlot<T>*>(smem);
     double* lds_s = reinterpret_cast<double*>(smem + static_cast<size_t>(g.k_slots) * sizeof(QSlot<T>));
     double* lds_b = lds_s + g.k_slots;
 
-    const LaneSite site = lane_site(g, V);
+    const LaneSite site = WW ? lane_site_ww(g, V) : lane_site(g, V);
     const RowWalk walk(g, site);
     // A group = UNROLL rows.  load_group never predicates: rows past the lane's last one re-read the last row.
     auto load_group = [&](E (&gb)[UNROLL][V], E (&xb)[UNROLL][V], int64_t i0) {
@@ -238,16 +241,27 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
     E first_g[UNROLL][V], first_x[UNROLL][V];   // first group in flight before the table build (see K3)
     const bool first_full = PIPE ? walk.n_rows > 0 : walk.n_rows >= UNROLL;
     if (first_full) load_group(first_g, first_x, 0);
-    build_channel_table<T>(table, g.k_slots, site.c_lo, g.C, scale, shift, r);
-    if (!EVAL) {
-        for (int k = threadIdx.x; k < g.k_slots; k += kBlock) {
-            lds_s[k] = 0.0;
-            lds_b[k] = 0.0;
-        }
-    }
-    __syncthreads();
     LC ch;
-    ch.init(table, site, g);
+    if constexpr (WW) {
+        // channel p0 + j is component j's own: constants straight into registers (lsq_kernel.h:157-158 + :12)
+        ch.split = V;
+#pragma unroll
+        for (int j = 0; j < LC::N; ++j) {
+            const int64_t c = site.live ? site.p0 + j : 0;
+            ch.q[j] = make_qparams<T>(sanitize_scale_per_channel<T>(scale[c]), shift[c], r);
+            ch.key[j] = j * 64 + static_cast<int32_t>(threadIdx.x & 63);
+        }
+    } else {
+        build_channel_table<T>(table, g.k_slots, site.c_lo, g.C, scale, shift, r);
+        if (!EVAL) {
+            for (int k = threadIdx.x; k < g.k_slots; k += kBlock) {
+                lds_s[k] = 0.0;
+                lds_b[k] = 0.0;
+            }
+        }
+        __syncthreads();
+        ch.init(table, site, g);
+    }
 
     // CPL == 1: one accumulator pair.  CPL == 2 / V: one pair per COMPONENT of the packet (a cvt + an add per
     // term in the loop, no selects); CPL == 2 folds them into its two channels after the walk, by `split`.
@@ -340,6 +354,34 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
         if constexpr (UNROLL >= 2) if (i < walk.n_rows) group(i, std::integral_constant<int, 1>{});
     }
     if (EVAL) return;
+
+    if constexpr (WW) {
+        // four waves, four interleaved row sets of the same 64 x V channels: waves 1..3 park their sums in LDS
+        // ([wave][component][lane]: a lane-contiguous 16 bytes each, conflict-free), wave 0 adds them in wave order and
+        // stores the workgroup's partial row, slot = component * 64 + lane (1 KiB contiguous per component).
+        double2* comb = reinterpret_cast<double2*>(smem);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (wave > 0) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) comb[((wave - 1) * V + j) * 64 + lane] = make_double2(acc_s[j], acc_b[j]);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            double2* out = partials + (static_cast<int64_t>(blockIdx.y) * g.n_windows + blockIdx.x) * g.k_slots;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                double ts = acc_s[j], tb = acc_b[j];
+#pragma unroll
+                for (int w = 0; w < kBlock / 64 - 1; ++w) {
+                    const double2 o = comb[(w * V + j) * 64 + lane];
+                    ts += o.x;
+                    tb += o.y;
+                }
+                out[j * 64 + lane] = make_double2(ts, tb);
+            }
+        }
+        return;
+    }
 
     if (CPL == 2) {
         // components below `split` -> first channel, the rest -> second channel (two disjoint sums: a
@@ -452,6 +494,44 @@ __global__ __launch_bounds__(kBlock) void finalize_pc_kernel(const double2* __re
     }
     const double2 t = combine_parts(wave_part, fin_ch, s, b);
     if (part == 0 && c < g.C) {
+        double ts = t.x, tb = t.y;
+        if (!eval_mode && sym) tb = 0.0 + static_cast<double>(sym_term);
+        ds[c] = static_cast<T>(ts);
+        db[c] = static_cast<T>(tb);
+        if (wide) {
+            wide[c] = ts;
+            wide[g.C + c] = tb;
+        }
+    }
+}
+
+// Finalize (wave-wide windows): the partials are [splits][n_windows * 64 V] in slot order (slot = component * 64 + lane
+// inside a window), so consecutive threads read consecutive 16-byte partials; thread -> slot -> channel
+// c = window * 64 V + lane * V + component.  fin_ch slots x (256 / fin_ch) interleaved slices of the splits per
+// workgroup, fixed-order combination as in finalize_pc_kernel.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void finalize_ww_kernel(const double2* __restrict__ partials, PcGeom g, int fin_ch,
+                                                             int eval_mode, int sym, T sym_term, T* __restrict__ ds,
+                                                             T* __restrict__ db, double* __restrict__ wide) {
+    __shared__ double2 wave_part[(kBlock / 64) * kFinCh];
+    const int parts = kBlock / fin_ch;
+    const int lane_c = threadIdx.x % fin_ch, part = threadIdx.x / fin_ch;
+    const int64_t total_slots = g.n_windows * g.k_slots;
+    const int64_t gslot = static_cast<int64_t>(blockIdx.x) * fin_ch + lane_c;
+    const int64_t win = gslot / g.k_slots, k = gslot - win * g.k_slots;
+    const int64_t c = win * g.wpos + (k & 63) * g.vec + (k >> 6);
+    const bool valid = gslot < total_slots && c < g.C;
+    double s = 0.0, b = 0.0;
+    if (!eval_mode && valid) {
+#pragma unroll 4
+        for (int64_t sy = part; sy < g.splits; sy += parts) {
+            const double2 v = partials[sy * total_slots + gslot];
+            s += v.x;
+            b += v.y;
+        }
+    }
+    const double2 t = combine_parts(wave_part, fin_ch, s, b);
+    if (part == 0 && valid) {
         double ts = t.x, tb = t.y;
         if (!eval_mode && sym) tb = 0.0 + static_cast<double>(sym_term);
         ds[c] = static_cast<T>(ts);
@@ -676,6 +756,7 @@ __global__ __launch_bounds__(kBlock) void finalize_seg_kernel(const double2* __r
 template <typename IO>
 constexpr int kWindowBwdVec = IO::VEC;
 constexpr int kLastAxisBwdBlocksPerCU = 2;
+constexpr int kWwBwdBlocksPerCU = 4;     // wave-wide windows: one full round for every storage type (3-4 resident per CU)
 // Rows a forward workgroup walks at least, per unit of its per-workgroup overhead (make_geom): that overhead is only
 // the channel-table build -- VEC channels per lane when the quantized axis is the last one, so twice as heavy per
 // streamed byte for 16-bit storage.  ([64,197,768] fp32 forward 17.8 -> 13.7 us, bf16 13.8 -> 11.4 us against the
@@ -695,8 +776,17 @@ size_t bwd_pc_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64
     const int vecs[3] = {io_vec, 1, 4};   // full packets, single elements, half packets (16-bit window backward)
     for (int vi = 0; vi < 3; ++vi) {
         for (int bpc = 1; bpc <= kMaxBlocksPerCU; ++bpc) {
-            const PcGeom g = make_geom(outer, channels, inner, vecs[vi], dev.cu_count * bpc);
-            need = std::max(need, static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2));
+            for (int res = 0; res <= 8; ++res) {   // residency of the instantiation that will run: 0 (not used) .. 8 per CU
+                const PcGeom g = make_geom(outer, channels, inner, vecs[vi], dev.cu_count * bpc, 27, dev.cu_count * res);
+                need = std::max(need, static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2));
+            }
+            if (vi == 0 && inner == 1 && io_vec > 1) {
+                const int min_rows = (107 + (16 / io_vec) - 1) / (16 / io_vec);   // kWwMinRows of the storage type
+                for (int res = 0; res <= 8; ++res) {
+                    const PcGeom g = make_geom_ww(outer, channels, io_vec, dev.cu_count * bpc, min_rows, dev.cu_count * res);
+                    need = std::max(need, static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2));
+                }
+            }
             if (vi < 2 && pick_segment_mode(vecs[vi], outer, channels, inner)) {
                 const SegGeom sgm = make_seg_geom(outer, channels, inner, vecs[vi], dev.cu_count * bpc);
                 need = std::max(need, static_cast<size_t>(channels) * sgm.segs * sgm.osplits * sizeof(double2));
@@ -785,14 +875,37 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
 }
 
 // ---- backward -------------------------------------------------------------------------------------
-template <typename IO, int V, int CPL, bool SYM, bool INIT, bool EVAL>
-static hipError_t launch_bwd_pc(const void* grad, const void* x, void* dx, const PcGeom& g, const void* scale,
-                                const void* shift, const lsq_params& p, typename IO::arith gs, double2* partials,
-                                const Variant& v, hipStream_t stream) {
+// Everything a window-mode backward launch needs besides the kernel's template arguments.
+template <typename T>
+struct BwdPcCall {
+    const void* grad;
+    const void* x;
+    void* dx;
+    T* ds;
+    T* db;
+    double* wide;
+    int64_t outer, C, inner;
+    const void* scale;
+    const void* shift;
+    const lsq_params* p;
+    T gs, sym_term;
+    double2* partials;
+    size_t workspace_bytes;
+    int target_blocks;     // requested workgroups (CUs x workgroups per CU)
+    bool whole_rounds;     // size the grid in whole rounds of what the chip holds at once (make_geom)
+    Variant v;
+    hipStream_t stream;
+};
+
+// rows a wave-wide-window workgroup walks at least: keeps its 16-byte-per-slot partial row under ~5 % of what it streams
+template <typename IO>
+constexpr int kWwMinRows = (107 + static_cast<int>(sizeof(typename IO::elem)) - 1) / static_cast<int>(sizeof(typename IO::elem));
+
+template <typename IO, int V, int CPL, bool SYM, bool INIT, bool EVAL, bool WW = false>
+static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
     using T = typename IO::arith;
-    const Range<T> r = make_range<T>(p);
-    const dim3 grid(static_cast<unsigned>(g.n_windows), static_cast<unsigned>(g.splits));
-    const size_t lds = static_cast<size_t>(g.k_slots) * (sizeof(QSlot<T>) + 2 * sizeof(double));
+    const Range<T> r = make_range<T>(*c.p);
+    const lsq_params& p = *c.p;
     [[maybe_unused]] constexpr bool kFull = !SYM && !INIT && !EVAL && V > 1 && !std::is_same<IO, io_f64>::value &&
                                             !std::is_same<IO, io_f16>::value;
     // 16-bit storage: unroll 1 + the software-pipelined loop (profiles/r01_pc_pipeline_sweep.txt: 36.3 us against
@@ -801,13 +914,42 @@ static hipError_t launch_bwd_pc(const void* grad, const void* x, void* dx, const
     // CPL == V (inner < V: the quantized axis is the last or nearly the last one -- [tokens, features], NHWC): 16-bit
     // storage runs the pipelined loop at unroll 2 there (profiles/r01_lastaxis_sweep.txt).
     constexpr bool kNarrow = sizeof(typename IO::elem) < 4;
-    constexpr int kDefU = kNarrow ? ((CPL == V && V > 1) ? 2 : 1) : 4;
-#define LSQ_LAUNCH_P(U, NTLF, NTSF, PIPEF)                                                                                 \
-    hipLaunchKernelGGL((bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, U, NTLF, NTSF, PIPEF>), grid, dim3(kBlock), lds, stream, grad, \
-                       x, dx, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r, gs, partials)
+    constexpr int kDefU = kNarrow ? ((CPL == V && V > 1 && !WW) ? 2 : 1) : 4;
+    hipError_t result = hipSuccess;
+    // The geometry depends on how many workgroups of the chosen instantiation fit on the chip at once, so it is built
+    // here, where the kernel is known, together with the launch and the finalize.
+    auto run = [&](auto kern) {
+        const DeviceInfo& dev = device_info();
+        const int per_cu = c.whole_rounds ? resident_blocks_per_cu(reinterpret_cast<const void*>(kern)) : 0;
+        const PcGeom g = WW ? make_geom_ww(c.outer, c.C, V, c.target_blocks, kWwMinRows<IO>, per_cu * dev.cu_count)
+                            : make_geom(c.outer, c.C, c.inner, V, c.target_blocks, 27, per_cu * dev.cu_count);
+        if (!grid_fits(g)) { result = hipErrorInvalidConfiguration; return; }
+        const size_t need = static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2);
+        if (!p.eval_mode && c.workspace_bytes < need) { result = hipErrorInvalidValue; return; }
+        const dim3 grid(static_cast<unsigned>(g.n_windows), static_cast<unsigned>(g.splits));
+        const size_t lds = WW ? static_cast<size_t>(kBlock / 64 - 1) * V * 64 * sizeof(double2)
+                              : static_cast<size_t>(g.k_slots) * (sizeof(QSlot<T>) + 2 * sizeof(double));
+        last_launch_note() = LaunchNote{static_cast<int>(g.n_windows), g.splits, per_cu, 0};
+        hipLaunchKernelGGL(kern, grid, dim3(kBlock), lds, c.stream, c.grad, c.x, c.dx, g, static_cast<const T*>(c.scale),
+                           static_cast<const T*>(c.shift), r, c.gs, c.partials);
+        result = hipGetLastError();
+        if (result != hipSuccess) return;
+        const int fin_ch = fin_channels(c.C);
+        if (WW) {
+            const unsigned fgrid = static_cast<unsigned>((g.n_windows * g.k_slots + fin_ch - 1) / fin_ch);
+            hipLaunchKernelGGL((finalize_ww_kernel<T>), dim3(fgrid), dim3(kBlock), 0, c.stream, c.partials, g, fin_ch,
+                               p.eval_mode ? 1 : 0, p.sym ? 1 : 0, c.sym_term, c.ds, c.db, c.wide);
+        } else {
+            const unsigned fgrid_w = static_cast<unsigned>((c.C + fin_ch - 1) / fin_ch);
+            hipLaunchKernelGGL((finalize_pc_kernel<T>), dim3(fgrid_w), dim3(kBlock), 0, c.stream, c.partials, g, fin_ch,
+                               p.eval_mode ? 1 : 0, p.sym ? 1 : 0, c.sym_term, c.ds, c.db, c.wide);
+        }
+        result = hipGetLastError();
+    };
+#define LSQ_LAUNCH_P(U, NTLF, NTSF, PIPEF) run(bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, U, NTLF, NTSF, PIPEF, WW>)
 #ifdef LSQ_TUNING
     // tuning builds compile both loops for the swept kernels; the switch is the variant's `chunked` bit (unused here)
-    const bool pipe = kFull ? v.chunked : kNarrow;
+    const bool pipe = kFull ? c.v.chunked : kNarrow;
 #define LSQ_LAUNCH(U, NTLF, NTSF)                                   \
     do {                                                            \
         if constexpr (kFull) {                                      \
@@ -820,10 +962,10 @@ static hipError_t launch_bwd_pc(const void* grad, const void* x, void* dx, const
 #else
 #define LSQ_LAUNCH(U, NTLF, NTSF) LSQ_LAUNCH_P(U, NTLF, NTSF, kNarrow)
 #endif
-    LSQ_DISPATCH_VARIANT(kFull, kDefU, v, LSQ_LAUNCH);
+    LSQ_DISPATCH_VARIANT(kFull, kDefU, c.v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH
 #undef LSQ_LAUNCH_P
-    return hipGetLastError();
+    return result;
 }
 
 template <typename IO, bool SYM, bool INIT, bool EVAL>
@@ -857,11 +999,10 @@ static hipError_t launch_bwd_seg(const void* grad, const void* x, void* dx, cons
         return CALL(false, false, false);                      \
     } while (0)
 
-template <typename IO, int V, int CPL>
-static hipError_t bwd_pc_modes(const void* grad, const void* x, void* dx, const PcGeom& g, const void* scale,
-                               const void* shift, const lsq_params& p, typename IO::arith gs, double2* partials,
-                               const Variant& v, hipStream_t stream) {
-#define LSQ_CASE(S, I, E) launch_bwd_pc<IO, V, CPL, S, I, E>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream)
+template <typename IO, int V, int CPL, bool WW = false>
+static hipError_t bwd_pc_modes(const BwdPcCall<typename IO::arith>& c) {
+    const lsq_params& p = *c.p;
+#define LSQ_CASE(S, I, E) launch_bwd_pc<IO, V, CPL, S, I, E, WW>(c)
     LSQ_MODE_SWITCH(LSQ_CASE);
 #undef LSQ_CASE
 }
@@ -919,20 +1060,22 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
     // long epilogue and a 16-byte partial per slot, and the finalize has `splits` of them to fold per channel.  Fewer,
     // fatter workgroups win there in every shape swept (profiles/r01_lastaxis_sweep.txt: 2 per CU; [8192, 4096] fp32
     // 82 us against 100 us at 16 per CU, [200704, 256] 133 against 205).
-    const int target_w = (variant == 0 && vecw > 1 && cpl == vecw) ? dev.cu_count * kLastAxisBwdBlocksPerCU : target;
-    const PcGeom g = make_geom(outer, channels, inner, vecw, target_w);
-    if (!grid_fits(g)) return hipErrorInvalidConfiguration;
-    const size_t need = static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2);
-    if (!p.eval_mode && workspace_bytes < need) return hipErrorInvalidValue;
-    hipError_t e;
-    if (vecw == 1) e = bwd_pc_modes<IO, 1, 1>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
-    else if (cpl == 1) e = bwd_pc_modes<IO, VB, 1>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
-    else if (cpl == 2) e = bwd_pc_modes<IO, VB, 2>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
-    else e = bwd_pc_modes<IO, VB, VB>(grad, x, dx, g, scale, shift, p, gs, partials, v, stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((finalize_pc_kernel<T>), dim3(fgrid_w), dim3(kBlock), 0, stream, partials, g, fin_ch, p.eval_mode ? 1 : 0,
-                       p.sym ? 1 : 0, sym_term, static_cast<T*>(ds), static_cast<T*>(db), wide);
-    return hipGetLastError();
+    const bool last_axis = vecw > 1 && cpl == vecw;
+    if (last_axis && inner == 1) {
+        // the quantized axis is the last one ([tokens, features], channels-last): wave-wide windows, one round of what
+        // the chip holds (variant: workgroups per CU requested, rounded to whole rounds)
+        BwdPcCall<T> call{grad, x, dx, static_cast<T*>(ds), static_cast<T*>(db), wide, outer, channels, inner, scale, shift, &p,
+                          gs, sym_term, partials, workspace_bytes, variant == 0 ? dev.cu_count * kWwBwdBlocksPerCU : target,
+                          /*whole_rounds=*/true, v, stream};
+        return bwd_pc_modes<IO, VB, VB, true>(call);
+    }
+    const int target_w = (variant == 0 && last_axis) ? dev.cu_count * kLastAxisBwdBlocksPerCU : target;
+    BwdPcCall<T> call{grad, x, dx, static_cast<T*>(ds), static_cast<T*>(db), wide, outer, channels, inner, scale, shift, &p,
+                      gs, sym_term, partials, workspace_bytes, target_w, /*whole_rounds=*/!last_axis, v, stream};
+    if (vecw == 1) return bwd_pc_modes<IO, 1, 1>(call);
+    if (cpl == 1) return bwd_pc_modes<IO, VB, 1>(call);
+    if (cpl == 2) return bwd_pc_modes<IO, VB, 2>(call);
+    return bwd_pc_modes<IO, VB, VB>(call);
 }
 
 #define LSQ_INSTANTIATE(IO)                                                                                          \

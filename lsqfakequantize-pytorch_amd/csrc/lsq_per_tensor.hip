@@ -207,8 +207,12 @@ __device__ __forceinline__ void block_reduce_store(double s, double b, double2* 
             ts += wave_tot[w].x;
             tb += wave_tot[w].y;
         }
-        partials[blockIdx.x] = make_double2(ts, tb);
-        if (f.ticket) is_last = ticket_arrive_is_last(f.ticket, gridDim.x) ? 1 : 0;
+        if (f.ticket) {
+            store_partial_agent(partials + blockIdx.x, ts, tb);
+            is_last = ticket_arrive_is_last(f.ticket, gridDim.x) ? 1 : 0;
+        } else {
+            partials[blockIdx.x] = make_double2(ts, tb);
+        }
     }
     if (!f.ticket) return;
     __syncthreads();

@@ -28,7 +28,8 @@ def _inputs(n, dtype, dev, seed=5):
 
 
 def _bits(t):
-    return t.detach().cpu().numpy().tobytes()
+    t = t.detach().contiguous()
+    return t.view(torch.int16 if t.element_size() == 2 else (torch.int32 if t.element_size() == 4 else torch.int64)).cpu().numpy().tobytes()
 
 
 @pytest.mark.parametrize("n", [1, 63, 1024, 4096 + 3, 802816, 25690112 + 5])
