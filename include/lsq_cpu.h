@@ -1,0 +1,45 @@
+/* include/lsq_cpu.h -- the host-memory twin of the drop-in boundary (include/lsq_hip.h).
+ *
+ * `liblsq_cpu.so` (built from lsqfakequantize-pytorch_amd/csrc/cpu/ with g++) serves CPU tensors the way the
+ * reference's own CPU backend does -- TORCH_LIBRARY_IMPL(torchlsq, CPU),
+ *   /root/reference/torchlsq/csrc/ops/cpu/lsq_cpu.cpp:298-311
+ * -- so that a model can be prepared, calibrated, evaluated or exported on the CPU with the same operators.  It is NOT a
+ * fallback of the GPU path: GPU tensors are dispatched to liblsq_hip.so only, and a missing liblsq_hip.so disables the
+ * package as a whole (torchlsq/extension.py::_assert_has_ops).
+ *
+ * Same conventions as lsq_hip.h with HOST pointers and no stream: caller-owned dense buffers, the [outer, C, inner] view
+ * for per-channel ops, `lsq_params` (shared with lsq_hip.h, incl. numel_for_scaler), 0 / negative status codes, never
+ * throws.  Storage: LSQ_F32, LSQ_F64 (the reference's AT_DISPATCH_FLOATING_TYPES, lsq_cpu.cpp:37,92) and LSQ_BF16
+ * storage with fp32 arithmetic like the GPU build (LSQ_F16 is refused).  d_scale / d_shift: fp64 accumulation over fixed-size blocks
+ * combined in block order -- independent of the number of threads, hence bit-reproducible.
+ */
+#ifndef LSQ_CPU_H_
+#define LSQ_CPU_H_
+
+#include "lsq_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int lsq_cpu_abi_version(void);
+const char* lsq_cpu_last_error(void);
+
+/* lsq_forward_per_tensor_impl, lsq_cpu.cpp:15-53 */
+int lsq_cpu_forward_per_tensor(int dtype, const void* x, void* y, int64_t n, const void* scale, const void* shift,
+                               const lsq_params* p);
+/* lsq_backward_per_tensor_impl, lsq_cpu.cpp:56-141 (one fused pass; no N-sized temporaries).  dsdb_wide as in lsq_hip.h. */
+int lsq_cpu_backward_per_tensor(int dtype, const void* grad, const void* x, void* dx, void* ds, void* db,
+                                double* dsdb_wide, int64_t n, const void* scale, const void* shift, const lsq_params* p);
+/* lsq_forward_per_channel_impl, lsq_cpu.cpp:145-193 */
+int lsq_cpu_forward_per_channel(int dtype, const void* x, void* y, int64_t outer, int64_t channels, int64_t inner,
+                                const void* scale, const void* shift, const lsq_params* p);
+/* lsq_backward_per_channel_impl, lsq_cpu.cpp:197-294 */
+int lsq_cpu_backward_per_channel(int dtype, const void* grad, const void* x, void* dx, void* ds, void* db,
+                                 double* dsdb_wide, int64_t outer, int64_t channels, int64_t inner, const void* scale,
+                                 const void* shift, const lsq_params* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSQ_CPU_H_ */

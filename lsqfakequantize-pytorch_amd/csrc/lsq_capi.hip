@@ -223,6 +223,11 @@ int lsq_hip_backward_from_mask(int dtype, const void* grad, const void* mask, vo
 
 void lsq_hip_debug_set_observe_wg_per_cu(int v) { lsq::set_observe_wg_per_cu(v); }
 
+void lsq_hip_debug_last_launch(int* out4) {
+    const lsq::LaunchNote& n = lsq::last_launch_note();
+    out4[0] = n.grid_x; out4[1] = n.grid_y; out4[2] = n.resident_per_cu; out4[3] = n.vgprs_hint;
+}
+
 size_t lsq_hip_minmax_workspace(int dtype, int64_t outer, int64_t channels, int64_t inner) {
     if (!dtype_ok(dtype) || outer <= 0 || channels <= 0 || inner <= 0) return 256;
     return lsq::minmax_workspace_bytes(io_vec(dtype), dtype == LSQ_F64 ? 8 : 4, outer, channels, inner);

@@ -23,6 +23,9 @@ int lsq_hip_backward_per_channel_ex(int dtype, const void* grad, const void* x, 
                                     const void* scale, const void* shift, const lsq_params* p,
                                     const lsq_bwd_extras* extras, void* workspace, size_t workspace_bytes, void* stream,
                                     int variant);
+/* tools only: [grid x, grid y, resident workgroups per CU used for the geometry, numRegs] of this thread's last
+ * window-mode backward launch */
+void lsq_hip_debug_last_launch(int* out4);
 /* tuning only: override the workgroups-per-CU of the observer-statistics kernels (0 = defaults) */
 void lsq_hip_debug_set_observe_wg_per_cu(int v);
 #ifdef __cplusplus

@@ -66,6 +66,8 @@ struct PcGeom {
     int32_t k_slots;         // channel slots per window (LDS table / partial row length)
     int32_t vec;             // elements per lane per row (IO::VEC or 1)
     int32_t fits32;          // L < 2^31: index divisions in 32 bits
+    int32_t ww_lanes;        // row-group windows (make_geom_ww): lanes per row group; 0 otherwise
+    int32_t block_threads;   // workgroup size to launch (kBlock except for row-group windows)
 };
 
 // per_slot_rows: rows a workgroup should walk per (slot / lane-position) of per-workgroup overhead.  27 for the
@@ -94,14 +96,19 @@ static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec,
         g.k_slots = static_cast<int32_t>(C);
     }
     g.n_tiles = (outer + g.R - 1) / g.R;
+    g.ww_lanes = 0;
+    g.block_threads = kBlock;
     // keep the partial-sum traffic (16 B per slot per workgroup) below ~5 % of the streamed bytes -- except for small
     // tensors (< 2 M elements), which are latency- not traffic-bound: there a workgroup takes as few rows as the grid
     // target allows ([128, 768]: 128 workgroups of one row instead of 7 walking 21 rows one group after the other)
     const bool small = outer * g.L < (int64_t{1} << 21);
     const int64_t min_tiles = small ? 1 : std::max<int64_t>(1, (per_slot_rows * static_cast<int64_t>(g.k_slots) + W - 1) / W);
     const int64_t max_splits = std::max<int64_t>(1, g.n_tiles / min_tiles);       // every split gets >= min_tiles tiles
-    int64_t splits = std::max<int64_t>(1, (target_blocks + g.n_windows - 1) / g.n_windows);
-    splits = std::min(splits, max_splits);
+    const int64_t want_splits = std::max<int64_t>(1, (target_blocks + g.n_windows - 1) / g.n_windows);
+    // whole tiles per workgroup first (ceil), then as many workgroups as that needs: [64,197,768] forward = 3152
+    // workgroups of 4 rows, not 4096 of 3-or-4 (every workgroup rebuilds the window's channel table)
+    const int64_t tiles_each = std::max<int64_t>((g.n_tiles + want_splits - 1) / want_splits, min_tiles);
+    int64_t splits = std::max<int64_t>(1, (g.n_tiles + tiles_each - 1) / tiles_each);
     const int64_t per_round = resident_blocks > 0 ? resident_blocks / g.n_windows : 0;
     if (per_round >= 1 && splits >= per_round) {
         // whole rounds: the nearest multiple of per_round that the row count allows (at least one round)
@@ -115,19 +122,31 @@ static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec,
     return g;
 }
 
-// WAVE-WIDE windows for the case "the quantized axis is the last one" (inner == 1, position == channel): a window is
-// 64 lanes x V channels -- ONE wave wide -- and the four waves of a workgroup take four different rows of it (the row
-// tile is R = 4 rows: wave w owns row w of every tile), so a workgroup still has four wave64 streams in flight but only
-// 64 x V partial slots to flush, a quarter of the 256-lane window's.  ([8192, 4096] bf16: 768 workgroups write 6 MB of
-// partials instead of 25 MB.)  The lane's V channels are its own: their constants live in registers, there is no LDS
-// table, and the epilogue is a fixed-order sum of the four waves through LDS.
+// ROW-GROUP windows for the case "the quantized axis is the last one" (inner == 1, position == channel, L % V == 0).
+// A workgroup is R row groups of w lanes; row group r owns row r of every tile of R rows, all over the same w x V channels:
+//   * rows of at most 256 lanes (L / V <= 256: NHWC with 256 channels, [tokens, 768]): w = L / V -- the whole row --
+//     and R = 256 / w row groups, the workgroup size rounded up to whole waves (L / V = 96 -> 192 threads, none idle);
+//   * longer rows ([8192, 4096]): w = 64, one wave per row group, R = 4, ceil(L / 64 V) windows per row.
+// A workgroup so has up to four wave64 streams in flight but only w x V partial slots to flush -- a quarter of the
+// 256-lane window's ([8192, 4096] bf16: 768 workgroups write 6 MB of partials instead of 25 MB).  The lane's V channels
+// are its own: their constants live in registers, there is no LDS table, and the epilogue is a fixed-order sum of the
+// row groups through LDS.
 static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_blocks, int min_rows, int resident_blocks) {
     PcGeom g;
     g.outer = outer; g.C = C; g.inner = 1; g.L = C; g.vec = vec;
     g.fits32 = (g.L + static_cast<int64_t>(kBlock) * vec) < 0x7fffffffLL ? 1 : 0;
-    g.R = kBlock / 64;
-    g.wpos = 64 * static_cast<int64_t>(vec);
-    g.n_windows = (g.L + g.wpos - 1) / g.wpos;
+    const int64_t lanes_per_row = g.L / vec;
+    if (lanes_per_row <= kBlock) {
+        g.ww_lanes = static_cast<int32_t>(lanes_per_row);
+        g.R = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(kBlock / lanes_per_row, outer)));
+        g.n_windows = 1;
+    } else {
+        g.ww_lanes = 64;
+        g.R = kBlock / 64;
+        g.n_windows = (lanes_per_row + 63) / 64;
+    }
+    g.block_threads = static_cast<int32_t>((static_cast<int64_t>(g.R) * g.ww_lanes + 63) / 64 * 64);
+    g.wpos = static_cast<int64_t>(g.ww_lanes) * vec;
     g.k_slots = static_cast<int32_t>(g.wpos);
     g.n_tiles = (outer + g.R - 1) / g.R;
     const bool small = outer * g.L < (int64_t{1} << 21);
@@ -173,12 +192,16 @@ __device__ __forceinline__ LaneSite lane_site(const PcGeom& g, int V) {
     return s;
 }
 
-__device__ __forceinline__ LaneSite lane_site_ww(const PcGeom& g, int V) {
+// row-group windows: thread t = lane (t % w) of row group (t / w); `lane_in_group` comes back through c_lo's neighbour
+__device__ __forceinline__ LaneSite lane_site_ww(const PcGeom& g, int V, int32_t& lane_in_group) {
     LaneSite s;
+    const uint32_t w = static_cast<uint32_t>(g.ww_lanes);
+    const uint32_t rg = threadIdx.x / w;
+    lane_in_group = static_cast<int32_t>(threadIdx.x - rg * w);
     const int64_t base = static_cast<int64_t>(blockIdx.x) * g.wpos;
-    s.p0 = base + static_cast<int64_t>(threadIdx.x & 63) * V;
-    s.row_in_tile = static_cast<int32_t>(threadIdx.x >> 6);
-    s.live = s.p0 < g.L;
+    s.p0 = base + static_cast<int64_t>(lane_in_group) * V;
+    s.row_in_tile = static_cast<int32_t>(rg);
+    s.live = static_cast<int32_t>(rg) < g.R && s.p0 < g.L;
     s.c_lo = base;     // inner == 1: position == channel
     return s;
 }

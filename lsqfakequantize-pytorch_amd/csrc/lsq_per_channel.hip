@@ -208,8 +208,8 @@ __device__ __forceinline__ void segmented_wave_accumulate(int key, double s, dou
     }
 }
 
-// WW: wave-wide windows (make_geom_ww: inner == 1, CPL == V) -- the lane's channels are its own, their constants are
-// computed from global memory into registers (no LDS table) and the epilogue sums the four waves in a fixed order.
+// WW: row-group windows (make_geom_ww: inner == 1, CPL == V) -- the lane's channels are its own, their constants are
+// computed from global memory into registers (no LDS table) and the epilogue sums the row groups in a fixed order.
 template <typename IO, int V, int CPL, bool SYM, bool INIT, bool EVAL, int UNROLL, bool NTL, bool NTS, bool PIPE, bool WW = false>
 __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__ grad, const void* __restrict__ x,
                                                         void* __restrict__ dx, PcGeom g,
@@ -221,12 +221,13 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
     using E = typename IO::elem;
     using LC = LaneChannels<T, V, CPL>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    static_assert(!WW || (CPL == V && V > 1), "wave-wide windows: one channel per packet component");
+    static_assert(!WW || (CPL == V && V > 1), "row-group windows: one channel per packet component");
     QSlot<T>* table = reinterpret_cast<QSlot<T>*>(smem);
     double* lds_s = reinterpret_cast<double*>(smem + static_cast<size_t>(g.k_slots) * sizeof(QSlot<T>));
     double* lds_b = lds_s + g.k_slots;
 
-    const LaneSite site = WW ? lane_site_ww(g, V) : lane_site(g, V);
+    int32_t lane_in_group = 0;
+    const LaneSite site = WW ? lane_site_ww(g, V, lane_in_group) : lane_site(g, V);
     const RowWalk walk(g, site);
     // A group = UNROLL rows.  load_group never predicates: rows past the lane's last one re-read the last row.
     auto load_group = [&](E (&gb)[UNROLL][V], E (&xb)[UNROLL][V], int64_t i0) {
@@ -244,12 +245,12 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
     LC ch;
     if constexpr (WW) {
         // channel p0 + j is component j's own: constants straight into registers (lsq_kernel.h:157-158 + :12)
-        ch.split = V;
+        ch.split = (CPL == 2) ? 1 : V;     // V == 2 (8-byte elements): LaneChannels' two-channel form, component 1 = channel 1
 #pragma unroll
         for (int j = 0; j < LC::N; ++j) {
             const int64_t c = site.live ? site.p0 + j : 0;
             ch.q[j] = make_qparams<T>(sanitize_scale_per_channel<T>(scale[c]), shift[c], r);
-            ch.key[j] = j * 64 + static_cast<int32_t>(threadIdx.x & 63);
+            ch.key[j] = j * g.ww_lanes + lane_in_group;
         }
     } else {
         build_channel_table<T>(table, g.k_slots, site.c_lo, g.C, scale, shift, r);
@@ -356,28 +357,27 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
     if (EVAL) return;
 
     if constexpr (WW) {
-        // four waves, four interleaved row sets of the same 64 x V channels: waves 1..3 park their sums in LDS
-        // ([wave][component][lane]: a lane-contiguous 16 bytes each, conflict-free), wave 0 adds them in wave order and
-        // stores the workgroup's partial row, slot = component * 64 + lane (1 KiB contiguous per component).
+        // R row groups, R interleaved row sets of the same w x V channels: groups 1..R-1 park their sums in LDS
+        // ([group][component][lane]: a lane-contiguous 16 bytes each, conflict-free), group 0 adds them in group order
+        // and stores the workgroup's partial row, slot = component * w + lane (contiguous per component).
         double2* comb = reinterpret_cast<double2*>(smem);
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if (wave > 0) {
+        const int w = g.ww_lanes, rg = site.row_in_tile;
+        if (rg > 0 && rg < g.R) {
 #pragma unroll
-            for (int j = 0; j < V; ++j) comb[((wave - 1) * V + j) * 64 + lane] = make_double2(acc_s[j], acc_b[j]);
+            for (int j = 0; j < V; ++j) comb[((rg - 1) * V + j) * w + lane_in_group] = make_double2(acc_s[j], acc_b[j]);
         }
         __syncthreads();
-        if (wave == 0) {
+        if (rg == 0) {
             double2* out = partials + (static_cast<int64_t>(blockIdx.y) * g.n_windows + blockIdx.x) * g.k_slots;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 double ts = acc_s[j], tb = acc_b[j];
-#pragma unroll
-                for (int w = 0; w < kBlock / 64 - 1; ++w) {
-                    const double2 o = comb[(w * V + j) * 64 + lane];
-                    ts += o.x;
-                    tb += o.y;
+                for (int o = 0; o < g.R - 1; ++o) {
+                    const double2 v = comb[(o * V + j) * w + lane_in_group];
+                    ts += v.x;
+                    tb += v.y;
                 }
-                out[j * 64 + lane] = make_double2(ts, tb);
+                out[j * w + lane_in_group] = make_double2(ts, tb);
             }
         }
         return;
@@ -505,9 +505,9 @@ __global__ __launch_bounds__(kBlock) void finalize_pc_kernel(const double2* __re
     }
 }
 
-// Finalize (wave-wide windows): the partials are [splits][n_windows * 64 V] in slot order (slot = component * 64 + lane
+// Finalize (row-group windows): the partials are [splits][n_windows * w V] in slot order (slot = component * w + lane
 // inside a window), so consecutive threads read consecutive 16-byte partials; thread -> slot -> channel
-// c = window * 64 V + lane * V + component.  fin_ch slots x (256 / fin_ch) interleaved slices of the splits per
+// c = window * w V + lane * V + component.  fin_ch slots x (256 / fin_ch) interleaved slices of the splits per
 // workgroup, fixed-order combination as in finalize_pc_kernel.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void finalize_ww_kernel(const double2* __restrict__ partials, PcGeom g, int fin_ch,
@@ -516,16 +516,19 @@ __global__ __launch_bounds__(kBlock) void finalize_ww_kernel(const double2* __re
     __shared__ double2 wave_part[(kBlock / 64) * kFinCh];
     const int parts = kBlock / fin_ch;
     const int lane_c = threadIdx.x % fin_ch, part = threadIdx.x / fin_ch;
-    const int64_t total_slots = g.n_windows * g.k_slots;
-    const int64_t gslot = static_cast<int64_t>(blockIdx.x) * fin_ch + lane_c;
-    const int64_t win = gslot / g.k_slots, k = gslot - win * g.k_slots;
-    const int64_t c = win * g.wpos + (k & 63) * g.vec + (k >> 6);
+    const uint32_t k_slots = static_cast<uint32_t>(g.k_slots), w = static_cast<uint32_t>(g.ww_lanes);
+    const uint32_t total_slots = static_cast<uint32_t>(g.n_windows) * k_slots;     // ~ the channel count: fits 32 bits
+    const uint32_t gslot = blockIdx.x * static_cast<uint32_t>(fin_ch) + lane_c;
+    const uint32_t win = gslot / k_slots, k = gslot - win * k_slots;
+    const uint32_t comp = k / w, lane = k - comp * w;
+    const int64_t c = static_cast<int64_t>(win) * k_slots + static_cast<int64_t>(lane) * g.vec + comp;
     const bool valid = gslot < total_slots && c < g.C;
     double s = 0.0, b = 0.0;
     if (!eval_mode && valid) {
+        const double2* col = partials + gslot;
 #pragma unroll 4
-        for (int64_t sy = part; sy < g.splits; sy += parts) {
-            const double2 v = partials[sy * total_slots + gslot];
+        for (int sy = part; sy < g.splits; sy += parts) {
+            const double2 v = col[static_cast<int64_t>(sy) * total_slots];
             s += v.x;
             b += v.y;
         }
@@ -756,7 +759,7 @@ __global__ __launch_bounds__(kBlock) void finalize_seg_kernel(const double2* __r
 template <typename IO>
 constexpr int kWindowBwdVec = IO::VEC;
 constexpr int kLastAxisBwdBlocksPerCU = 2;
-constexpr int kWwBwdBlocksPerCU = 4;     // wave-wide windows: one full round for every storage type (3-4 resident per CU)
+constexpr int kWwBwdBlocksPerCU = 4;     // row-group windows: one full round for every storage type (3-4 resident per CU)
 // Rows a forward workgroup walks at least, per unit of its per-workgroup overhead (make_geom): that overhead is only
 // the channel-table build -- VEC channels per lane when the quantized axis is the last one, so twice as heavy per
 // streamed byte for 16-bit storage.  ([64,197,768] fp32 forward 17.8 -> 13.7 us, bf16 13.8 -> 11.4 us against the
@@ -897,7 +900,7 @@ struct BwdPcCall {
     hipStream_t stream;
 };
 
-// rows a wave-wide-window workgroup walks at least: keeps its 16-byte-per-slot partial row under ~5 % of what it streams
+// rows a row-group-window workgroup walks at least: keeps its 16-byte-per-slot partial row under ~5 % of what it streams
 template <typename IO>
 constexpr int kWwMinRows = (107 + static_cast<int>(sizeof(typename IO::elem)) - 1) / static_cast<int>(sizeof(typename IO::elem));
 
@@ -906,7 +909,8 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
     using T = typename IO::arith;
     const Range<T> r = make_range<T>(*c.p);
     const lsq_params& p = *c.p;
-    [[maybe_unused]] constexpr bool kFull = !SYM && !INIT && !EVAL && V > 1 && !std::is_same<IO, io_f64>::value &&
+    // (tuning builds also compile the variant table of the dx-only EVAL kernel: the streaming rate of the access pattern)
+    [[maybe_unused]] constexpr bool kFull = !SYM && !INIT && V > 1 && !std::is_same<IO, io_f64>::value &&
                                             !std::is_same<IO, io_f16>::value;
     // 16-bit storage: unroll 1 + the software-pipelined loop (profiles/r01_pc_pipeline_sweep.txt: 36.3 us against
     // 38.5 us for the best plain variant at BASELINE config 5); 4/8-byte storage gains nothing from it (55.6 vs 55.9 us)
@@ -927,10 +931,14 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
         const size_t need = static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2);
         if (!p.eval_mode && c.workspace_bytes < need) { result = hipErrorInvalidValue; return; }
         const dim3 grid(static_cast<unsigned>(g.n_windows), static_cast<unsigned>(g.splits));
-        const size_t lds = WW ? static_cast<size_t>(kBlock / 64 - 1) * V * 64 * sizeof(double2)
+        const size_t lds = WW ? static_cast<size_t>(std::max(1, g.R - 1)) * g.k_slots * sizeof(double2)
                               : static_cast<size_t>(g.k_slots) * (sizeof(QSlot<T>) + 2 * sizeof(double));
-        last_launch_note() = LaunchNote{static_cast<int>(g.n_windows), g.splits, per_cu, 0};
-        hipLaunchKernelGGL(kern, grid, dim3(kBlock), lds, c.stream, c.grad, c.x, c.dx, g, static_cast<const T*>(c.scale),
+        {
+            hipFuncAttributes fa;
+            const int regs = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)) == hipSuccess ? fa.numRegs : -1;
+            last_launch_note() = LaunchNote{static_cast<int>(g.n_windows), g.splits, per_cu, regs};
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(g.block_threads), lds, c.stream, c.grad, c.x, c.dx, g, static_cast<const T*>(c.scale),
                            static_cast<const T*>(c.shift), r, c.gs, c.partials);
         result = hipGetLastError();
         if (result != hipSuccess) return;
@@ -1062,7 +1070,7 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
     // 82 us against 100 us at 16 per CU, [200704, 256] 133 against 205).
     const bool last_axis = vecw > 1 && cpl == vecw;
     if (last_axis && inner == 1) {
-        // the quantized axis is the last one ([tokens, features], channels-last): wave-wide windows, one round of what
+        // the quantized axis is the last one ([tokens, features], channels-last): row-group windows, one round of what
         // the chip holds (variant: workgroups per CU requested, rounded to whole rounds)
         BwdPcCall<T> call{grad, x, dx, static_cast<T*>(ds), static_cast<T*>(db), wide, outer, channels, inner, scale, shift, &p,
                           gs, sym_term, partials, workspace_bytes, variant == 0 ? dev.cu_count * kWwBwdBlocksPerCU : target,

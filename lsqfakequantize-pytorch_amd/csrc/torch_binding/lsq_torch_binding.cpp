@@ -24,6 +24,8 @@
 #include <hip/hip_runtime_api.h>
 
 #include <array>
+#include <atomic>
+#include <cstdlib>
 #include <limits>
 #include <map>
 #include <mutex>
@@ -157,6 +159,8 @@ Tensor byte_workspace(const Tensor& like, size_t nbytes) {
 // launches that can run concurrently.  One slab of kTicketSlots tickets per device is allocated (and zeroed) at the
 // first eager backward on that device; streams get a slot each on first use (host bookkeeping only, so a stream first
 // seen during graph capture still gets one as long as the slab exists; otherwise that call takes the two-launch route).
+// Off by default: measured on MI355X the single-launch route is not faster than kernel + finalize launch.
+std::atomic<bool> g_use_ticket{[] { const char* e = std::getenv("TORCHLSQ_SINGLE_LAUNCH_BACKWARD"); return e && e[0] == '1'; }()};
 constexpr int kTicketSlots = 64;
 struct TicketSlab {
     Tensor storage;
@@ -168,6 +172,7 @@ std::map<int, TicketSlab> g_ticket_slabs;                    // device index -> 
 std::map<std::pair<int, void*>, void*> g_tickets;            // (device index, stream) -> ticket
 
 void* ticket_for(const Tensor& x, void* stream) {
+    if (!g_use_ticket.load(std::memory_order_relaxed)) return nullptr;
     const int dev = x.device().index();
     std::lock_guard<std::mutex> lock(g_ticket_mutex);
     const auto key = std::make_pair(dev, stream);
@@ -419,6 +424,7 @@ TORCH_LIBRARY(torchlsq_native, m) {
           "bool use_grad_scaling, float grad_scale, bool is_affine, bool is_perchannel, bool eval_mode, bool init_mode) -> Tensor",
           &lsq);
     m.def("_abi_version() -> int", []() -> int64_t { return lsq_hip_abi_version(); });
+    m.def("_set_single_launch_backward(bool on) -> ()", [](bool on) { g_use_ticket.store(on); });
 }
 
 TORCH_LIBRARY_IMPL(torchlsq_native, CUDA, m) {  // PyTorch-ROCm dispatches HIP tensors under the CUDA key

@@ -10,10 +10,11 @@ This module replaces two pieces of the reference:
     (lsq_cpu.cpp:28-29,72-78,159-163,214-223) -- which are restated with `torch.library`.
 
 Dispatch keys: HIP tensors carry PyTorch's "CUDA" dispatch key on ROCm builds, so the gfx950
-kernels are registered under "CUDA".  Nothing is registered for "CPU": this is the MI355X build,
-CPU tensors raise NotImplementedError from the dispatcher (there is no silent fallback; the test
-suite plugs the independent CPU oracle in under the CPU key to exercise this Python layer on a
-machine without a GPU).
+kernels are registered under "CUDA".  CPU tensors are served, like in the reference
+(TORCH_LIBRARY_IMPL(torchlsq, CPU), lsq_cpu.cpp:298-311), by kernels for host memory: `liblsq_cpu.so`
+(include/lsq_cpu.h, csrc/cpu/lsq_cpu_twin.cpp), registered under "CPU".  The two never substitute for
+each other: a GPU tensor is only ever handled by the HIP library, and when `liblsq_hip.so` is missing
+the package refuses to work at all (`_assert_has_ops`), CPU tensors included.
 """
 import ctypes
 import os
@@ -110,6 +111,38 @@ try:
     _HAS_OPS = True
 except (ImportError, OSError, AttributeError) as e:  # surfaced by _assert_has_ops(), like the reference
     error_str = str(e)
+
+
+# The kernels for tensors in host memory (include/lsq_cpu.h): the counterpart of the reference's CPU dispatch.
+_CPU_LIB = None
+_CPU_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblsq_cpu.so")
+cpu_error_str = ""
+C_ABI_CPU = {
+    "lsq_cpu_abi_version": (_int, []),
+    "lsq_cpu_last_error": (ctypes.c_char_p, []),
+    "lsq_cpu_forward_per_tensor": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _PP]),
+    "lsq_cpu_backward_per_tensor": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _PP]),
+    "lsq_cpu_forward_per_channel": (_int, [_int, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP]),
+    "lsq_cpu_backward_per_channel": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP]),
+}
+
+
+def _load_cpu_library():
+    global _CPU_LIB, cpu_error_str
+    try:
+        lib = ctypes.CDLL(_CPU_LIB_PATH)
+        for name, (res, args) in C_ABI_CPU.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.lsq_cpu_abi_version() != ABI_VERSION:
+            raise OSError("liblsq_cpu.so was built for another ABI version")
+        _CPU_LIB = lib
+    except (OSError, AttributeError) as e:
+        cpu_error_str = str(e)
+
+
+_load_cpu_library()
 
 
 # The optional second host layer: torchlsq/_lsq_torch.so, the C++ torch binding of the same C ABI
@@ -402,6 +435,20 @@ def _workspace(device, nbytes):
 # first eager backward on that device; streams get a slot each on first use (pure host bookkeeping, so a stream first
 # seen DURING graph capture still gets one -- as long as the slab exists; otherwise that call takes the two-launch
 # route).  Kernels of one stream are serialised by the stream, kernels captured from one stream by the graph.
+# Measured on MI355X (profiles/r02_ticket_single_launch.txt): the single-launch route is NOT faster -- the last workgroup's
+# serial chain (drain its dx stores, agent-scope counter round trip, agent-scope loads of the partials) costs as much
+# as the finalize kernel's launch (config 1 backward 8.0 us against 6.9 us; config 2 / 4 unchanged) -- so it is off unless
+# asked for: TORCHLSQ_SINGLE_LAUNCH_BACKWARD=1 or set_single_launch_backward(True).
+_SINGLE_LAUNCH_BWD = [os.environ.get("TORCHLSQ_SINGLE_LAUNCH_BACKWARD", "0") == "1"]
+
+
+def set_single_launch_backward(on):
+    """Use tickets (one launch per backward) in both host layers from now on."""
+    _SINGLE_LAUNCH_BWD[0] = bool(on)
+    if hasattr(torch.ops, "torchlsq_native") and _NATIVE_LSQ is not None:
+        torch.ops.torchlsq_native._set_single_launch_backward(bool(on))
+
+
 _TICKET_SLOTS = 64
 _TICKET_SLABS = {}     # device index -> (slab tensor, base pointer, [next free slot])
 _TICKETS = {}          # (device index, raw stream) -> byref(LsqBwdExtras)
@@ -478,7 +525,7 @@ def hip_forward_per_tensor(x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, 
 
 
 def hip_backward_per_tensor(grad, x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode,
-                            numel_for_scaler=0, want_wide=False, variant=0, use_ticket=True):
+                            numel_for_scaler=0, want_wide=False, variant=0, use_ticket=None):
     _assert_has_ops()
     check_backward_dtypes(grad, x, scale, shift)
     if x.numel() <= 0:  # lsq_cpu.cpp:76-78 returns (x, scale, shift) themselves
@@ -503,6 +550,8 @@ def hip_backward_per_tensor(grad, x, scale, shift, qmin, qmax, tmin, tmax, use_g
     ws = _workspace(dev, _WS_BYTES_PT[0])
     idx = dev.index
     stream = _stream_of(idx)
+    if use_ticket is None:
+        use_ticket = _SINGLE_LAUNCH_BWD[0]
     rc = _on_device(idx, _LIB.lsq_hip_backward_per_tensor_ex, code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(),
                     ds.data_ptr(), db.data_ptr(), wide.data_ptr() if want_wide else None, xd.numel(),
                     scale_c.data_ptr(), shift_c.data_ptr(), pref, _ticket(idx, stream) if use_ticket else None,
@@ -568,7 +617,7 @@ _WS_BYTES_PC = {}
 
 
 def hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode,
-                             init_mode, numel_for_scaler=0, want_wide=False, variant=0, use_ticket=True):
+                             init_mode, numel_for_scaler=0, want_wide=False, variant=0, use_ticket=None):
     _assert_has_ops()
     check_backward_dtypes(grad, x, scale, shift)
     check_channel_args(x, scale, shift, axis, backward=True)
@@ -598,6 +647,8 @@ def hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax
             _WS_BYTES_PC[wkey] = nbytes
     ws = _workspace(dev, nbytes)
     stream = _stream_of(idx)
+    if use_ticket is None:
+        use_ticket = _SINGLE_LAUNCH_BWD[0]
     rc = _on_device(idx, _LIB.lsq_hip_backward_per_channel_ex, code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(),
                     ds.data_ptr(), db.data_ptr(), wide.data_ptr() if want_wide else None, outer, C, inner,
                     scale_c.data_ptr(), shift_c.data_ptr(), pref, _ticket(idx, stream) if use_ticket else None,
@@ -737,6 +788,128 @@ _lib_hip.impl("lsq_minmax_per_tensor", _impl_minmax_pt)
 _lib_hip.impl("lsq_minmax_per_channel", _impl_minmax_pc)
 _lib_hip.impl("lsq_meanstd_per_tensor", _impl_meanstd_pt)
 _lib_hip.impl("lsq_meanstd_per_channel", _impl_meanstd_pc)
+
+
+# -------------------------------------------------------------------------------------------------
+# the CPU backend ("CPU" dispatch key): host-memory tensors -> liblsq_cpu.so, the counterpart of the reference's
+# TORCH_LIBRARY_IMPL(torchlsq, CPU) (lsq_cpu.cpp:298-311).  Same checks, same layout handling, same outputs as the HIP
+# backend above; never reached by a GPU tensor.
+# -------------------------------------------------------------------------------------------------
+def _cpu_lib(what):
+    _assert_has_ops()      # the package as a whole needs its HIP library: CPU tensors do not make it usable on their own
+    if _CPU_LIB is None:
+        raise NotImplementedError("%s: the CPU kernels (liblsq_cpu.so) are not available: %s" % (what, cpu_error_str))
+    return _CPU_LIB
+
+
+def _require_cpu(what, *tensors):
+    for t in tensors:
+        if t.device.type != "cpu":
+            raise RuntimeError("%s: expected all tensors on the CPU but got one on %s" % (what, t.device))
+
+
+def _cpu_status(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, _CPU_LIB.lsq_cpu_last_error().decode("utf-8", "replace")))
+
+
+def _cpu_dtype(x, what):
+    _check(x.dtype in (torch.float32, torch.float64, torch.bfloat16),
+           '"%s" not implemented for \'%s\'' % (what, str(x.dtype).replace("torch.", "")))
+    return _DTYPE_CODE[x.dtype]
+
+
+def cpu_forward(x, scale, shift, axis, per_channel, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode):
+    what = "lsq_forward_per_channel" if per_channel else "lsq_forward_per_tensor"
+    lib = _cpu_lib(what)
+    code = _cpu_dtype(x, "lsq_forward")
+    check_forward_dtypes(x, scale, shift)
+    if per_channel:
+        check_channel_args(x, scale, shift, axis, backward=False)
+    _require_cpu(what, x, scale, shift)
+    xd, order = _dense(x)
+    y = torch.empty_like(xd)
+    if xd.numel() == 0:
+        return y
+    _require_param(what, scale, shift)
+    _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
+    sc, sh = scale.contiguous(), shift.contiguous()
+    if per_channel:
+        outer, C, inner = _ocl(xd, order, axis)
+        rc = lib.lsq_cpu_forward_per_channel(code, xd.data_ptr(), y.data_ptr(), outer, C, inner, sc.data_ptr(), sh.data_ptr(), pref)
+    else:
+        rc = lib.lsq_cpu_forward_per_tensor(code, xd.data_ptr(), y.data_ptr(), xd.numel(), sc.data_ptr(), sh.data_ptr(), pref)
+    _cpu_status(rc, what)
+    return y
+
+
+def cpu_backward(grad, x, scale, shift, axis, per_channel, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode,
+                 numel_for_scaler=0, want_wide=False):
+    what = "lsq_backward_per_channel" if per_channel else "lsq_backward_per_tensor"
+    lib = _cpu_lib(what)
+    code = _cpu_dtype(x, "lsq_backward")
+    check_backward_dtypes(grad, x, scale, shift)
+    if per_channel:
+        check_channel_args(x, scale, shift, axis, backward=True)
+    C = scale.numel() if per_channel else 1
+    if x.numel() <= 0:  # lsq_cpu.cpp:76-78, :221-223 return (x, scale, shift) themselves
+        if want_wide:
+            return x.clone(), torch.zeros((2, C) if per_channel else (2,), dtype=torch.float64)
+        return x.clone(), scale.clone(), shift.clone()
+    _require_cpu(what, x, grad, scale, shift)
+    _require_param(what, scale, shift)
+    xd, order = _dense(x)
+    gd = _like_layout(grad, xd)
+    dx = torch.empty_like(xd)
+    pd = _param_dtype(x)
+    ds, db = torch.empty(C, dtype=pd), torch.empty(C, dtype=pd)
+    wide = torch.empty((2, C) if per_channel else (2,), dtype=torch.float64) if want_wide else None
+    _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode, numel_for_scaler)
+    sc, sh = scale.contiguous(), shift.contiguous()
+    wptr = wide.data_ptr() if want_wide else None
+    if per_channel:
+        outer, C_, inner = _ocl(xd, order, axis)
+        rc = lib.lsq_cpu_backward_per_channel(code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(), ds.data_ptr(), db.data_ptr(),
+                                              wptr, outer, C_, inner, sc.data_ptr(), sh.data_ptr(), pref)
+    else:
+        rc = lib.lsq_cpu_backward_per_tensor(code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(), ds.data_ptr(), db.data_ptr(),
+                                             wptr, xd.numel(), sc.data_ptr(), sh.data_ptr(), pref)
+    _cpu_status(rc, what)
+    if want_wide:
+        return dx, wide
+    return dx, ds, db
+
+
+def _cpu_minmax(x, axis=None):
+    """torch's own reductions: the stock observers' arithmetic (reference observers.py:446-449 calls them on CPU tensors)"""
+    y = x.detach().to(_param_dtype(x))
+    if axis is None:
+        return torch.aminmax(y)
+    dims = [d for d in range(x.dim()) if d != axis]
+    return torch.amin(y, dims), torch.amax(y, dims)
+
+
+def _cpu_meanstd(x, axis=None):
+    y = x.detach().to(_param_dtype(x))
+    if axis is None:
+        return y.mean(), y.std()
+    dims = [d for d in range(x.dim()) if d != axis]
+    return torch.mean(y, dims), torch.std(y, dims)
+
+
+_lib_cpu = torch.library.Library("torchlsq", "IMPL", "CPU")
+_lib_cpu.impl("lsq_forward_per_tensor", lambda x, s, b, *a: cpu_forward(x, s, b, 0, False, *a))
+_lib_cpu.impl("lsq_backward_per_tensor", lambda g, x, s, b, *a: cpu_backward(g, x, s, b, 0, False, *a))
+_lib_cpu.impl("lsq_forward_per_channel", lambda x, s, b, axis, *a: cpu_forward(x, s, b, axis, True, *a))
+_lib_cpu.impl("lsq_backward_per_channel", lambda g, x, s, b, axis, *a: cpu_backward(g, x, s, b, axis, True, *a))
+_lib_cpu.impl("lsq_backward_per_tensor_wide",
+              lambda g, x, s, b, *a: cpu_backward(g, x, s, b, 0, False, *a[:-1], numel_for_scaler=a[-1], want_wide=True))
+_lib_cpu.impl("lsq_backward_per_channel_wide",
+              lambda g, x, s, b, axis, *a: cpu_backward(g, x, s, b, axis, True, *a[:-1], numel_for_scaler=a[-1], want_wide=True))
+_lib_cpu.impl("lsq_minmax_per_tensor", lambda x: _cpu_minmax(x))
+_lib_cpu.impl("lsq_minmax_per_channel", lambda x, axis: _cpu_minmax(x, axis))
+_lib_cpu.impl("lsq_meanstd_per_tensor", lambda x: _cpu_meanstd(x))
+_lib_cpu.impl("lsq_meanstd_per_channel", lambda x, axis: _cpu_meanstd(x, axis))
 
 
 # -------------------------------------------------------------------------------------------------

@@ -12,9 +12,11 @@ every forward (observers.py:431-451) -- once the module lives on the GPU each te
 device synchronisation, four per call, which serialises the whole training step.  Here the buffers stay
 the persisted state (same names, dtypes and state_dict keys) but every decision reads a host-side
 mirror kept by the module's own methods; the mirror is re-read from the buffers after
-`load_state_dict` and on every `train()` / `eval()` call.  Change the flags through the methods
-(`enable_observer()`, `disable_fake_quant()`, `enable_static_estimate()`, ...), as the reference's own
-`apply` helpers do.
+`load_state_dict`, on every `train()` / `eval()` call, and whenever a buffer was written behind the
+module's back (`m.fake_quant_enabled[0] = 0`, `.fill_()`, `.copy_()`, a broadcast into the buffers, `.to(device)`):
+`forward` compares each buffer's identity and `Tensor._version` -- host-side counters, no device access -- with
+what it last saw, so such writes are honoured at the next call like in the reference, at the price of one
+re-read (a synchronisation) per out-of-band write, never in the steady state.
 
 Two deliberate differences from the reference, both turning a crash into the documented behaviour:
   * `LSQFakeQuantizer.with_args(...)` works (the reference calls `partial` without importing it,
@@ -230,17 +232,25 @@ class LSQFakeQuantizer(ObserverBase):
         self.register_buffer('learning_enabled', _flag(learn_params))
         self.register_buffer('current_batch', torch.tensor([0], dtype=torch.int64))
         self._h = {'fake_quant': 1, 'observer': 1, 'learning': int(learn_params), 'batch': 0}   # host mirror
+        self._stamp = self._buffer_stamp()
         self.enable_observer()           # applies the "observer not needed" rules below
 
     # ---- host mirror of the state buffers (no device synchronisation on the hot path) --------------
+    def _buffer_stamp(self):
+        """identity + version counter of the four state buffers: changes iff one was replaced or written in place"""
+        return tuple((id(b), b._version) for b in (self.fake_quant_enabled, self.observer_enabled,
+                                                   self.learning_enabled, self.current_batch))
+
     def _refresh_host_state(self):
-        """re-read the mirror from the buffers (after load_state_dict / train() / eval())"""
+        """re-read the mirror from the buffers (after load_state_dict / train() / eval() / an out-of-band write)"""
         self._h = {'fake_quant': int(self.fake_quant_enabled[0]), 'observer': int(self.observer_enabled[0]),
                    'learning': int(self.learning_enabled[0]), 'batch': int(self.current_batch[0])}
+        self._stamp = self._buffer_stamp()
 
     def _set_flag(self, name, buffer, value):
         buffer[0] = value                 # tiny async host-to-device write, never a sync
         self._h[name] = int(value)
+        self._stamp = self._buffer_stamp()
 
     def train(self, mode=True):
         out = super().train(mode)
@@ -379,6 +389,8 @@ class LSQFakeQuantizer(ObserverBase):
         if not self._initialized:
             self._init_weights(x)
             return x                        # the creating call passes its input through
+        if self._stamp != self._buffer_stamp():
+            self._refresh_host_state()       # a state buffer was written or replaced outside the module's methods
         h = self._h                          # host mirror: no device synchronisation below
         full_lsq = bool(h['learning'])
         backprop_init = False
@@ -394,6 +406,7 @@ class LSQFakeQuantizer(ObserverBase):
                 backprop_init = not last
             self.current_batch[0] += 1       # in place on the device, asynchronous
             h['batch'] += 1
+            self._stamp = self._buffer_stamp()
 
         if h['observer'] == 1:
             self.activation_post_process(x.detach())

@@ -83,17 +83,36 @@ def test_argument_validation_never_reaches_the_gpu():
     assert lib.lsq_hip_backward_per_tensor_workspace(0, 1 << 20) >= 256 * 8 * 16
 
 
-def test_no_cpu_fallback_in_the_product():
-    """CPU tensors must not be served silently: the dispatcher has no CPU kernel from the product."""
+def test_cpu_library_exports_its_header_and_devices_never_substitute():
+    """include/lsq_cpu.h <-> liblsq_cpu.so <-> the ctypes table; CPU tensors are served by the CPU kernels, and neither
+    device's kernels ever stand in for the other's: without the HIP library the package refuses CPU tensors too."""
+    import pytest
     import torch
     import torchlsq  # noqa: F401
-    import pytest
-    from conftest import _cpu_backend_lib
-    if _cpu_backend_lib:
-        pytest.skip("the oracle CPU plug is already installed in this process")
-    with pytest.raises(NotImplementedError):
-        torch.ops.torchlsq.lsq_forward_per_tensor(torch.randn(8), torch.ones(1), torch.zeros(1), 0, 127, 0, 255, True, 1.0,
-                                                  False, False, False)
+    from torchlsq import extension as E
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "lsq_cpu.h")).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(lsq_cpu_\w+)\s*\(", text)))
+    assert declared == sorted(E.C_ABI_CPU) and len(declared) == 6
+    cpu_lib = os.path.join(os.path.dirname(LIB), "liblsq_cpu.so")
+    nm = subprocess.run(["nm", "-D", "--defined-only", cpu_lib], capture_output=True, text=True, check=True).stdout
+    exported = set(l.split()[-1] for l in nm.splitlines() if " T " in l)
+    assert set(declared) <= exported
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", cpu_lib], capture_output=True, text=True, check=True).stdout
+    assert "hip" not in undefined.lower() and "lsq_oracle" not in undefined     # host code only, and not the oracle
+    x, s, b = torch.linspace(-1, 3, 64), torch.tensor([0.03]), torch.tensor([0.1])
+    y = torch.ops.torchlsq.lsq_forward_per_tensor(x, s, b, 0, 127, 0, 255, True, 1.0, False, False, False)
+    assert y.device.type == "cpu" and y.shape == x.shape and not torch.equal(y, x)
+    # the package is the MI355X build: no HIP library -> nothing works, CPU tensors included
+    saved = E._HAS_OPS
+    E._HAS_OPS = False
+    try:
+        with pytest.raises(RuntimeError, match="native HIP library could not be loaded"):
+            torch.ops.torchlsq.lsq_forward_per_tensor(x, s, b, 0, 127, 0, 255, True, 1.0, False, False, False)
+    finally:
+        E._HAS_OPS = saved
+    # a CPU parameter next to a GPU tensor (or the reverse) is an error, not a silent copy
+    with pytest.raises(RuntimeError, match="expected all tensors on the CPU"):
+        E.cpu_forward(x, s.to("meta"), b, 0, False, 0, 127, 0, 255, True, 1.0, False, False, False)
 
 
 def test_product_never_imports_the_oracle():
@@ -129,7 +148,7 @@ def test_cpp_torch_binding_uses_only_the_public_abi():
         a = str(getattr(ns, op).default._schema).split("(", 1)[1]
         b = str(getattr(ref, op).default._schema).split("(", 1)[1]
         assert a == b, (op, a, b)                       # argument lists identical to the reference schemas
-    # CPU tensors: no kernel registered and the composite refuses them -- never a fallback
+    # CPU tensors: this binding is the GPU host layer only -- no kernel registered for them, never a fallback
     x, s, b = torch.zeros(4), torch.ones(1), torch.zeros(1)
     import pytest
     with pytest.raises(NotImplementedError):

@@ -242,9 +242,22 @@ def test_host_mirror_tracks_buffers(oracle_cpu_backend):
     b(x)
     b.load_state_dict(a.state_dict())
     assert mirror(b) == bufs(b) == (0, 1, 0, 3)
-    b.fake_quant_enabled[0] = 1          # an out-of-band write is picked up at the next train()/eval()
+    b.fake_quant_enabled[0] = 1          # an out-of-band write is picked up at the next train()/eval() ...
     b.train()
     assert mirror(b) == bufs(b) == (1, 1, 0, 3)
+    # ... and at the next forward (the reference reads the buffers on every call): in-place writes, copies from
+    # another module and replaced buffers are all seen through the buffers' identity + version counters
+    b.fake_quant_enabled.fill_(0)
+    y = b(x)
+    assert mirror(b)[0] == 0 and y is x                     # fake-quant off: the input passes through
+    b.fake_quant_enabled[0] = 1
+    assert not torch.equal(b(x), x) and mirror(b)[0] == 1
+    b.observer_enabled.copy_(a.fake_quant_enabled)          # a's flag is 0
+    b(x)
+    assert mirror(b) == bufs(b)
+    b.learning_enabled = torch.ones_like(b.learning_enabled)  # buffer replaced (what .to(device) does)
+    b(x)
+    assert mirror(b) == bufs(b) and mirror(b)[2] == 1
     import copy, pickle
     assert mirror(copy.deepcopy(b)) == mirror(b) and mirror(pickle.loads(pickle.dumps(b))) == mirror(b)
 

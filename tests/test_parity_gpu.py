@@ -337,8 +337,10 @@ def test_errors_match_reference_checks(dev, host_binding):
         lsq(x, torch.ones(3, device=dev), torch.zeros(3, device=dev), is_perchannel=True)
     with pytest.raises(AssertionError):
         lsq(x, s, b, quant_min=1, quant_max=5, is_affine=False)
-    with pytest.raises(NotImplementedError):
-        lsq(x.cpu(), s.cpu(), b.cpu())       # no CPU fallback in this build
+    y_cpu = lsq(x.cpu(), s.cpu(), b.cpu())   # CPU tensors -> the CPU kernels (liblsq_cpu.so), same bits as the GPU's
+    assert y_cpu.device.type == "cpu" and torch.equal(y_cpu, lsq(x, s, b).cpu())
+    with pytest.raises(RuntimeError, match="expected all tensors on"):
+        lsq(x, s.cpu(), b)                   # devices are never mixed or substituted
 
 
 def test_backward_is_deterministic_and_graph_safe(dev):

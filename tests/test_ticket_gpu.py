@@ -72,7 +72,7 @@ def test_ticket_survives_many_launches_graphs_and_streams(E):
     want = E.hip_backward_per_tensor(g, x, scale, shift, *args, use_ticket=False)
     torch.cuda.synchronize()
     # back-to-back launches on one stream reuse one ticket
-    outs = [E.hip_backward_per_tensor(g, x, scale, shift, *args) for _ in range(200)]
+    outs = [E.hip_backward_per_tensor(g, x, scale, shift, *args, use_ticket=True) for _ in range(200)]
     torch.cuda.synchronize()
     for o in outs:
         assert _bits(o[1]) == _bits(want[1]) and _bits(o[2]) == _bits(want[2])
@@ -82,7 +82,7 @@ def test_ticket_survives_many_launches_graphs_and_streams(E):
     for rep in range(25):
         for st in streams:
             with torch.cuda.stream(st):
-                res.append(E.hip_backward_per_tensor(g, x, scale, shift, *args))
+                res.append(E.hip_backward_per_tensor(g, x, scale, shift, *args, use_ticket=True))
     torch.cuda.synchronize()
     for o in res:
         assert _bits(o[1]) == _bits(want[1]) and _bits(o[2]) == _bits(want[2]) and _bits(o[0]) == _bits(want[0])
@@ -91,7 +91,7 @@ def test_ticket_survives_many_launches_graphs_and_streams(E):
     with torch.cuda.stream(st):
         gr = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gr, stream=st):
-            captured = [E.hip_backward_per_tensor(g, x, scale, shift, *args) for _ in range(10)]
+            captured = [E.hip_backward_per_tensor(g, x, scale, shift, *args, use_ticket=True) for _ in range(10)]
     for _ in range(5):
         gr.replay()
     torch.cuda.synchronize()
@@ -110,6 +110,7 @@ def test_native_binding_uses_tickets_and_matches(E):
     args = (0, 127, 0, 255, True, 1.0, False, False, False)
     want = E.hip_backward_per_tensor(g, x, scale, shift, *args, use_ticket=False)
     nat = torch.ops.torchlsq_native
+    E.set_single_launch_backward(True)
     for _ in range(20):
         got = nat.lsq_backward_per_tensor(g, x, scale, shift, *args)
         for u, v in zip(got, want):
@@ -117,4 +118,5 @@ def test_native_binding_uses_tickets_and_matches(E):
     dx, wide = nat.lsq_backward_per_tensor_wide(g, x, scale, shift, *args, 4 * x.numel())
     dx2, wide2 = E.hip_backward_per_tensor(g, x, scale, shift, *args, numel_for_scaler=4 * x.numel(), want_wide=True,
                                            use_ticket=False)
+    E.set_single_launch_backward(False)
     assert _bits(wide) == _bits(wide2) and _bits(dx) == _bits(dx2)

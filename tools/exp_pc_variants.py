@@ -30,8 +30,10 @@ def timeit(fn, reps=20):
             ts.append(e0.elapsed_time(e1) / reps * 1e3)
     return sorted(ts)[len(ts) // 2]
 
-# usage: exp_pc_variants.py [outer C inner]   (default: BASELINE config 5 = 256 2048 49)
-GEOM = tuple(int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (256, 2048, 49)
+# usage: exp_pc_variants.py [--eval] [outer C inner]   (default: BASELINE config 5 = 256 2048 49)
+EVAL = "--eval" in sys.argv      # the dx-only backward: the streaming rate of the access pattern, almost no arithmetic
+_args = [a for a in sys.argv[1:] if a != "--eval"]
+GEOM = tuple(int(v) for v in _args[:3]) if len(_args) >= 3 else (256, 2048, 49)
 for dt, code in ((torch.float32, 0), (torch.bfloat16, 2)):
     outer, C, inner = GEOM
     n_ = outer * C * inner
@@ -42,7 +44,7 @@ for dt, code in ((torch.float32, 0), (torch.bfloat16, 2)):
     y = torch.empty_like(x); dx = torch.empty_like(x)
     ds = torch.empty(C, device=dev); db = torch.empty(C, device=dev)
     ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
-    p = LsqParams(-8, 7, -128, 127, 1, 0, 0, 0, 1.0, 0)
+    p = LsqParams(-8, 7, -128, 127, 1, 0, 1 if EVAL else 0, 0, 1.0, 0)
     n = x.numel(); esz = x.element_size()
     rows = []
     for unroll in (1, 2, 4, 8):
