@@ -28,6 +28,7 @@ struct Variant {
     bool nt_store;      // non-temporal stores (global_store ... nt)
     int blocks_per_cu;  // persistent-grid size = CUs * blocks_per_cu
     bool chunked;       // tile -> workgroup map: false = strided (tile t -> wg t % grid), true = contiguous chunks
+    int dma;            // window-mode backward, 16-byte packets: 0 = the storage type's default, 1 = registers, 2 = LDS-DMA ring
 };
 // encoded as unroll | nt_load << 8 | nt_store << 9 | chunked << 10 | blocks_per_cu << 16 ; 0 = "use the default"
 constexpr int encode_variant(int unroll, bool ntl, bool nts, int bpc) {
@@ -58,6 +59,7 @@ inline Variant decode_variant(int code, int dflt) {
     v.nt_store = ((code >> 9) & 1) != 0;
     v.blocks_per_cu = (code >> 16) & 0xff;
     v.chunked = ((code >> 10) & 1) != 0;
+    v.dma = (code >> 12) & 3;
     if (v.unroll != 1 && v.unroll != 2 && v.unroll != 4 && v.unroll != 8) v.unroll = 4;
     if (v.blocks_per_cu < 1) v.blocks_per_cu = 1;
     if (v.blocks_per_cu > kMaxBlocksPerCU) v.blocks_per_cu = kMaxBlocksPerCU;

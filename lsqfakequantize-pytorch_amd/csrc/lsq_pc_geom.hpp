@@ -55,6 +55,51 @@ __device__ __forceinline__ void store_elems(void* base, int64_t e, const typenam
     }
 }
 
+// ---- LDS-DMA (global -> LDS without passing through VGPRs) ------------------------------------------------------------
+// One wave-wide 16-byte-per-lane copy: lane l's 16 bytes at `gsrc` land at LDS byte offset `lds_dst` + 16 l (the
+// destination is wave-uniform base + lane x size; M0 carries the base).  The load is in flight without holding any
+// VGPR, which is the point: a streaming kernel whose registers are taken by its arithmetic can still keep several rows
+// of HBM requests outstanding per wave.  hipcc does not count asm memory operations in its s_waitcnt bookkeeping:
+// the reader orders itself with wait_vm<N>() below (cdna_hip_programming.md: LDS-DMA recipe, M0 rule).
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+// Wait until at most N of this wave's vector-memory operations are outstanding.  They complete in issue order on gfx9
+// (loads, stores and LDS-DMA share the one counter), so "at most N outstanding" = "everything but the youngest N is done".
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_vm_upto(int n) {     // n uniform; n > 15 waits as for 15 (longer than needed)
+    switch (n < 15 ? n : 15) {
+        case 0: wait_vm<0>(); break;
+        case 1: wait_vm<1>(); break;
+        case 2: wait_vm<2>(); break;
+        case 3: wait_vm<3>(); break;
+        case 4: wait_vm<4>(); break;
+        case 5: wait_vm<5>(); break;
+        case 6: wait_vm<6>(); break;
+        case 7: wait_vm<7>(); break;
+        case 8: wait_vm<8>(); break;
+        case 9: wait_vm<9>(); break;
+        case 10: wait_vm<10>(); break;
+        case 11: wait_vm<11>(); break;
+        case 12: wait_vm<12>(); break;
+        case 13: wait_vm<13>(); break;
+        case 14: wait_vm<14>(); break;
+        default: wait_vm<15>(); break;
+    }
+}
+// byte offset of a __shared__ address inside the workgroup's LDS allocation
+__device__ __forceinline__ uint32_t lds_offset_of(const void* p) {
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) char*)p));
+}
+constexpr int kDmaStageBytes = 2 * 64 * 16;     // one row of one wave: 64 grad packets, then 64 x packets
+
 struct PcGeom {
     int64_t outer, C, inner, L;
     int64_t wpos;            // positions per window (R == 1) or L (R > 1)
@@ -166,6 +211,14 @@ static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_
     return g;
 }
 
+// Dynamic LDS of the window-mode backward in front of the LDS-DMA ring: the channel table + fp64 slots (256-lane
+// windows) or the row-group combine buffer; the ring starts at the next 1 KiB boundary.
+static inline __host__ __device__ uint32_t bwd_lds_front_bytes(const PcGeom& g, uint32_t slot_bytes) {
+    const uint32_t front = g.ww_lanes ? static_cast<uint32_t>(g.R > 1 ? g.R - 1 : 1) * g.k_slots * 16u
+                                      : static_cast<uint32_t>(g.k_slots) * (slot_bytes + 16u);
+    return (front + 1023u) & ~1023u;
+}
+
 // Where a lane sits: position p0 of its first element, its row inside the tile, and whether it is live.
 struct LaneSite {
     int64_t p0;
@@ -209,11 +262,13 @@ __device__ __forceinline__ LaneSite lane_site_ww(const PcGeom& g, int V, int32_t
 // The rows a lane walks: o_begin, o_begin + step, ... (n_rows of them)
 struct RowWalk {
     int64_t o_begin, step, n_rows;
+    int64_t n_tiles_split;      // tiles of this workgroup's split: the same for every lane (n_rows is per lane)
     __device__ __forceinline__ RowWalk(const PcGeom& g, const LaneSite& site) {
         // split y of `splits` owns the row tiles [y * n_tiles / splits, (y + 1) * n_tiles / splits): sizes differ by at
         // most one tile (a uniform ceil(n / splits) leaves the last workgroup a short remainder and the rest too much)
         const int64_t t0 = static_cast<int64_t>(blockIdx.y) * g.n_tiles / g.splits;
         const int64_t t1 = static_cast<int64_t>(blockIdx.y + 1) * g.n_tiles / g.splits;
+        n_tiles_split = t1 - t0;
         o_begin = t0 * g.R + site.row_in_tile;
         const int64_t o_end = std::min<int64_t>(g.outer, t1 * g.R);
         step = g.R;

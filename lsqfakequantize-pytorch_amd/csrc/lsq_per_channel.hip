@@ -110,7 +110,9 @@ struct LaneChannels {
 // ------------------------------------------------------------------------------------------------
 // K3 (window mode): forward
 // ------------------------------------------------------------------------------------------------
-template <typename IO, int V, int CPL, bool INIT, bool LEVELS, int UNROLL, bool NTL, bool NTS>
+// DMA > 0: the rows arrive through an LDS-DMA ring of DMA stages per wave (see bwd_pc_kernel): DMA rows in flight per
+// wave and no load registers.
+template <typename IO, int V, int CPL, bool INIT, bool LEVELS, int UNROLL, bool NTL, bool NTS, int DMA = 0>
 __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                         int8_t* __restrict__ levels, int level_bias, int aux_kind, PcGeom g,
                                                         const typename IO::arith* __restrict__ scale,
@@ -126,10 +128,26 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
     // the first group of loads does not depend on the channel constants: put it in flight before the
     // table build (global loads of scale/shift + a division + a barrier) so the two latencies overlap
     E first[UNROLL][V];
-    const bool first_full = walk.n_rows >= UNROLL;
+    const bool first_full = DMA > 0 ? false : walk.n_rows >= UNROLL;
     if (first_full) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) load_elems<IO, V, NTL>(x, walk.row(u) * g.L + site.p0, first[u]);
+    }
+    // ---- LDS-DMA ring (DMA > 0): this wave's DMA stages of 64 x packets ----
+    static_assert(DMA == 0 || V * sizeof(E) == 16, "the LDS-DMA ring moves 16-byte packets");
+    constexpr int kStage = 64 * 16;
+    const int64_t dma_n = walk.n_tiles_split;
+    const uint32_t front = (static_cast<uint32_t>(g.k_slots) * static_cast<uint32_t>(sizeof(QSlot<T>)) + 1023u) & ~1023u;
+    unsigned char* ring = smem + front + (threadIdx.x >> 6) * (DMA * kStage);
+    const uint32_t ring_lds = DMA > 0 ? __builtin_amdgcn_readfirstlane(lds_offset_of(ring)) : 0u;
+    auto dma_issue = [&](int64_t i) {
+        int64_t row = walk.row(i);
+        row = row < g.outer ? row : g.outer - 1;
+        const int64_t e = row * g.L + (site.live ? site.p0 : 0);
+        glds16(static_cast<const E*>(x) + e, ring_lds + static_cast<uint32_t>(i % (DMA > 0 ? DMA : 1)) * kStage);
+    };
+    if constexpr (DMA > 0) {
+        for (int64_t i = 0; i < DMA && i < dma_n; ++i) dma_issue(i);
     }
     build_channel_table<T>(table, g.k_slots, site.c_lo, g.C, scale, shift, r);
     __syncthreads();
@@ -166,6 +184,29 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
         for (int u = 0; u < H; ++u) emit_row(walk.row(i0 + u), in[u], true);
     };
     int64_t i = 0;
+    if constexpr (DMA > 0) {
+        // one copy per row: younger than row i's are the copies of rows i+1 .. i+DMA-1 (the y stores in between are not
+        // counted: the wait is never too short)
+        const int lane = threadIdx.x & 63;
+        using V4 = __attribute__((ext_vector_type(4))) unsigned int;
+        auto consume = [&](int64_t it, bool refill) {
+            const V4 raw = *reinterpret_cast<const V4*>(ring + static_cast<uint32_t>(it % DMA) * kStage + lane * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (refill) dma_issue(it + DMA);
+            E in[V];
+            __builtin_memcpy(&in[0], &raw, 16);
+            emit_row(walk.row(it) < g.outer ? walk.row(it) : g.outer - 1, in, it < walk.n_rows);
+        };
+        for (; i + DMA < dma_n; ++i) {
+            wait_vm<DMA - 1>();
+            consume(i, true);
+        }
+        for (; i < dma_n; ++i) {
+            wait_vm_upto(static_cast<int>(dma_n - 1 - i));
+            consume(i, false);
+        }
+        return;
+    }
     if (first_full) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) emit_row(walk.row(u), first[u], true);
@@ -210,7 +251,13 @@ __device__ __forceinline__ void segmented_wave_accumulate(int key, double s, dou
 
 // WW: row-group windows (make_geom_ww: inner == 1, CPL == V) -- the lane's channels are its own, their constants are
 // computed from global memory into registers (no LDS table) and the epilogue sums the row groups in a fixed order.
-template <typename IO, int V, int CPL, bool SYM, bool INIT, bool EVAL, int UNROLL, bool NTL, bool NTS, bool PIPE, bool WW = false>
+// DMA > 0: the rows reach the wave through an LDS ring of DMA stages filled by LDS-DMA (glds16): DMA rows of HBM requests
+// stay in flight per wave without holding registers.  The arithmetic-heavy 16-bit kernels have no registers to spare for
+// more than one row of ordinary loads, and one row in flight per wave does not cover the HBM latency (the dx-only
+// kernel, which has the registers, streams the same tensor 20 % faster when all of a workgroup's loads are issued up
+// front: profiles/r02_pc_variants_eval.txt).
+template <typename IO, int V, int CPL, bool SYM, bool INIT, bool EVAL, int UNROLL, bool NTL, bool NTS, bool PIPE, bool WW = false,
+          int DMA = 0>
 __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__ grad, const void* __restrict__ x,
                                                         void* __restrict__ dx, PcGeom g,
                                                         const typename IO::arith* __restrict__ scale,
@@ -240,8 +287,25 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
         }
     };
     E first_g[UNROLL][V], first_x[UNROLL][V];   // first group in flight before the table build (see K3)
-    const bool first_full = PIPE ? walk.n_rows > 0 : walk.n_rows >= UNROLL;
+    const bool first_full = DMA > 0 ? false : (PIPE ? walk.n_rows > 0 : walk.n_rows >= UNROLL);
     if (first_full) load_group(first_g, first_x, 0);
+    // ---- LDS-DMA ring (DMA > 0): this wave's DMA stages; stage = [64 grad packets][64 x packets] ----
+    static_assert(DMA == 0 || V * sizeof(E) == 16, "the LDS-DMA ring moves 16-byte packets");
+    const int64_t dma_n = walk.n_tiles_split;                          // the same for every lane of the workgroup
+    unsigned char* ring = smem + bwd_lds_front_bytes(g, sizeof(QSlot<T>)) + (threadIdx.x >> 6) * (DMA * kDmaStageBytes);
+    const uint32_t ring_lds = DMA > 0 ? __builtin_amdgcn_readfirstlane(lds_offset_of(ring)) : 0u;
+    // row i of this lane, clamped into the tensor (rows past the lane's last one and dead lanes re-read valid memory)
+    auto dma_issue = [&](int64_t i) {
+        int64_t row = walk.row(i);
+        row = row < g.outer ? row : g.outer - 1;
+        const int64_t e = row * g.L + (site.live ? site.p0 : 0);
+        const uint32_t dst = ring_lds + static_cast<uint32_t>(i % (DMA > 0 ? DMA : 1)) * kDmaStageBytes;
+        glds16(static_cast<const E*>(grad) + e, dst);
+        glds16(static_cast<const E*>(x) + e, dst + 64 * 16);
+    };
+    if constexpr (DMA > 0) {
+        for (int64_t i = 0; i < DMA && i < dma_n; ++i) dma_issue(i);    // in flight before the constants are built
+    }
     LC ch;
     if constexpr (WW) {
         // channel p0 + j is component j's own: constants straight into registers (lsq_kernel.h:157-158 + :12)
@@ -302,7 +366,41 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
         for (int u = 0; u < UNROLL; ++u) emit_row(walk.row(i0 + u < last ? i0 + u : last), gb[u], xb[u], i0 + u <= last);
     };
     int64_t i = 0;
-    if (PIPE) {
+    if constexpr (DMA > 0) {
+        // Row i was requested DMA rows ago.  Younger than its two copies are the copies of rows i+1 .. i+DMA-1 (two each)
+        // and the dx stores in between; only the copies are counted (a wave without a valid lane skips its stores), so
+        // the wait is never too short and at least 2/3 of the ring stays in flight.
+        const int lane = threadIdx.x & 63;
+        using V4 = __attribute__((ext_vector_type(4))) unsigned int;
+        auto consume = [&](int64_t it, bool refill, auto all_valid) {
+            const unsigned char* stage = ring + static_cast<uint32_t>(it % DMA) * kDmaStageBytes + lane * 16;
+            const V4 graw = *reinterpret_cast<const V4*>(stage);
+            const V4 xraw = *reinterpret_cast<const V4*>(stage + 64 * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the stage is in registers: it may be refilled
+            if (refill) dma_issue(it + DMA);
+            E gi[V], xi[V];
+            __builtin_memcpy(&gi[0], &graw, 16);
+            __builtin_memcpy(&xi[0], &xraw, 16);
+            if constexpr (decltype(all_valid)::value) {
+                emit_row(walk.row(it), gi, xi, true);
+            } else {
+                emit_row(walk.row(it) < g.outer ? walk.row(it) : g.outer - 1, gi, xi, it < walk.n_rows);
+            }
+        };
+        auto loop = [&](auto all_valid) {
+            for (; i + DMA < dma_n; ++i) {           // steady state: the ring is full, one refill per row, no branches
+                wait_vm<2 * (DMA - 1)>();
+                consume(i, true, all_valid);
+            }
+            for (; i < dma_n; ++i) {                 // the last DMA rows: nothing left to request
+                wait_vm_upto(static_cast<int>(2 * (dma_n - 1 - i)));
+                consume(i, false, all_valid);
+            }
+        };
+        // every lane of this wave walks all dma_n rows (no dead lane, no ragged last tile): no per-row validity selects
+        if (__builtin_amdgcn_readfirstlane(__all(site.live && walk.n_rows == dma_n) ? 1 : 0)) loop(std::true_type{});
+        else loop(std::false_type{});
+    } else if (PIPE) {
         // Software pipeline, two register buffers: the loads of group k+1 are issued BEFORE the arithmetic of
         // group k, so every wave keeps HBM requests in flight while it computes (for 16-bit storage the VALU time
         // of a group is about its HBM time: without this the two only overlap across waves).
@@ -783,7 +881,7 @@ size_t bwd_pc_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64
                 const PcGeom g = make_geom(outer, channels, inner, vecs[vi], dev.cu_count * bpc, 27, dev.cu_count * res);
                 need = std::max(need, static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2));
             }
-            if (vi == 0 && inner == 1 && io_vec > 1) {
+            if (vi == 0 && inner == 1 && io_vec > 1 && channels % io_vec == 0) {
                 const int min_rows = (107 + (16 / io_vec) - 1) / (16 / io_vec);   // kWwMinRows of the storage type
                 for (int res = 0; res <= 8; ++res) {
                     const PcGeom g = make_geom_ww(outer, channels, io_vec, dev.cu_count * bpc, min_rows, dev.cu_count * res);
@@ -800,6 +898,19 @@ size_t bwd_pc_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64
 }
 
 
+// LDS-DMA ring in the window-mode kernels by default (A/B on one box, profiles/r02_dma_ab.txt: 8-16 % faster on every
+// large shape in both directions -- fp32 forward 6.4 TB/s, dx-only backward 6.3 TB/s -- and even on the rest), with the
+// grid it likes: fewer, longer workgroups than the register loops (it needs rows to keep its ring full).
+template <typename IO>
+constexpr bool kDmaDefault = true;
+template <typename IO>
+constexpr bool kFwdDmaDefault = true;
+template <typename IO>
+constexpr int kDmaBwdBlocksPerCU = sizeof(typename IO::elem) < 4 ? 4 : 8;
+template <typename IO>
+constexpr int kDmaFwdBlocksPerCU = sizeof(typename IO::elem) < 4 ? 4 : 8;
+constexpr int kFwdDmaDepth = 8;      // one 1 KiB stage per row and wave in the forward (x only); the backward rings are 4 deep
+
 // ---- forward --------------------------------------------------------------------------------------
 template <typename IO, int V, int CPL, bool INIT, bool LEVELS>
 static hipError_t launch_fwd_pc(const void* x, void* y, int8_t* levels, int bias, int aux_kind, const PcGeom& g, const void* scale,
@@ -808,6 +919,17 @@ static hipError_t launch_fwd_pc(const void* x, void* y, int8_t* levels, int bias
     const Range<T> r = make_range<T>(p);
     const dim3 grid(static_cast<unsigned>(g.n_windows), static_cast<unsigned>(g.splits));
     const size_t lds = static_cast<size_t>(g.k_slots) * sizeof(QSlot<T>);
+    // LDS-DMA ring (16-byte packets): forward_per_channel decided (v.dma == 2) and sized the grid for it
+    constexpr bool kDmaAble = V * sizeof(typename IO::elem) == 16;
+    constexpr int kDmaDepth = kFwdDmaDepth;
+    if constexpr (kDmaAble) {
+        const size_t lds_dma = ((lds + 1023) & ~size_t(1023)) + static_cast<size_t>(kBlock / 64) * kDmaDepth * 1024;
+        if (v.dma == 2 && lds_dma <= 64 * 1024) {
+            hipLaunchKernelGGL((fwd_pc_kernel<IO, V, CPL, INIT, LEVELS, 1, true, true, kDmaDepth>), grid, dim3(kBlock), lds_dma, stream,
+                               x, y, levels, bias, aux_kind, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r);
+            return hipGetLastError();
+        }
+    }
 #define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                       \
     hipLaunchKernelGGL((fwd_pc_kernel<IO, V, CPL, INIT, LEVELS, U, NTLF, NTSF>), grid, dim3(kBlock), lds, stream, x, y, levels, \
                        bias, aux_kind, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r)
@@ -869,12 +991,27 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
                       : launch_fwd_seg<IO, false, false>(x, y, levels, bias, aux_kind, sg, scale, shift, p, v, stream);
     }
     const int cpl = pick_cpl(vec, inner);
-    const PcGeom g = make_geom(outer, channels, inner, vec, target, kFwdPerSlotRows<IO>);
+    PcGeom g = make_geom(outer, channels, inner, vec, target, kFwdPerSlotRows<IO>);
+    // LDS-DMA ring (profiles/r02_dma_ab.txt): the default when a workgroup of the grid the ring likes walks at least as
+    // many rows as the ring is deep; not for small last-axis tensors, whose per-workgroup channel-table build wants many
+    // short workgroups ([64,197,768]: 14.7 us with 4-row workgroups, 17 us with the ring).  Bits 12-13 of the variant
+    // force either path (A/B runs).
+    Variant vv = v;
+    vv.dma = 1;
+    if (vec > 1 && vec * sizeof(typename IO::elem) == 16 && v.dma != 1 && (v.dma == 2 || kFwdDmaDefault<IO>)) {
+        const int tgt = variant == 0 ? dev.cu_count * kDmaFwdBlocksPerCU<IO> : target;
+        const PcGeom gd = make_geom(outer, channels, inner, vec, tgt, kFwdPerSlotRows<IO>);
+        const bool small_last_axis = cpl == vec && outer * channels * inner < (int64_t{1} << 24);
+        if (v.dma == 2 || (gd.n_tiles / std::max(1, gd.splits) >= kFwdDmaDepth && !small_last_axis)) {
+            g = gd;
+            vv.dma = 2;
+        }
+    }
     if (!grid_fits(g)) return hipErrorInvalidConfiguration;
-    if (vec == 1) return fwd_pc_modes<IO, 1, 1>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream);
-    if (cpl == 1) return fwd_pc_modes<IO, IO::VEC, 1>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream);
-    if (cpl == 2) return fwd_pc_modes<IO, IO::VEC, 2>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream);
-    return fwd_pc_modes<IO, IO::VEC, IO::VEC>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream);
+    if (vec == 1) return fwd_pc_modes<IO, 1, 1>(x, y, levels, bias, aux_kind, g, scale, shift, p, vv, stream);
+    if (cpl == 1) return fwd_pc_modes<IO, IO::VEC, 1>(x, y, levels, bias, aux_kind, g, scale, shift, p, vv, stream);
+    if (cpl == 2) return fwd_pc_modes<IO, IO::VEC, 2>(x, y, levels, bias, aux_kind, g, scale, shift, p, vv, stream);
+    return fwd_pc_modes<IO, IO::VEC, IO::VEC>(x, y, levels, bias, aux_kind, g, scale, shift, p, vv, stream);
 }
 
 // ---- backward -------------------------------------------------------------------------------------
@@ -895,10 +1032,12 @@ struct BwdPcCall {
     double2* partials;
     size_t workspace_bytes;
     int target_blocks;     // requested workgroups (CUs x workgroups per CU)
+    bool default_variant;  // the caller passed variant 0: the launcher may pick the grid of the code path it chooses
     bool whole_rounds;     // size the grid in whole rounds of what the chip holds at once (make_geom)
     Variant v;
     hipStream_t stream;
 };
+
 
 // rows a row-group-window workgroup walks at least: keeps its 16-byte-per-slot partial row under ~5 % of what it streams
 template <typename IO>
@@ -922,17 +1061,26 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
     hipError_t result = hipSuccess;
     // The geometry depends on how many workgroups of the chosen instantiation fit on the chip at once, so it is built
     // here, where the kernel is known, together with the launch and the finalize.
-    auto run = [&](auto kern) {
+    // returns false (nothing launched) when `min_tiles` is asked for and a workgroup would walk fewer row tiles than that
+    auto run = [&](auto kern, int dma_depth, int target_blocks, int64_t min_tiles) -> bool {
         const DeviceInfo& dev = device_info();
         const int per_cu = c.whole_rounds ? resident_blocks_per_cu(reinterpret_cast<const void*>(kern)) : 0;
-        const PcGeom g = WW ? make_geom_ww(c.outer, c.C, V, c.target_blocks, kWwMinRows<IO>, per_cu * dev.cu_count)
-                            : make_geom(c.outer, c.C, c.inner, V, c.target_blocks, 27, per_cu * dev.cu_count);
-        if (!grid_fits(g)) { result = hipErrorInvalidConfiguration; return; }
+        const PcGeom g = WW ? make_geom_ww(c.outer, c.C, V, target_blocks, kWwMinRows<IO>, per_cu * dev.cu_count)
+                            : make_geom(c.outer, c.C, c.inner, V, target_blocks, 27, per_cu * dev.cu_count);
+        if (g.n_tiles / std::max<int64_t>(1, g.splits) < min_tiles) return false;
+        if (!grid_fits(g)) { result = hipErrorInvalidConfiguration; return true; }
         const size_t need = static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2);
-        if (!p.eval_mode && c.workspace_bytes < need) { result = hipErrorInvalidValue; return; }
+        if (!p.eval_mode && c.workspace_bytes < need) { result = hipErrorInvalidValue; return true; }
         const dim3 grid(static_cast<unsigned>(g.n_windows), static_cast<unsigned>(g.splits));
-        const size_t lds = WW ? static_cast<size_t>(std::max(1, g.R - 1)) * g.k_slots * sizeof(double2)
-                              : static_cast<size_t>(g.k_slots) * (sizeof(QSlot<T>) + 2 * sizeof(double));
+        size_t lds = WW ? static_cast<size_t>(std::max(1, g.R - 1)) * g.k_slots * sizeof(double2)
+                        : static_cast<size_t>(g.k_slots) * (sizeof(QSlot<T>) + 2 * sizeof(double));
+        if (dma_depth > 0)
+            lds = bwd_lds_front_bytes(g, sizeof(QSlot<T>)) + static_cast<size_t>(g.block_threads / 64) * dma_depth * kDmaStageBytes;
+        if (lds > 64 * 1024) {
+            if (dma_depth > 0) return false;      // no room for the ring next to a very wide channel table: register loop
+            result = hipErrorInvalidConfiguration;
+            return true;
+        }
         {
             hipFuncAttributes fa;
             const int regs = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)) == hipSuccess ? fa.numRegs : -1;
@@ -941,7 +1089,7 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
         hipLaunchKernelGGL(kern, grid, dim3(g.block_threads), lds, c.stream, c.grad, c.x, c.dx, g, static_cast<const T*>(c.scale),
                            static_cast<const T*>(c.shift), r, c.gs, c.partials);
         result = hipGetLastError();
-        if (result != hipSuccess) return;
+        if (result != hipSuccess) return true;
         const int fin_ch = fin_channels(c.C);
         if (WW) {
             const unsigned fgrid = static_cast<unsigned>((g.n_windows * g.k_slots + fin_ch - 1) / fin_ch);
@@ -953,8 +1101,23 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
                                p.eval_mode ? 1 : 0, p.sym ? 1 : 0, c.sym_term, c.ds, c.db, c.wide);
         }
         result = hipGetLastError();
+        return true;
     };
-#define LSQ_LAUNCH_P(U, NTLF, NTSF, PIPEF) run(bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, U, NTLF, NTSF, PIPEF, WW>)
+    // LDS-DMA ring instead of register buffers (16-byte packets only): the default whenever a workgroup walks at least
+    // as many row tiles as the ring is deep -- with the grid the ring likes, kDmaBwdBlocksPerCU workgroups per CU;
+    // variant bits 12-13 force either path for A/B runs (1 = registers, 2 = ring).
+    constexpr bool kDmaAble = V * sizeof(typename IO::elem) == 16;
+    constexpr int kDmaDepth = 4;
+    if constexpr (kDmaAble) {
+        if (c.v.dma == 2 || (c.v.dma == 0 && kDmaDefault<IO>)) {
+            const int target = c.default_variant ? device_info().cu_count * kDmaBwdBlocksPerCU<IO> : c.target_blocks;
+            if (run(bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, 1, true, true, false, WW, kDmaDepth>, kDmaDepth, target,
+                    c.v.dma == 2 ? 0 : kDmaDepth))
+                return result;
+        }
+    }
+#define LSQ_LAUNCH_P(U, NTLF, NTSF, PIPEF) \
+    run(bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, U, NTLF, NTSF, PIPEF, WW>, 0, c.target_blocks, 0)
 #ifdef LSQ_TUNING
     // tuning builds compile both loops for the swept kernels; the switch is the variant's `chunked` bit (unused here)
     const bool pipe = kFull ? c.v.chunked : kNarrow;
@@ -1069,17 +1232,18 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
     // fatter workgroups win there in every shape swept (profiles/r01_lastaxis_sweep.txt: 2 per CU; [8192, 4096] fp32
     // 82 us against 100 us at 16 per CU, [200704, 256] 133 against 205).
     const bool last_axis = vecw > 1 && cpl == vecw;
-    if (last_axis && inner == 1) {
+    if (last_axis && inner == 1 && !(variant & (1 << 11))) {     // variant bit 11 (tools): the 256-lane windows instead, for A/B runs
         // the quantized axis is the last one ([tokens, features], channels-last): row-group windows, one round of what
         // the chip holds (variant: workgroups per CU requested, rounded to whole rounds)
         BwdPcCall<T> call{grad, x, dx, static_cast<T*>(ds), static_cast<T*>(db), wide, outer, channels, inner, scale, shift, &p,
                           gs, sym_term, partials, workspace_bytes, variant == 0 ? dev.cu_count * kWwBwdBlocksPerCU : target,
-                          /*whole_rounds=*/true, v, stream};
+                          /*default_variant=*/variant == 0, /*whole_rounds=*/true, v, stream};
         return bwd_pc_modes<IO, VB, VB, true>(call);
     }
     const int target_w = (variant == 0 && last_axis) ? dev.cu_count * kLastAxisBwdBlocksPerCU : target;
     BwdPcCall<T> call{grad, x, dx, static_cast<T*>(ds), static_cast<T*>(db), wide, outer, channels, inner, scale, shift, &p,
-                      gs, sym_term, partials, workspace_bytes, target_w, /*whole_rounds=*/!last_axis, v, stream};
+                      gs, sym_term, partials, workspace_bytes, target_w, /*default_variant=*/variant == 0,
+                      /*whole_rounds=*/!last_axis, v, stream};
     if (vecw == 1) return bwd_pc_modes<IO, 1, 1>(call);
     if (cpl == 1) return bwd_pc_modes<IO, VB, 1>(call);
     if (cpl == 2) return bwd_pc_modes<IO, VB, 2>(call);
