@@ -193,6 +193,37 @@ int lsq_hip_meanstd_per_channel(int dtype, const void* x, int64_t outer, int64_t
                                 void* mean_out, void* std_out, void* workspace, size_t workspace_bytes,
                                 void* stream);
 
+/* ---- observer-driven initialisation: the tail after the statistics pass ------------------------------ */
+
+/* ONE launch for what the reference module does with a dozen tiny tensor operations and several device
+ * synchronisations after every min/max pass of its initialisation batches (reference
+ * quantized/modules/observers.py:446-449: observer update, calculate_qparams, _set_weights):
+ *   1. fold the batch's per-channel min / max into the observer's running state, in place:
+ *        mode 1  running min / max         (torch MinMaxObserver / PerChannelMinMaxObserver)
+ *        mode 2  moving average            state += averaging_constant * (current - state)
+ *      `first`: 1 = the state is uninitialised, take the batch values; 0 = update; -1 = decide per element on the
+ *      device (state still at +inf / -inf: what the per-tensor torch observers test on the host);
+ *   2. derive (scale, zero_point) from the state exactly as torch's UniformQuantizationObserverBase._calculate_qparams
+ *      does (affine: scale = (max(max,0) - min(min,0)) * (1 / (quant_max - quant_min)), zero_point = clamp(quant_min -
+ *      rne(min / scale)); symmetric: scale = max(-min, max) * (1 / ((quant_max - quant_min) / 2)), zero_point =
+ *      `zero_point_symmetric`; scale >= eps), every operation individually rounded like the tensor operations it replaces;
+ *   3. store the LSQ parameters: scale_out = scale, shift_out = float(-zero_point) * scale (reference :346-373).
+ * fp32 state and parameters, `channels` of each (1 for per-tensor observers). */
+typedef struct lsq_observer_update {
+    int32_t mode;
+    int32_t first;
+    float averaging_constant;
+    int32_t quant_min;
+    int32_t quant_max;
+    int32_t symmetric;
+    int32_t zero_point_symmetric;
+    float eps;
+} lsq_observer_update;
+
+int lsq_hip_observer_update(int64_t channels, const float* cur_min, const float* cur_max, float* min_state,
+                            float* max_state, const lsq_observer_update* u, float* scale_out, float* shift_out,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -296,4 +296,16 @@ int lsq_hip_meanstd_per_channel(int dtype, const void* x, int64_t outer, int64_t
     return hip_status(e, "lsq_hip_meanstd_per_channel");
 }
 
+int lsq_hip_observer_update(int64_t channels, const float* cur_min, const float* cur_max, float* min_state,
+                            float* max_state, const lsq_observer_update* u, float* scale_out, float* shift_out, void* stream) {
+    if (channels <= 0) return fail(LSQ_EINVAL, "observer_update: channel count must be positive");
+    if (!cur_min || !cur_max || !min_state || !max_state || !u || !scale_out || !shift_out)
+        return fail(LSQ_EINVAL, "observer_update: NULL argument");
+    if (u->mode != 1 && u->mode != 2) return fail(LSQ_EINVAL, "observer_update: mode must be 1 (min/max) or 2 (moving average)");
+    if (u->quant_min >= u->quant_max) return fail(LSQ_EINVAL, "observer_update: quant_min %d >= quant_max %d", u->quant_min, u->quant_max);
+    return hip_status(lsq::observer_update(channels, cur_min, cur_max, min_state, max_state, *u, scale_out, shift_out,
+                                           static_cast<hipStream_t>(stream)),
+                      "lsq_hip_observer_update");
+}
+
 }  // extern "C"

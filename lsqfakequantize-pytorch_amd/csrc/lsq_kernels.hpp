@@ -120,7 +120,8 @@ inline const DeviceInfo& device_info() {
 // allocation: 512 VGPRs per SIMD lane, allocated in blocks of 8, at most 8 waves per SIMD.  0 = unknown.  (The HIP
 // occupancy API is one workgroup per CU too high for kernels with 81-112 SGPRs on this part, MI355X_MICROARCH.md, so the
 // count is derived from the register number instead.)  Immutable per kernel: cached after the first query.
-inline int resident_blocks_per_cu(const void* kernel) {
+inline int resident_blocks_per_cu(const void* kernel, size_t lds_bytes = 0);
+inline int resident_blocks_by_registers(const void* kernel) {
     static std::mutex mu;
     static std::vector<std::pair<const void*, int>> cache;
     std::lock_guard<std::mutex> lock(mu);
@@ -136,6 +137,13 @@ inline int resident_blocks_per_cu(const void* kernel) {
     }
     cache.emplace_back(kernel, waves);
     return waves;
+}
+
+// ... and the CU's 160 KiB of LDS allow (allocated in 1 KiB units here; the LDS-DMA rings take 32 KiB per workgroup)
+inline int resident_blocks_per_cu(const void* kernel, size_t lds_bytes) {
+    int n = resident_blocks_by_registers(kernel);
+    if (n > 0 && lds_bytes > 0) n = std::max(1, std::min<int>(n, static_cast<int>((160 * 1024) / ((lds_bytes + 1023) & ~size_t(1023)))));
+    return n;
 }
 
 // what the last window-mode backward launch of this thread looked like (tools/ only: lsq_hip_debug_last_launch)
@@ -287,5 +295,8 @@ hipError_t meanstd_per_tensor(const void* x, int64_t n, void* out_mean, void* ou
 template <typename IO>
 hipError_t meanstd_per_channel(const void* x, int64_t outer, int64_t channels, int64_t inner, void* out_mean,
                                void* out_std, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
+hipError_t observer_update(int64_t channels, const float* cur_min, const float* cur_max, float* min_state, float* max_state,
+                           const lsq_observer_update& u, float* scale_out, float* shift_out, hipStream_t stream);
 
 }  // namespace lsq

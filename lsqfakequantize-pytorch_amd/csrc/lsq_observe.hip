@@ -818,4 +818,60 @@ LSQ_INSTANTIATE(io_bf16)
 LSQ_INSTANTIATE(io_f16)
 #undef LSQ_INSTANTIATE
 
+// ------------------------------------------------------------------------------------------------
+// observer update + qparams + LSQ parameter store in one launch (lsq_hip_observer_update)
+// ------------------------------------------------------------------------------------------------
+// torch.min / torch.max of two tensors propagate NaN (unlike fmin / fmax)
+__device__ __forceinline__ float torch_min(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : (a < b ? a : b); }
+__device__ __forceinline__ float torch_max(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : (a > b ? a : b); }
+
+__global__ __launch_bounds__(kBlock) void observer_update_kernel(int64_t channels, const float* __restrict__ cur_min,
+                                                                 const float* __restrict__ cur_max, float* __restrict__ min_state,
+                                                                 float* __restrict__ max_state, lsq_observer_update u,
+                                                                 float inv_range, float* __restrict__ scale_out,
+                                                                 float* __restrict__ shift_out) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (c >= channels) return;
+    float mn = min_state[c], mx = max_state[c];
+    const float cmn = cur_min[c], cmx = cur_max[c];
+    const bool first = u.first == 1 || (u.first < 0 && mn == __builtin_inff() && mx == -__builtin_inff());
+    if (first) {
+        mn = cmn;
+        mx = cmx;
+    } else if (u.mode == 1) {
+        mn = torch_min(cmn, mn);
+        mx = torch_max(cmx, mx);
+    } else {      // min_val + averaging_constant * (min_val_cur - min_val): three tensor operations, three roundings
+        mn = mn + u.averaging_constant * (cmn - mn);
+        mx = mx + u.averaging_constant * (cmx - mx);
+    }
+    min_state[c] = mn;
+    max_state[c] = mx;
+    const float min_neg = torch_min(mn, 0.0f), max_pos = torch_max(mx, 0.0f);
+    float scale;
+    int zp;
+    if (u.symmetric) {
+        scale = torch_max(torch_max(-min_neg, max_pos) * inv_range, u.eps);      // tensor / python scalar = tensor * (1 / scalar)
+        zp = u.zero_point_symmetric;
+    } else {
+        scale = torch_max((max_pos - min_neg) * inv_range, u.eps);
+        const int q = u.quant_min - static_cast<int>(__builtin_rintf(min_neg / scale));
+        zp = q < u.quant_min ? u.quant_min : (q > u.quant_max ? u.quant_max : q);
+    }
+    scale_out[c] = scale;
+    shift_out[c] = static_cast<float>(-zp) * scale;
+}
+
+hipError_t observer_update(int64_t channels, const float* cur_min, const float* cur_max, float* min_state, float* max_state,
+                           const lsq_observer_update& u, float* scale_out, float* shift_out, hipStream_t stream) {
+    // ATen divides a tensor by a host scalar as a multiplication by its fp32 reciprocal (BinaryDivTrueKernel): same here
+    const float range = u.symmetric ? static_cast<float>(static_cast<double>(u.quant_max - u.quant_min) / 2.0)
+                                    : static_cast<float>(u.quant_max - u.quant_min);
+    const float inv_range = 1.0f / range;
+    const unsigned grid = static_cast<unsigned>((channels + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(observer_update_kernel, dim3(grid), dim3(kBlock), 0, stream, channels, cur_min, cur_max, min_state,
+                       max_state, u, inv_range, scale_out, shift_out);
+    return hipGetLastError();
+}
+
 }  // namespace lsq

@@ -115,14 +115,38 @@ struct PcGeom {
     int32_t block_threads;   // workgroup size to launch (kBlock except for row-group windows)
 };
 
+// How many workgroups along the row axis?  `want` is what the caller asked for (workgroups per CU x CUs / windows).
+// A kernel whose workgroups all take about the same time finishes in whole "rounds" of what the chip holds at once
+// (`resident_blocks`, 0 = unknown): 980 workgroups on a chip that holds 768 take as long as 1536 would -- the VALU-heavy
+// 16-bit backward measured exactly that, two rounds of ~19 us with the second three quarters empty.  So among the split
+// counts around `want` ([want/2, 2 want]) take the one closest to `want` whose last round is at least 90 % full, or the
+// fullest one if there is none.
+static inline int64_t pick_splits(int64_t n_windows, int64_t want, int64_t max_splits, int64_t resident_blocks) {
+    want = std::max<int64_t>(1, std::min(want, max_splits));
+    if (resident_blocks <= 0 || n_windows >= 2 * resident_blocks) return want;      // many rounds anyway: the tail is small
+    const int64_t lo = std::max<int64_t>(1, want / 2), hi = std::min(max_splits, 2 * want);
+    int64_t best = want;
+    double best_fill = -1.0;
+    int64_t best_dist = 0;
+    for (int64_t sp = lo; sp <= hi; ++sp) {
+        const int64_t total = n_windows * sp, rounds = (total + resident_blocks - 1) / resident_blocks;
+        const double fill = static_cast<double>(total) / static_cast<double>(rounds * resident_blocks);
+        const int64_t dist = sp > want ? sp - want : want - sp;
+        const bool good = fill >= 0.9, best_good = best_fill >= 0.9;
+        if (best_fill < 0 || (good && !best_good) || (good && best_good && dist < best_dist) ||
+            (!good && !best_good && fill > best_fill)) {
+            best = sp; best_fill = fill; best_dist = dist;
+        }
+    }
+    return best;
+}
+
 // per_slot_rows: rows a workgroup should walk per (slot / lane-position) of per-workgroup overhead.  27 for the
 // kernels that write a 16-byte partial per slot (backward, statistics); the forward only rebuilds its channel
 // table per workgroup and passes 4.
-// resident_blocks: how many workgroups of THIS kernel the chip holds at once (CUs x the occupancy its registers allow),
-// 0 = unknown.  A kernel whose workgroups all take about the same time finishes in whole "rounds": 980 workgroups on a
-// chip that holds 768 take as long as 1536 would (the VALU-heavy 16-bit backward measured exactly that: two rounds of
-// ~19 us, the second three quarters empty).  With resident_blocks the split count is a multiple of what fits in one
-// round, floor(resident_blocks / n_windows), and the rows are dealt out evenly (RowWalk).
+// resident_blocks: how many workgroups of THIS kernel the chip holds at once (CUs x the occupancy its registers and LDS
+// allow), 0 = unknown: the split count is chosen so that the last round of workgroups is nearly full (pick_splits); the
+// rows are dealt out evenly (RowWalk).
 static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec, int target_blocks, int per_slot_rows = 27,
                                int resident_blocks = 0) {
     PcGeom g;
@@ -154,13 +178,7 @@ static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec,
     // workgroups of 4 rows, not 4096 of 3-or-4 (every workgroup rebuilds the window's channel table)
     const int64_t tiles_each = std::max<int64_t>((g.n_tiles + want_splits - 1) / want_splits, min_tiles);
     int64_t splits = std::max<int64_t>(1, (g.n_tiles + tiles_each - 1) / tiles_each);
-    const int64_t per_round = resident_blocks > 0 ? resident_blocks / g.n_windows : 0;
-    if (per_round >= 1 && splits >= per_round) {
-        // whole rounds: the nearest multiple of per_round that the row count allows (at least one round)
-        int64_t k = std::max<int64_t>(1, (splits + per_round / 2) / per_round);
-        while (k > 1 && k * per_round > max_splits) --k;
-        if (k * per_round <= max_splits) splits = k * per_round;
-    }
+    if (resident_blocks > 0) splits = pick_splits(g.n_windows, splits, max_splits, resident_blocks);
     splits = std::min<int64_t>(splits, 65535);
     g.splits = static_cast<int32_t>(splits);
     g.rows_per_split = (g.n_tiles + splits - 1) / splits * g.R;
@@ -199,12 +217,7 @@ static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_
     const int64_t max_splits = std::max<int64_t>(1, g.n_tiles / min_tiles);
     int64_t splits = std::max<int64_t>(1, (target_blocks + g.n_windows - 1) / g.n_windows);
     splits = std::min(splits, max_splits);
-    const int64_t per_round = resident_blocks > 0 ? resident_blocks / g.n_windows : 0;
-    if (per_round >= 1 && splits >= per_round) {
-        int64_t k = std::max<int64_t>(1, (splits + per_round / 2) / per_round);
-        while (k > 1 && k * per_round > max_splits) --k;
-        if (k * per_round <= max_splits) splits = k * per_round;
-    }
+    if (resident_blocks > 0) splits = pick_splits(g.n_windows, splits, max_splits, resident_blocks);
     splits = std::min<int64_t>(splits, 65535);
     g.splits = static_cast<int32_t>(splits);
     g.rows_per_split = (g.n_tiles + splits - 1) / splits * g.R;

@@ -876,7 +876,7 @@ size_t bwd_pc_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64
     size_t need = 0;
     const int vecs[3] = {io_vec, 1, 4};   // full packets, single elements, half packets (16-bit window backward)
     for (int vi = 0; vi < 3; ++vi) {
-        for (int bpc = 1; bpc <= kMaxBlocksPerCU; ++bpc) {
+        for (int bpc = 1; bpc <= 2 * kMaxBlocksPerCU; ++bpc) {   // pick_splits may go up to twice the requested count
             for (int res = 0; res <= 8; ++res) {   // residency of the instantiation that will run: 0 (not used) .. 8 per CU
                 const PcGeom g = make_geom(outer, channels, inner, vecs[vi], dev.cu_count * bpc, 27, dev.cu_count * res);
                 need = std::max(need, static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2));
@@ -1064,23 +1064,31 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
     // returns false (nothing launched) when `min_tiles` is asked for and a workgroup would walk fewer row tiles than that
     auto run = [&](auto kern, int dma_depth, int target_blocks, int64_t min_tiles) -> bool {
         const DeviceInfo& dev = device_info();
-        const int per_cu = c.whole_rounds ? resident_blocks_per_cu(reinterpret_cast<const void*>(kern)) : 0;
-        const PcGeom g = WW ? make_geom_ww(c.outer, c.C, V, target_blocks, kWwMinRows<IO>, per_cu * dev.cu_count)
-                            : make_geom(c.outer, c.C, c.inner, V, target_blocks, 27, per_cu * dev.cu_count);
-        if (g.n_tiles / std::max<int64_t>(1, g.splits) < min_tiles) return false;
-        if (!grid_fits(g)) { result = hipErrorInvalidConfiguration; return true; }
-        const size_t need = static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2);
-        if (!p.eval_mode && c.workspace_bytes < need) { result = hipErrorInvalidValue; return true; }
-        const dim3 grid(static_cast<unsigned>(g.n_windows), static_cast<unsigned>(g.splits));
-        size_t lds = WW ? static_cast<size_t>(std::max(1, g.R - 1)) * g.k_slots * sizeof(double2)
-                        : static_cast<size_t>(g.k_slots) * (sizeof(QSlot<T>) + 2 * sizeof(double));
-        if (dma_depth > 0)
-            lds = bwd_lds_front_bytes(g, sizeof(QSlot<T>)) + static_cast<size_t>(g.block_threads / 64) * dma_depth * kDmaStageBytes;
+        auto geom = [&](int resident) {
+            return WW ? make_geom_ww(c.outer, c.C, V, target_blocks, kWwMinRows<IO>, resident)
+                      : make_geom(c.outer, c.C, c.inner, V, target_blocks, 27, resident);
+        };
+        auto lds_of = [&](const PcGeom& gg) {
+            size_t b = WW ? static_cast<size_t>(std::max(1, gg.R - 1)) * gg.k_slots * sizeof(double2)
+                          : static_cast<size_t>(gg.k_slots) * (sizeof(QSlot<T>) + 2 * sizeof(double));
+            if (dma_depth > 0)
+                b = bwd_lds_front_bytes(gg, sizeof(QSlot<T>)) + static_cast<size_t>(gg.block_threads / 64) * dma_depth * kDmaStageBytes;
+            return b;
+        };
+        // the LDS a workgroup needs does not depend on the split count: size it first, then the residency, then the grid
+        const size_t lds = lds_of(geom(0));
         if (lds > 64 * 1024) {
             if (dma_depth > 0) return false;      // no room for the ring next to a very wide channel table: register loop
             result = hipErrorInvalidConfiguration;
             return true;
         }
+        const int per_cu = c.whole_rounds ? resident_blocks_per_cu(reinterpret_cast<const void*>(kern), lds) : 0;
+        const PcGeom g = geom(per_cu * dev.cu_count);
+        if (g.n_tiles / std::max<int64_t>(1, g.splits) < min_tiles) return false;
+        if (!grid_fits(g)) { result = hipErrorInvalidConfiguration; return true; }
+        const size_t need = static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2);
+        if (!p.eval_mode && c.workspace_bytes < need) { result = hipErrorInvalidValue; return true; }
+        const dim3 grid(static_cast<unsigned>(g.n_windows), static_cast<unsigned>(g.splits));
         {
             hipFuncAttributes fa;
             const int regs = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)) == hipSuccess ? fa.numRegs : -1;

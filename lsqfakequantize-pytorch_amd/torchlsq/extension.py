@@ -50,6 +50,13 @@ class LsqBwdExtras(ctypes.Structure):
     _fields_ = [("ticket", ctypes.c_void_p)]
 
 
+class LsqObserverUpdate(ctypes.Structure):
+    """struct lsq_observer_update (include/lsq_hip.h)."""
+    _fields_ = [("mode", ctypes.c_int32), ("first", ctypes.c_int32), ("averaging_constant", ctypes.c_float),
+                ("quant_min", ctypes.c_int32), ("quant_max", ctypes.c_int32), ("symmetric", ctypes.c_int32),
+                ("zero_point_symmetric", ctypes.c_int32), ("eps", ctypes.c_float)]
+
+
 LSQ_TICKET_BYTES = 4096
 ABI_VERSION = 2
 
@@ -78,6 +85,7 @@ C_ABI = {
     "lsq_hip_meanstd_workspace": (_sz, [_int, _i64, _i64, _i64]),
     "lsq_hip_meanstd_per_tensor": (_int, [_int, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "lsq_hip_meanstd_per_channel": (_int, [_int, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "lsq_hip_observer_update": (_int, [_i64, _vp, _vp, _vp, _vp, ctypes.POINTER(LsqObserverUpdate), _vp, _vp, _vp]),
 }
 # tuning twins (csrc/lsq_internal.h): same signatures + a trailing launch-variant code
 C_ABI_INTERNAL = {
@@ -699,6 +707,34 @@ def _two_stats(x, axis, what, ws_fn, pt_fn, pc_fn):
     if axis is None:
         return a.reshape(()), b.reshape(())
     return a, b
+
+
+_OBS_UPDATE_CACHE = {}
+
+
+def hip_observer_update(cur_min, cur_max, min_state, max_state, scale_out, shift_out, mode, first, averaging_constant,
+                        quant_min, quant_max, symmetric, zero_point_symmetric, eps):
+    """One launch: fold the batch's min / max into an observer's running state (in place), derive torch's qparams
+    from it and store the LSQ parameters scale / shift = -zero_point * scale (lsq_hip_observer_update).  All fp32,
+    one element per channel; nothing is read back to the host."""
+    _assert_has_ops()
+    tensors = (cur_min, cur_max, min_state, max_state, scale_out, shift_out)
+    _require_gpu("lsq_observer_update", *tensors)
+    n = min_state.numel()
+    for t in tensors:
+        _check(t.dtype == torch.float32 and t.numel() == n and t.is_contiguous(),
+               "lsq_observer_update: every tensor must be a contiguous float32 tensor with one element per channel")
+    key = (mode, first, float(averaging_constant), quant_min, quant_max, bool(symmetric), zero_point_symmetric, float(eps))
+    hit = _OBS_UPDATE_CACHE.get(key)
+    if hit is None:
+        u = LsqObserverUpdate(int(mode), int(first), float(averaging_constant), int(quant_min), int(quant_max),
+                              int(bool(symmetric)), int(zero_point_symmetric), float(eps))
+        hit = _OBS_UPDATE_CACHE[key] = (u, ctypes.byref(u))
+    idx = min_state.device.index
+    rc = _on_device(idx, _LIB.lsq_hip_observer_update, n, cur_min.data_ptr(), cur_max.data_ptr(), min_state.data_ptr(),
+                    max_state.data_ptr(), hit[1], scale_out.data_ptr(), shift_out.data_ptr(), _stream_of(idx))
+    if rc:
+        _status(rc, "lsq_hip_observer_update")
 
 
 def hip_minmax(x, axis=None):

@@ -10,6 +10,12 @@ semantics incl. NaN propagation).  CPU tensors take the stock code path.
 
 LSQFakeQuantizer swaps a stock class for its subclass automatically (`accelerated(observer_cls)`), so
 user code keeps passing `MovingAverageMinMaxObserver` etc.
+
+`lsq_fused_step` goes one step further for the module's initialisation batches: after the statistics pass ONE more
+launch (`lsq_hip_observer_update`) updates the observer's running state, derives torch's qparams from it and
+writes the module's `scale` / `shift` parameters -- instead of the stock sequence "update buffers, calculate_qparams,
+_set_weights", which is a dozen tiny tensor kernels and several host synchronisations (`if min_val == inf`,
+`check_min_max_valid`, `float(scale)`) per call.  Same numbers, bit for bit (tests/test_parity_gpu.py).
 """
 import torch
 from torch.ao.quantization.observer import (MinMaxObserver, MovingAverageMinMaxObserver,
@@ -27,7 +33,45 @@ def _fast(x, buf):
     return buf.dtype == want
 
 
+def _fused_step(obs, x, scale_param, shift_param, mode, per_channel):
+    """statistics pass + one update launch; False when the stock path must be taken instead"""
+    from torchlsq import extension as E
+    if not (_fast(x, obs.min_val) and obs.min_val.dtype == torch.float32 and scale_param.dtype == torch.float32
+            and obs.qscheme in (torch.per_tensor_affine, torch.per_tensor_symmetric, torch.per_channel_affine,
+                                torch.per_channel_symmetric)):
+        return False
+    n = x.shape[obs.ch_axis] if per_channel else 1
+    if scale_param.numel() != n or shift_param.numel() != n or not (scale_param.is_cuda and shift_param.is_cuda):
+        return False
+    if per_channel:
+        cur_min, cur_max = torch.ops.torchlsq.lsq_minmax_per_channel(x.detach(), obs.ch_axis)
+        first = 0
+        if obs.min_val.numel() == 0 or obs.max_val.numel() == 0:      # host-side fact: the buffers are still empty
+            obs.min_val.resize_(cur_min.shape)
+            obs.max_val.resize_(cur_max.shape)
+            first = 1
+    else:
+        cur_min, cur_max = torch.ops.torchlsq.lsq_minmax_per_tensor(x.detach())
+        cur_min, cur_max = cur_min.reshape(1), cur_max.reshape(1)
+        first = -1                                                     # +inf / -inf state: decided on the device
+    eps = getattr(obs, "_lsq_eps", None)
+    if eps is None:                                                    # read the observer's eps buffer once
+        eps = obs._lsq_eps = float(obs.eps)
+    symmetric = obs.qscheme in (torch.per_tensor_symmetric, torch.per_channel_symmetric)
+    zp_sym = 0
+    if obs.dtype in (torch.quint8, torch.uint8):
+        zp_sym = (obs.quant_min + obs.quant_max) // 2 if obs.has_customized_qrange else 128
+    min_state = obs.min_val if obs.min_val.dim() else obs.min_val.view(1)
+    max_state = obs.max_val if obs.max_val.dim() else obs.max_val.view(1)
+    E.hip_observer_update(cur_min, cur_max, min_state, max_state, scale_param.data, shift_param.data, mode, first,
+                          getattr(obs, "averaging_constant", 0.0), obs.quant_min, obs.quant_max, symmetric, zp_sym, eps)
+    return True
+
+
 class HipMinMaxObserver(MinMaxObserver):
+    def lsq_fused_step(self, x, scale_param, shift_param):
+        return _fused_step(self, x, scale_param, shift_param, 1, False)
+
     def forward(self, x_orig):
         if not _fast(x_orig, self.min_val):
             return super().forward(x_orig)
@@ -38,6 +82,9 @@ class HipMinMaxObserver(MinMaxObserver):
 
 
 class HipMovingAverageMinMaxObserver(MovingAverageMinMaxObserver):
+    def lsq_fused_step(self, x, scale_param, shift_param):
+        return _fused_step(self, x, scale_param, shift_param, 2, False)
+
     def forward(self, x_orig):
         if not _fast(x_orig, self.min_val):
             return super().forward(x_orig)
@@ -54,6 +101,9 @@ class HipMovingAverageMinMaxObserver(MovingAverageMinMaxObserver):
 
 
 class HipPerChannelMinMaxObserver(PerChannelMinMaxObserver):
+    def lsq_fused_step(self, x, scale_param, shift_param):
+        return _fused_step(self, x, scale_param, shift_param, 1, True)
+
     def _forward(self, x_orig):
         if not _fast(x_orig, self.min_val):
             return super()._forward(x_orig)
@@ -72,6 +122,9 @@ class HipPerChannelMinMaxObserver(PerChannelMinMaxObserver):
 
 
 class HipMovingAveragePerChannelMinMaxObserver(MovingAveragePerChannelMinMaxObserver):
+    def lsq_fused_step(self, x, scale_param, shift_param):
+        return _fused_step(self, x, scale_param, shift_param, 2, True)
+
     def forward(self, x_orig):
         if not _fast(x_orig, self.min_val):
             return super().forward(x_orig)

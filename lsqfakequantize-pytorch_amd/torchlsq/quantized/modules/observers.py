@@ -135,6 +135,7 @@ class LSQFakeQuantizer(ObserverBase):
         debug_mode: forward is the identity.
     """
     init_modes = ('learnable', 'observer')
+    fuse_observer_tail = True     # observer-driven init batches on the GPU: one launch after the statistics pass
 
     @staticmethod
     def sign(x):
@@ -409,9 +410,14 @@ class LSQFakeQuantizer(ObserverBase):
             self._stamp = self._buffer_stamp()
 
         if h['observer'] == 1:
-            self.activation_post_process(x.detach())
-            scale, zero_point = self.activation_post_process.calculate_qparams()
-            self._set_weights(scale=scale, zero_point=zero_point)
+            obs = self.activation_post_process
+            fused = getattr(obs, 'lsq_fused_step', None) if self.fuse_observer_tail else None
+            # GPU fast path: statistics pass + ONE launch that updates the observer state, derives the qparams and
+            # writes scale / shift, nothing read back to the host (hip_observers.py); otherwise the reference sequence
+            if fused is None or not fused(x.detach(), self.scale, self.shift):
+                obs(x.detach())
+                scale, zero_point = obs.calculate_qparams()
+                self._set_weights(scale=scale, zero_point=zero_point)
 
         if h['fake_quant'] == 1:
             backprop_init = bool(backprop_init and full_lsq)

@@ -83,6 +83,13 @@ def test_streaming_kernels_move_16_byte_packets(kernels):
     picked = [n for n in kernels if re.search(r"(fwd_pt_kernel|bwd_pt_kernel|fwd_pc_kernel|bwd_pc_kernel|fwd_seg_kernel|bwd_seg_kernel)"
                                               r"INS_(6io_f32|7io_bf16|6io_f16|6io_f64)ELi(4|8|2)", n)]
     assert len(picked) > 20
+    rings = 0
     for name in picked:
         ops = _ops(kernels[name][0])
-        assert "global_load_dwordx4" in ops and "global_store_dwordx4" in ops, name
+        # 16-byte packets in: ordinary loads, or the LDS-DMA ring's global -> LDS copies read back with ds_read_b128
+        if "global_load_lds_dwordx4" in ops:
+            rings += 1
+            assert "ds_read_b128" in ops and "global_store_dwordx4" in ops, name
+        else:
+            assert "global_load_dwordx4" in ops and "global_store_dwordx4" in ops, name
+    assert rings > 10       # the window-mode per-channel kernels ship with their LDS-DMA variants

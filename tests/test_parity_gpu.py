@@ -567,6 +567,52 @@ def test_accelerated_observers_equal_stock_observers(dev):
         assert list(a.state_dict().keys()) == list(b.state_dict().keys())
 
 
+@pytest.mark.parametrize("kind", ["act_pt_affine", "act_pt_symmetric", "act_pc_affine", "weightless_minmax", "custom_range"])
+def test_fused_observer_tail_equals_the_reference_sequence(dev, kind):
+    """Initialisation batches of an observer-driven quantizer on the GPU: the one-launch tail (observer state update +
+    torch's qparams + scale / shift store, lsq_hip_observer_update) leaves the module in EXACTLY the state the reference
+    sequence -- observer forward, calculate_qparams, _set_weights -- leaves it in, batch after batch, and (from the second
+    observed batch on) without a single host synchronisation."""
+    from torch.ao.quantization import observer as O
+    from torchlsq import synth
+    from torchlsq.quantized import LSQFakeQuantizer
+    cfg = {
+        "act_pt_affine": (O.MovingAverageMinMaxObserver, dict(), (8, 16, 9, 9)),
+        "act_pt_symmetric": (O.MovingAverageMinMaxObserver, dict(qscheme=torch.per_tensor_symmetric), (8, 16, 9, 9)),
+        "act_pc_affine": (O.MovingAveragePerChannelMinMaxObserver, dict(qscheme=torch.per_channel_affine), (8, 16, 9, 9)),
+        "weightless_minmax": (O.MinMaxObserver, dict(avoid_torch_overflow=False), (4, 8, 33)),
+        "custom_range": (O.PerChannelMinMaxObserver, dict(qscheme=torch.per_channel_symmetric, quant_min=0, quant_max=15),
+                         (8, 16, 9, 9)),
+    }[kind]
+    obs_cls, kw, shape = cfg
+    n = int(np.prod(shape))
+
+    def make(fused):
+        m = LSQFakeQuantizer(obs_cls, "activation", init_batches=6, **kw).to(dev)
+        m.fuse_observer_tail = fused
+        return m
+
+    a, b = make(True), make(False)
+    for step in range(6):
+        x = synth.normal_like(n, 300 + step, 0.3 * step - 0.4, 1.0 + 0.2 * step, device=dev).view(shape)
+        if step == 2:                        # from here on the fused module must not touch the host
+            torch.cuda.synchronize()
+            torch.cuda.set_sync_debug_mode("error")
+        try:
+            ya = a(x)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        yb = b(x)
+        if step == 0:
+            continue                         # the creating call passes its input through
+        oa, ob = a.activation_post_process, b.activation_post_process
+        assert torch.equal(oa.min_val.reshape(-1), ob.min_val.reshape(-1)), (kind, step)
+        assert torch.equal(oa.max_val.reshape(-1), ob.max_val.reshape(-1)), (kind, step)
+        assert torch.equal(a.scale, b.scale) and torch.equal(a.shift, b.shift), (kind, step, a.scale, b.scale, a.shift, b.shift)
+        assert torch.equal(ya, yb)
+    assert a.state_dict().keys() == b.state_dict().keys()
+
+
 def test_steady_state_forward_backward_never_synchronises(dev, host_binding):
     """After the init phase a quantizer call must not block on the device: the reference tests its state
     buffers with Python `if`s (4 device syncs per call on the GPU); here decisions read a host mirror and
