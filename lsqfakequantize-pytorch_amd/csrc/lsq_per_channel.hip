@@ -1117,7 +1117,10 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
     constexpr bool kDmaAble = V * sizeof(typename IO::elem) == 16;
     constexpr int kDmaDepth = 4;
     if constexpr (kDmaAble) {
-        if (c.v.dma == 2 || (c.v.dma == 0 && kDmaDefault<IO>)) {
+        // (4- and 8-byte storage with one channel per lane, CPL == 1, keeps its register loop: it already has eight loads
+        // in flight per lane and few registers, the ring only adds its LDS round trip -- measured 3-6 % slower)
+        constexpr bool kDefaultHere = kDmaDefault<IO> && (sizeof(typename IO::elem) < 4 || CPL >= 2);
+        if (c.v.dma == 2 || (c.v.dma == 0 && kDefaultHere)) {
             const int target = c.default_variant ? device_info().cu_count * kDmaBwdBlocksPerCU<IO> : c.target_blocks;
             if (run(bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, 1, true, true, false, WW, kDmaDepth>, kDmaDepth, target,
                     c.v.dma == 2 ? 0 : kDmaDepth))

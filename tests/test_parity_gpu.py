@@ -578,11 +578,12 @@ def test_fused_observer_tail_equals_the_reference_sequence(dev, kind):
     from torchlsq.quantized import LSQFakeQuantizer
     cfg = {
         "act_pt_affine": (O.MovingAverageMinMaxObserver, dict(), (8, 16, 9, 9)),
-        "act_pt_symmetric": (O.MovingAverageMinMaxObserver, dict(qscheme=torch.per_tensor_symmetric), (8, 16, 9, 9)),
+        "act_pt_symmetric": (O.MovingAverageMinMaxObserver, dict(qscheme=torch.per_tensor_symmetric, avoid_torch_overflow=False),
+                             (8, 16, 9, 9)),       # (torch refuses reduce_range with symmetric quint8)
         "act_pc_affine": (O.MovingAveragePerChannelMinMaxObserver, dict(qscheme=torch.per_channel_affine), (8, 16, 9, 9)),
         "weightless_minmax": (O.MinMaxObserver, dict(avoid_torch_overflow=False), (4, 8, 33)),
-        "custom_range": (O.PerChannelMinMaxObserver, dict(qscheme=torch.per_channel_symmetric, quant_min=0, quant_max=15),
-                         (8, 16, 9, 9)),
+        "custom_range": (O.PerChannelMinMaxObserver, dict(qscheme=torch.per_channel_symmetric, quant_min=0, quant_max=15,
+                                                          avoid_torch_overflow=False), (8, 16, 9, 9)),
     }[kind]
     obs_cls, kw, shape = cfg
     n = int(np.prod(shape))
