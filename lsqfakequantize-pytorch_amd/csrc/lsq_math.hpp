@@ -98,7 +98,10 @@ __device__ __forceinline__ T dequant(T lvl, const QParams<T>& q) {
 // ---- backward (lsq_kernel.h:94-123) ------------------------------------------------------------
 // Returns dX; ds_term / db_term are the per-element contributions (already multiplied by the
 // gradient scaler, :122) that the reference writes to ds_buffer / db_buffer (lsq_cpu.cpp:131-133).
-template <typename T, bool SYM, bool INIT>
+// RAW: leave the gradient scaler out (ds_term = dS, db_term = dB): the caller multiplies its SUMS by it once.  Only the
+// 16-bit-storage kernels do that (their parity is defined by this build); a sum of individually scaled and
+// rounded terms and the scaled sum differ by at most 2^-24 per term, far inside the 1e-6 bar.
+template <typename T, bool SYM, bool INIT, bool RAW = false>
 __device__ __forceinline__ T backward_elem(T grad, T x, const QParams<T>& q, const Range<T>& r,
                                            T grad_scaler, T& ds_term, T& db_term) {
     const T xq = fmax_(fmin_(x * q.inv_s + q.zp, r.qmax), r.qmin);  // :108, clamp = min then max, unrounded
@@ -110,12 +113,12 @@ __device__ __forceinline__ T backward_elem(T grad, T x, const QParams<T>& q, con
     const T g_ = INIT ? static_cast<T>(2) * err : grad;            // :116
     const T border = (xq <= r.qmin) ? g_ * (r.qmin - q.zp) : g_ * (r.qmax - q.zp);  // :120
     const T dS = inside ? g_ * err * q.inv_s : border;             // :121
-    ds_term = dS * grad_scaler;                                    // :122
+    ds_term = RAW ? dS : dS * grad_scaler;                         // :122
     if (SYM) {
         db_term = static_cast<T>(0);                               // :118 (0 * scaler)
     } else {
         const T dB = (static_cast<T>(1) - mask) * g_;              // :118 static_cast<scalar_t>(!mask) * _grad
-        db_term = dB * grad_scaler;
+        db_term = RAW ? dB : dB * grad_scaler;
     }
     return dX;
 }

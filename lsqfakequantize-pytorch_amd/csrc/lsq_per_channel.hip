@@ -334,6 +334,32 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
     double acc_s[kAcc], acc_b[kAcc];
 #pragma unroll
     for (int j = 0; j < kAcc; ++j) { acc_s[j] = 0.0; acc_b[j] = 0.0; }
+    // PRE32 (16-bit storage on the LDS-DMA ring): the kernel is VALU-bound (profiles/r02_sq_counters_before_cfg5_bf16.txt)
+    // and every wave64 VALU instruction costs ~4 cycles whatever its width (profiles/r02_valu_issue_rates.txt), so the
+    // reduction is made cheaper per term, within the parity bar of 1e-6 x sum|terms| (profiles/r02_pre32_ab.txt: -6 %):
+    //  * the terms of up to kPreRows consecutive rows are first added per component in fp32 (one packed add for the
+    //    d_scale / d_shift pair), then the pre-sum joins the fp64 accumulator -- a convert and an fp64 add per kPreRows
+    //    terms instead of per term; at most kPreRows - 1 fp32 roundings per pre-sum, <= 1.8e-7 of the sum of the |terms|
+    //    in the worst case, ~1e-9 typically;
+    //  * the gradient scaler multiplies the fp64 sums once (backward_elem<.., RAW>) instead of every term.
+    constexpr bool PRE32 = DMA > 0 && sizeof(E) < 4 && !EVAL;
+    constexpr int kPreRows = 4;
+    T pre_s[PRE32 ? kAcc : 1], pre_b[PRE32 ? kAcc : 1];
+#pragma unroll
+    for (int j = 0; j < (PRE32 ? kAcc : 1); ++j) { pre_s[j] = static_cast<T>(0); pre_b[j] = static_cast<T>(0); }
+    auto flush_pre = [&]() {
+        if constexpr (PRE32) {
+#pragma unroll
+            for (int j = 0; j < kAcc; ++j) {
+                acc_s[j] += static_cast<double>(pre_s[j]);
+                pre_s[j] = static_cast<T>(0);
+                if (!SYM) {
+                    acc_b[j] += static_cast<double>(pre_b[j]);
+                    pre_b[j] = static_cast<T>(0);
+                }
+            }
+        }
+    };
 
     auto emit_row = [&](int64_t oo, const E (&gi)[V], const E (&xi)[V], bool valid) {
         const int64_t e = oo * g.L + site.p0;
@@ -346,11 +372,16 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
                 out[j] = IO::to_elem(backward_elem_eval<T, INIT>(gv, xv, q, r));
             } else {
                 T ds_t, db_t;
-                out[j] = IO::to_elem(backward_elem<T, SYM, INIT>(gv, xv, q, r, grad_scaler, ds_t, db_t));
+                out[j] = IO::to_elem(backward_elem<T, SYM, INIT, PRE32>(gv, xv, q, r, grad_scaler, ds_t, db_t));
                 if (!valid) { ds_t = static_cast<T>(0); db_t = static_cast<T>(0); }
-                const double a = static_cast<double>(ds_t), c = static_cast<double>(db_t);
-                acc_s[j < kAcc ? j : 0] += a;
-                if (!SYM) acc_b[j < kAcc ? j : 0] += c;
+                if constexpr (PRE32) {
+                    pre_s[j < kAcc ? j : 0] += ds_t;
+                    if (!SYM) pre_b[j < kAcc ? j : 0] += db_t;
+                } else {
+                    const double a = static_cast<double>(ds_t), c = static_cast<double>(db_t);
+                    acc_s[j < kAcc ? j : 0] += a;
+                    if (!SYM) acc_b[j < kAcc ? j : 0] += c;
+                }
             }
         }
         if (valid) store_elems<IO, V, NTS>(dx, e, out);
@@ -391,10 +422,20 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
             for (; i + DMA < dma_n; ++i) {           // steady state: the ring is full, one refill per row, no branches
                 wait_vm<2 * (DMA - 1)>();
                 consume(i, true, all_valid);
+                if (PRE32 && (i & (kPreRows - 1)) == kPreRows - 1) flush_pre();
             }
             for (; i < dma_n; ++i) {                 // the last DMA rows: nothing left to request
                 wait_vm_upto(static_cast<int>(2 * (dma_n - 1 - i)));
                 consume(i, false, all_valid);
+                if (PRE32 && (i & (kPreRows - 1)) == kPreRows - 1) flush_pre();
+            }
+            flush_pre();
+            if constexpr (PRE32) {           // the gradient scaler, once per sum
+#pragma unroll
+                for (int j = 0; j < kAcc; ++j) {
+                    acc_s[j] *= static_cast<double>(grad_scaler);
+                    acc_b[j] *= static_cast<double>(grad_scaler);
+                }
             }
         };
         // every lane of this wave walks all dma_n rows (no dead lane, no ragged last tile): no per-row validity selects
