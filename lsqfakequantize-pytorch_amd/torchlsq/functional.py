@@ -30,6 +30,12 @@ class _LSQOnDevice(torch.autograd.Function):
         # only needs "was the element strictly inside the range", so the forward emits that as one byte per
         # element and autograd keeps the mask instead of x (1 instead of 4 bytes per fp32 element, and the
         # backward reads 9 instead of 12 bytes per element).
+        # One observable difference from the reference, which recomputes the mask in its backward from the saved
+        # (x, scale, shift) (lsq_autograd.cpp:52-67): the mask is that of the FORWARD's parameter values.  They only
+        # differ if scale / shift are overwritten in place (param.data.copy_, which autograd's version check does not
+        # see) between this forward and its backward -- e.g. the same quantizer instance called twice before one
+        # backward during its observer-driven phase; the reference then differentiates with the newer parameters, this
+        # build with the ones the output was actually computed with.  (The C++ host binding's LsqNode does the same.)
         masked = eval_mode and not init_mode and x.requires_grad
         if per_channel:
             y = _E.hip_forward_per_channel(x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode,

@@ -1,0 +1,101 @@
+"""GPU: the LDS-DMA ring loops of the window-mode per-channel kernels against their register loops.
+
+Both are reachable on any shape through the launch-variant code (bits 12-13: 1 = registers, 2 = ring), so the ring is
+exercised here on shapes the default policy would not give it: fewer rows than ring stages, ragged last row tiles, dead
+lanes in the last window, row-group windows of every width, unaligned-size fallbacks.  y and dx must be bit-identical;
+d_scale / d_shift bit-identical for 4- and 8-byte storage (same per-lane summation order) and within the parity bar for
+16-bit storage (fp32 pre-sums on the ring).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+REG, RING = 1 << 12, 2 << 12
+
+
+@pytest.fixture(scope="module")
+def E():
+    import torchlsq  # noqa: F401
+    from torchlsq import extension
+    extension._assert_has_ops()
+    return extension
+
+
+def _bits(t):
+    t = t.detach().contiguous()
+    return t.view({1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[t.element_size()]).cpu().numpy().tobytes()
+
+
+SHAPES = [
+    # (shape, axis)                      what it hits
+    ((3, 16, 7, 7), 1),                  # folded rows (L < window), two channels per lane
+    ((5, 64, 49), 1),                    # CPL 2, 5 rows < ring depth
+    ((37, 2048, 49), 1),                 # BASELINE config 5 geometry, odd row count
+    ((9, 256, 56, 56), 1),               # one channel per lane, many windows
+    ((2, 3, 1000, 1001), 1),             # huge inner, last window partly dead
+    ((1030, 4096), 1),                   # last axis, wide rows: 64-lane row groups, ragged last tile (1030 % 4)
+    ((1001, 768), 1),                    # last axis, 96/192 lanes per row
+    ((333, 7, 256), 2),                  # channels-last, 32/64 lanes per row, R = 8 / 4
+    ((50, 8), 1),                        # tiny rows: many row groups
+    ((4100, 1024), 1),                   # exactly 256 lanes per row (fp32)
+    ((123, 40), 1),                      # L not a multiple of the packet: element-wise kernels (no ring; must still work)
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float64, torch.float16])
+@pytest.mark.parametrize("mode", ["train", "sym", "eval", "init"])
+def test_ring_equals_register_loops(E, dtype, mode):
+    from torchlsq import synth
+    dev = torch.device("cuda:0")
+    pdt = torch.float64 if dtype == torch.float64 else torch.float32
+    for k, (shape, axis) in enumerate(SHAPES):
+        n = int(np.prod(shape))
+        x = synth.normal_like(n, 500 + k, 0.4, 1.0, dtype=dtype, device=dev).view(shape)
+        g = synth.normal_like(n, 600 + k, 0.0, 1e-2, dtype=dtype, device=dev).view(shape)
+        C = shape[axis]
+        s = synth.uniform_like(C, 700 + k, 0.02, 0.2, device=dev, dtype=pdt)
+        b = synth.normal_like(C, 800 + k, 0.0, 0.1, device=dev, dtype=pdt)
+        q = (-8, 7, -128, 127, True, 1.0, mode == "sym", mode == "eval", mode == "init")
+        for bpc in (1, 4, 16):
+            base = 4 | (3 << 8) | (bpc << 16)
+            y_reg = E.hip_forward_per_channel(x, s, b, axis, *q, variant=base | REG)
+            y_ring = E.hip_forward_per_channel(x, s, b, axis, *q, variant=base | RING)
+            r_reg = E.hip_backward_per_channel(g, x, s, b, axis, *q, variant=base | REG)
+            r_ring = E.hip_backward_per_channel(g, x, s, b, axis, *q, variant=base | RING)
+            torch.cuda.synchronize()
+            what = (shape, axis, str(dtype), mode, bpc)
+            assert _bits(y_reg) == _bits(y_ring), ("y", what)
+            assert _bits(r_reg[0]) == _bits(r_ring[0]), ("dx", what)
+            if dtype in (torch.float32, torch.float64):
+                assert _bits(r_reg[1]) == _bits(r_ring[1]) and _bits(r_reg[2]) == _bits(r_ring[2]), ("ds/db", what)
+            else:
+                # 16-bit storage: the ring pre-adds up to 4 rows in fp32 and scales the sums: compare on the scale of
+                # the sum of |terms| (an upper bound of it: every |term| <= |g| * max(|err/s|, |q - zp|) * scaler)
+                for u, v in ((r_reg[1], r_ring[1]), (r_reg[2], r_ring[2])):
+                    tol = 1e-6 * float(g.float().abs().sum()) * 300.0 / max(1, C) + 1e-30
+                    assert float((u.double() - v.double()).abs().max()) <= tol, ("ds/db", what)
+
+
+def test_default_policy_takes_the_ring_on_large_shapes(E):
+    """the launch note of the window-mode backward reports the grid; with the ring a [256,2048,7,7] bf16 backward is
+    sized for 4 resident workgroups per CU (LDS-bound) and fills one round"""
+    import ctypes
+    from torchlsq import synth
+    dev = torch.device("cuda:0")
+    lib = E.library()
+    lib.lsq_hip_debug_last_launch.argtypes = [ctypes.POINTER(ctypes.c_int * 4)]
+    n = 256 * 2048 * 49
+    x = synth.normal_like(n, 1, 0.0, 1.0, dtype=torch.bfloat16, device=dev).view(256, 2048, 7, 7)
+    g = synth.normal_like(n, 2, 0.0, 1e-3, dtype=torch.bfloat16, device=dev).view(256, 2048, 7, 7)
+    s, b = synth.uniform_like(2048, 3, 0.05, 0.35, device=dev), synth.normal_like(2048, 4, 0.0, 0.1, device=dev)
+    E.hip_backward_per_channel(g, x, s, b, 1, -8, 7, -128, 127, True, 1.0, False, False, False)
+    torch.cuda.synchronize()
+    out = (ctypes.c_int * 4)()
+    lib.lsq_hip_debug_last_launch(ctypes.byref(out))
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert out[0] == 49 and out[2] >= 3                      # 49 windows of 2048 positions; residency known
+    total = out[0] * out[1]
+    rounds = -(-total // (out[2] * cus))
+    assert total / (rounds * out[2] * cus) >= 0.9, (list(out), "the last round of workgroups is not full")

@@ -501,7 +501,13 @@ def test_more_than_2_pow_31_elements(dev):
         assert torch.equal(y[lo:hi], yp) and torch.equal(dx[lo:hi], dxp)
         acc += wp
         del yp, dxp
-    np.testing.assert_allclose(acc.cpu().numpy(), wide.cpu().numpy(), rtol=1e-11)
+    # 16-bit storage adds up to 4 consecutive rows in fp32 before its fp64 accumulation, and which rows share a pre-sum
+    # depends on where a workgroup's slab starts: whole tensor and halves agree on the scale of the sum of |terms|
+    # (every |term| <= |g| * 128 * scaler; scaler = 1 / sqrt(m * 127 / C)), not to the last fp64 digit
+    scaler = 1.0 / np.sqrt(float(m) * 127.0 / C)
+    bound = gv.float().abs().sum(dim=(0, 2)).double().cpu().numpy() * 128.0 * scaler
+    err = np.abs(acc.cpu().numpy() - wide.cpu().numpy())
+    assert np.all(err <= 1e-7 * bound[None, :]), (err.max(), bound.min())
 
 
 MM_SHAPES = [((7,), None), ((4099,), None), ((3, 1 << 20), None), ((4, 8, 6, 6), 1), ((8, 4, 3, 3), 0), ((5, 16), 1),
