@@ -90,18 +90,19 @@ size_t lsq_hip_backward_per_channel_workspace(int dtype, int64_t outer, int64_t 
     // The size is the maximum over every launch geometry the tuning range allows (a few dozen candidate geometries).
     // Callers ask once per backward with the same few shapes: remember the last answers of this thread.
     // (The answer depends on the CU count of the current device, so the device ordinal is part of the key.)
-    struct Memo { int dtype, device; int64_t outer, channels, inner; size_t bytes; };
+    struct Memo { int dtype, device, knob; int64_t outer, channels, inner; size_t bytes; };
     constexpr int kMemo = 8;
     thread_local Memo memo[kMemo] = {};
     thread_local int next = 0;
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) device = 0;
+    const int knob = lsq::get_ww_min_rows();      // (a tools-only geometry override: part of the key)
     for (int i = 0; i < kMemo; ++i)
-        if (memo[i].bytes && memo[i].dtype == dtype && memo[i].device == device && memo[i].outer == outer &&
+        if (memo[i].bytes && memo[i].dtype == dtype && memo[i].device == device && memo[i].knob == knob && memo[i].outer == outer &&
             memo[i].channels == channels && memo[i].inner == inner)
             return memo[i].bytes;
     const size_t bytes = lsq::bwd_pc_workspace_bytes(io_vec(dtype), outer, channels, inner);
-    memo[next] = Memo{dtype, device, outer, channels, inner, bytes};
+    memo[next] = Memo{dtype, device, knob, outer, channels, inner, bytes};
     next = (next + 1) % kMemo;
     return bytes;
 }
@@ -222,6 +223,8 @@ int lsq_hip_backward_from_mask(int dtype, const void* grad, const void* mask, vo
 }
 
 void lsq_hip_debug_set_observe_wg_per_cu(int v) { lsq::set_observe_wg_per_cu(v); }
+
+void lsq_hip_debug_set_ww_min_rows(int v) { lsq::set_ww_min_rows(v); }
 
 void lsq_hip_debug_last_launch(int* out4) {
     const lsq::LaunchNote& n = lsq::last_launch_note();

@@ -224,12 +224,12 @@ static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_
     return g;
 }
 
-// Dynamic LDS of the window-mode backward in front of the LDS-DMA ring: the channel table + fp64 slots (256-lane
-// windows) or the row-group combine buffer; the ring starts at the next 1 KiB boundary.
+// Dynamic LDS of the window-mode backward in front of the LDS-DMA ring: the channel table + fp64 slots of the 256-lane
+// windows (the ring starts at the next 1 KiB boundary).  Row-group windows have nothing in front: their combine buffer
+// is only used after the last row has been consumed and takes the ring's place (one barrier in between).
 static inline __host__ __device__ uint32_t bwd_lds_front_bytes(const PcGeom& g, uint32_t slot_bytes) {
-    const uint32_t front = g.ww_lanes ? static_cast<uint32_t>(g.R > 1 ? g.R - 1 : 1) * g.k_slots * 16u
-                                      : static_cast<uint32_t>(g.k_slots) * (slot_bytes + 16u);
-    return (front + 1023u) & ~1023u;
+    if (g.ww_lanes) return 0u;
+    return (static_cast<uint32_t>(g.k_slots) * (slot_bytes + 16u) + 1023u) & ~1023u;
 }
 
 // Where a lane sits: position p0 of its first element, its row inside the tile, and whether it is live.

@@ -501,6 +501,7 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
         // and stores the workgroup's partial row, slot = component * w + lane (contiguous per component).
         double2* comb = reinterpret_cast<double2*>(smem);
         const int w = g.ww_lanes, rg = site.row_in_tile;
+        if constexpr (DMA > 0) __syncthreads();     // the combine buffer takes the ring's place: every wave is done reading
         if (rg > 0 && rg < g.R) {
 #pragma unroll
             for (int j = 0; j < V; ++j) comb[((rg - 1) * V + j) * w + lane_in_group] = make_double2(acc_s[j], acc_b[j]);
@@ -898,6 +899,9 @@ __global__ __launch_bounds__(kBlock) void finalize_seg_kernel(const double2* __r
 template <typename IO>
 constexpr int kWindowBwdVec = IO::VEC;
 constexpr int kLastAxisBwdBlocksPerCU = 2;
+static std::atomic<int> g_ww_min_rows_override{0};          // tools only (lsq_hip_debug_set_ww_min_rows): 0 = kWwMinRows
+void set_ww_min_rows(int v) { g_ww_min_rows_override.store(v); }
+int get_ww_min_rows() { return g_ww_min_rows_override.load(); }
 constexpr int kWwBwdBlocksPerCU = 4;     // row-group windows: one full round for every storage type (3-4 resident per CU)
 // Rows a forward workgroup walks at least, per unit of its per-workgroup overhead (make_geom): that overhead is only
 // the channel-table build -- VEC channels per lane when the quantized axis is the last one, so twice as heavy per
@@ -923,7 +927,8 @@ size_t bwd_pc_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64
                 need = std::max(need, static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2));
             }
             if (vi == 0 && inner == 1 && io_vec > 1 && channels % io_vec == 0) {
-                const int min_rows = (107 + (16 / io_vec) - 1) / (16 / io_vec);   // kWwMinRows of the storage type
+                const int ovr = g_ww_min_rows_override.load(std::memory_order_relaxed);
+                const int min_rows = ovr > 0 ? ovr : (107 + (16 / io_vec) - 1) / (16 / io_vec);   // kWwMinRows of the storage type
                 for (int res = 0; res <= 8; ++res) {
                     const PcGeom g = make_geom_ww(outer, channels, io_vec, dev.cu_count * bpc, min_rows, dev.cu_count * res);
                     need = std::max(need, static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2));
@@ -1043,7 +1048,10 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
         const int tgt = variant == 0 ? dev.cu_count * kDmaFwdBlocksPerCU<IO> : target;
         const PcGeom gd = make_geom(outer, channels, inner, vec, tgt, kFwdPerSlotRows<IO>);
         const bool small_last_axis = cpl == vec && outer * channels * inner < (int64_t{1} << 24);
-        if (v.dma == 2 || (gd.n_tiles / std::max(1, gd.splits) >= kFwdDmaDepth && !small_last_axis)) {
+        const int64_t tiles_each = gd.n_tiles / std::max(1, gd.splits);
+        // (not on very long walks either: [32,2048,4096] fp32, 128 rows per workgroup, 380 us with the register loops,
+        // 450-580 us on the ring, profiles/r02_dma_ab_big_shapes.txt)
+        if (v.dma == 2 || (tiles_each >= kFwdDmaDepth && tiles_each <= 64 && !small_last_axis)) {
             g = gd;
             vv.dma = 2;
         }
@@ -1083,6 +1091,11 @@ struct BwdPcCall {
 // rows a row-group-window workgroup walks at least: keeps its 16-byte-per-slot partial row under ~5 % of what it streams
 template <typename IO>
 constexpr int kWwMinRows = (107 + static_cast<int>(sizeof(typename IO::elem)) - 1) / static_cast<int>(sizeof(typename IO::elem));
+template <typename IO>
+static inline int ww_min_rows() {
+    const int o = g_ww_min_rows_override.load(std::memory_order_relaxed);
+    return o > 0 ? o : kWwMinRows<IO>;
+}
 
 template <typename IO, int V, int CPL, bool SYM, bool INIT, bool EVAL, bool WW = false>
 static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
@@ -1103,17 +1116,20 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
     // The geometry depends on how many workgroups of the chosen instantiation fit on the chip at once, so it is built
     // here, where the kernel is known, together with the launch and the finalize.
     // returns false (nothing launched) when `min_tiles` is asked for and a workgroup would walk fewer row tiles than that
-    auto run = [&](auto kern, int dma_depth, int target_blocks, int64_t min_tiles) -> bool {
+    auto run = [&](auto kern, int dma_depth, int target_blocks, int64_t min_tiles, int64_t max_tiles = INT64_MAX) -> bool {
         const DeviceInfo& dev = device_info();
         auto geom = [&](int resident) {
-            return WW ? make_geom_ww(c.outer, c.C, V, target_blocks, kWwMinRows<IO>, resident)
+            return WW ? make_geom_ww(c.outer, c.C, V, target_blocks, ww_min_rows<IO>(), resident)
                       : make_geom(c.outer, c.C, c.inner, V, target_blocks, 27, resident);
         };
         auto lds_of = [&](const PcGeom& gg) {
             size_t b = WW ? static_cast<size_t>(std::max(1, gg.R - 1)) * gg.k_slots * sizeof(double2)
                           : static_cast<size_t>(gg.k_slots) * (sizeof(QSlot<T>) + 2 * sizeof(double));
-            if (dma_depth > 0)
-                b = bwd_lds_front_bytes(gg, sizeof(QSlot<T>)) + static_cast<size_t>(gg.block_threads / 64) * dma_depth * kDmaStageBytes;
+            if (dma_depth > 0) {
+                const size_t ring = bwd_lds_front_bytes(gg, sizeof(QSlot<T>)) +
+                                    static_cast<size_t>(gg.block_threads / 64) * dma_depth * kDmaStageBytes;
+                b = WW ? std::max(b, ring) : ring;      // row groups: the combine buffer reuses the ring's LDS
+            }
             return b;
         };
         // the LDS a workgroup needs does not depend on the split count: size it first, then the residency, then the grid
@@ -1125,7 +1141,8 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
         }
         const int per_cu = c.whole_rounds ? resident_blocks_per_cu(reinterpret_cast<const void*>(kern), lds) : 0;
         const PcGeom g = geom(per_cu * dev.cu_count);
-        if (g.n_tiles / std::max<int64_t>(1, g.splits) < min_tiles) return false;
+        const int64_t tiles_each = g.n_tiles / std::max<int64_t>(1, g.splits);
+        if (tiles_each < min_tiles || tiles_each > max_tiles) return false;
         if (!grid_fits(g)) { result = hipErrorInvalidConfiguration; return true; }
         const size_t need = static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2);
         if (!p.eval_mode && c.workspace_bytes < need) { result = hipErrorInvalidValue; return true; }
@@ -1163,7 +1180,14 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
         constexpr bool kDefaultHere = kDmaDefault<IO> && (sizeof(typename IO::elem) < 4 || CPL >= 2);
         if (c.v.dma == 2 || (c.v.dma == 0 && kDefaultHere)) {
             const int target = c.default_variant ? device_info().cu_count * kDmaBwdBlocksPerCU<IO> : c.target_blocks;
-            if (run(bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, 1, true, true, false, WW, kDmaDepth>, kDmaDepth, target,
+            // (row-group windows of 4- and 8-byte storage: only tensors up to 160 MB -- [8192,4096] 78 -> 69 us,
+            // [64,197,768] 33 -> 28 us; on the bigger ones, four elements a row, the ring's per-row bookkeeping costs more
+            // than its loads in flight gain: NHWC [64,56,56,256] 119 -> 127 us, [65536,1024] 157 -> 172 us,
+            // profiles/r02_ww_min_rows_sweep.txt)
+            const bool big_wide = WW && sizeof(typename IO::elem) >= 4 &&
+                                  c.outer * c.C * static_cast<int64_t>(sizeof(typename IO::elem)) > (int64_t{160} << 20);
+            if (!(big_wide && c.v.dma != 2) &&
+                run(bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, 1, true, true, false, WW, kDmaDepth>, kDmaDepth, target,
                     c.v.dma == 2 ? 0 : kDmaDepth))
                 return result;
         }
