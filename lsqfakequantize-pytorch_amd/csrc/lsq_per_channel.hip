@@ -1308,7 +1308,10 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
     // fatter workgroups win there in every shape swept (profiles/r01_lastaxis_sweep.txt: 2 per CU; [8192, 4096] fp32
     // 82 us against 100 us at 16 per CU, [200704, 256] 133 against 205).
     const bool last_axis = vecw > 1 && cpl == vecw;
-    if (last_axis && inner == 1 && !(variant & (1 << 11))) {     // variant bit 11 (tools): the 256-lane windows instead, for A/B runs
+    // (not for tensors of 2^27 elements and more: on [32,2048,4096] -- 65536 rows -- the 256-lane windows, which read 4 KiB
+    // contiguous per row and workgroup instead of 1 KiB from each of four rows, are 7-12 % faster,
+    // profiles/r02_lastaxis_rowgroup_ab.txt; variant bit 11 (tools) forces them, for A/B runs)
+    if (last_axis && inner == 1 && !(variant & (1 << 11)) && (variant != 0 || outer * channels < (int64_t{1} << 27))) {
         // the quantized axis is the last one ([tokens, features], channels-last): row-group windows, one round of what
         // the chip holds (variant: workgroups per CU requested, rounded to whole rounds)
         BwdPcCall<T> call{grad, x, dx, static_cast<T*>(ds), static_cast<T*>(db), wide, outer, channels, inner, scale, shift, &p,
