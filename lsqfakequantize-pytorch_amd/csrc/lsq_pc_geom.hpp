@@ -194,12 +194,13 @@ static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec,
 // 256-lane window's ([8192, 4096] bf16: 768 workgroups write 6 MB of partials instead of 25 MB).  The lane's V channels
 // are its own: their constants live in registers, there is no LDS table, and the epilogue is a fixed-order sum of the
 // row groups through LDS.
-static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_blocks, int min_rows, int resident_blocks) {
+static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_blocks, int min_rows, int resident_blocks,
+                                  bool split64 = false) {
     PcGeom g;
     g.outer = outer; g.C = C; g.inner = 1; g.L = C; g.vec = vec;
     g.fits32 = (g.L + static_cast<int64_t>(kBlock) * vec) < 0x7fffffffLL ? 1 : 0;
     const int64_t lanes_per_row = g.L / vec;
-    if (lanes_per_row <= kBlock) {
+    if (lanes_per_row <= kBlock && !(split64 && lanes_per_row >= 128 && lanes_per_row % 64 == 0)) {
         g.ww_lanes = static_cast<int32_t>(lanes_per_row);
         g.R = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(kBlock / lanes_per_row, outer)));
         g.n_windows = 1;

@@ -901,7 +901,9 @@ constexpr int kWindowBwdVec = IO::VEC;
 constexpr int kLastAxisBwdBlocksPerCU = 2;
 static std::atomic<int> g_ww_min_rows_override{0};          // tools only (lsq_hip_debug_set_ww_min_rows): 0 = kWwMinRows
 void set_ww_min_rows(int v) { g_ww_min_rows_override.store(v); }
-int get_ww_min_rows() { return g_ww_min_rows_override.load(); }
+static std::atomic<int> g_ww_split64{0};                   // tools only: rows of 128 / 192 / 256 lanes as 64-lane windows
+void set_ww_split64(int v) { g_ww_split64.store(v); }
+int get_ww_min_rows() { return g_ww_min_rows_override.load() | (g_ww_split64.load() << 16); }   // (the geometry knobs, as one key)
 constexpr int kWwBwdBlocksPerCU = 4;     // row-group windows: one full round for every storage type (3-4 resident per CU)
 // Rows a forward workgroup walks at least, per unit of its per-workgroup overhead (make_geom): that overhead is only
 // the channel-table build -- VEC channels per lane when the quantized axis is the last one, so twice as heavy per
@@ -930,8 +932,10 @@ size_t bwd_pc_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64
                 const int ovr = g_ww_min_rows_override.load(std::memory_order_relaxed);
                 const int min_rows = ovr > 0 ? ovr : (107 + (16 / io_vec) - 1) / (16 / io_vec);   // kWwMinRows of the storage type
                 for (int res = 0; res <= 8; ++res) {
-                    const PcGeom g = make_geom_ww(outer, channels, io_vec, dev.cu_count * bpc, min_rows, dev.cu_count * res);
-                    need = std::max(need, static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2));
+                    for (int s64 = 0; s64 < 2; ++s64) {
+                        const PcGeom g = make_geom_ww(outer, channels, io_vec, dev.cu_count * bpc, min_rows, dev.cu_count * res, s64 != 0);
+                        need = std::max(need, static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2));
+                    }
                 }
             }
             if (vi < 2 && pick_segment_mode(vecs[vi], outer, channels, inner)) {
@@ -1119,7 +1123,7 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
     auto run = [&](auto kern, int dma_depth, int target_blocks, int64_t min_tiles, int64_t max_tiles = INT64_MAX) -> bool {
         const DeviceInfo& dev = device_info();
         auto geom = [&](int resident) {
-            return WW ? make_geom_ww(c.outer, c.C, V, target_blocks, ww_min_rows<IO>(), resident)
+            return WW ? make_geom_ww(c.outer, c.C, V, target_blocks, ww_min_rows<IO>(), resident, g_ww_split64.load() != 0)
                       : make_geom(c.outer, c.C, c.inner, V, target_blocks, 27, resident);
         };
         auto lds_of = [&](const PcGeom& gg) {
