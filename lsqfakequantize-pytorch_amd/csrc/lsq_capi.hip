@@ -226,6 +226,7 @@ void lsq_hip_debug_set_observe_wg_per_cu(int v) { lsq::set_observe_wg_per_cu(v);
 
 void lsq_hip_debug_set_ww_min_rows(int v) { lsq::set_ww_min_rows(v); }
 void lsq_hip_debug_set_ww_split64(int v) { lsq::set_ww_split64(v); }
+void lsq_hip_debug_set_fin_ch(int v) { lsq::set_fin_ch(v); }
 
 void lsq_hip_debug_last_launch(int* out4) {
     const lsq::LaunchNote& n = lsq::last_launch_note();

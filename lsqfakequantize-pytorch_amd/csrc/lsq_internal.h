@@ -28,8 +28,10 @@ int lsq_hip_backward_per_channel_ex(int dtype, const void* grad, const void* x, 
 void lsq_hip_debug_last_launch(int* out4);
 /* tools only: rows a row-group-window workgroup walks at least (0 = the built-in rule) */
 void lsq_hip_debug_set_ww_min_rows(int v);
-/* tools only: 1 = row-group windows cut rows of 128 / 192 / 256 lanes into 64-lane windows (4 row groups each) */
-void lsq_hip_debug_set_ww_split64(int v);
+/* tools only: row-group windows cut rows of 128 / 192 / 256 lanes into 64-lane windows (4 row groups each) */
+void lsq_hip_debug_set_ww_split64(int v);   /* 0 = default (on for 4/8-byte storage), 1 = on for all, 2 = off */
+/* tools only: channels (slots) per finalize workgroup, a power of two <= 32 (0 = the built-in rule) */
+void lsq_hip_debug_set_fin_ch(int v);
 /* tuning only: override the workgroups-per-CU of the observer-statistics kernels (0 = defaults) */
 void lsq_hip_debug_set_observe_wg_per_cu(int v);
 #ifdef __cplusplus

@@ -574,9 +574,16 @@ constexpr int kFinCh = 32;   // channels per finalize workgroup when there are a
 // workgroups when the channel count allows it: with few channels (RGB inputs; 768 features x 512 row slabs) the
 // lanes of a workgroup share a channel's partials -- there can be thousands -- instead of 24 workgroups walking
 // them one lane per channel.
+static std::atomic<int> g_fin_ch_override{0};      // tools only (lsq_hip_debug_set_fin_ch)
+void set_fin_ch(int v) { g_fin_ch_override.store(v); }
 static inline int fin_channels(int64_t C) {
+    const int o = g_fin_ch_override.load(std::memory_order_relaxed);
+    if (o > 0) return o;
     int ch = 1;
     while (ch < kFinCh && static_cast<int64_t>(ch) * 2 * 256 <= C) ch <<= 1;
+    // ... but at least 8 channels (128 contiguous bytes of partials per split) where there are that many: better
+    // coalescing beats the extra workgroups (profiles/r02_finalize_channels_sweep.txt: 1-2 us on every shape)
+    while (ch < 8 && static_cast<int64_t>(ch) * 2 <= C) ch <<= 1;
     return ch;
 }
 
@@ -1123,7 +1130,10 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
     auto run = [&](auto kern, int dma_depth, int target_blocks, int64_t min_tiles, int64_t max_tiles = INT64_MAX) -> bool {
         const DeviceInfo& dev = device_info();
         auto geom = [&](int resident) {
-            return WW ? make_geom_ww(c.outer, c.C, V, target_blocks, ww_min_rows<IO>(), resident, g_ww_split64.load() != 0)
+            // rows of 128 / 192 / 256 lanes: 4- and 8-byte storage cuts them into 64-lane windows of four row groups
+            // ([65536,1024] fp32 backward 157 -> 140 us, profiles/r02_ww_split64_ab.txt); 16-bit storage gains nothing
+            const bool split64 = sizeof(typename IO::elem) >= 4 ? g_ww_split64.load() != 2 : g_ww_split64.load() == 1;
+            return WW ? make_geom_ww(c.outer, c.C, V, target_blocks, ww_min_rows<IO>(), resident, split64)
                       : make_geom(c.outer, c.C, c.inner, V, target_blocks, 27, resident);
         };
         auto lds_of = [&](const PcGeom& gg) {

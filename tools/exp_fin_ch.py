@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Finalize kernels: channels (slots) per workgroup -- the rule (a power of two keeping ~256 workgroups) against fixed values;
+GPU-side us per backward incl. finalize, one MI355X."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
+import torch
+import torchlsq  # noqa: F401
+from torchlsq import extension as E, synth
+lib = E.library()
+lib.lsq_hip_debug_set_fin_ch.argtypes = [ctypes.c_int]
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, reps=20):
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        fn()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st):
+            for _ in range(reps):
+                fn()
+        gr.replay(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(7):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); gr.replay(); e1.record(); e1.synchronize()
+            ts.append(e0.elapsed_time(e1) / reps * 1e3)
+    return sorted(ts)[len(ts) // 2]
+
+
+for shape, axis in (((64, 197, 768), 2), ((8192, 4096), 1), ((256, 2048, 7, 7), 1), ((64, 56, 56, 256), 3), ((65536, 1024), 1), ((128, 768), 1)):
+    for dt in (torch.float32, torch.bfloat16):
+        n = 1
+        for d in shape: n *= d
+        x = synth.normal_like(n, 1, 0.5, 1.0, device=dev, dtype=dt).view(shape)
+        g = synth.normal_like(n, 2, 0.0, 1e-3, device=dev, dtype=dt).view(shape)
+        C = shape[axis]
+        s = synth.uniform_like(C, 3, 0.02, 0.05, device=dev); b = synth.normal_like(C, 4, 0.0, 0.1, device=dev)
+        q = (0, 127, 0, 255, True, 1.0, False, False, False)
+        res = []
+        for fc in (0, 1, 2, 4, 8, 16, 32):
+            lib.lsq_hip_debug_set_fin_ch(fc)
+            res.append("%s %.1f" % (fc or "rule", timeit(lambda: E.hip_backward_per_channel(g, x, s, b, axis, *q))))
+        lib.lsq_hip_debug_set_fin_ch(0)
+        print("%-9s %-18s %s" % (str(dt).replace("torch.", ""), shape, " | ".join(res)), flush=True)
