@@ -410,7 +410,9 @@ def run_rank(a):
             what = "per-tensor quint8 (qmin,qmax=%d,%d)" % (c["qmin"], c["qmax"])
             opnames = "lsq_forward_per_tensor + lsq_backward_per_tensor"
         traffic, traffic_source = None, "not measured"
-        want_pmc = a.measure_traffic if a.measure_traffic is not None else (world == 1 and not a.graph)
+        # default: measure at N = 1 -- unless this process itself runs under a profiler (a nested rocprofv3 is asking for trouble)
+        profiled = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+        want_pmc = a.measure_traffic if a.measure_traffic is not None else (world == 1 and not a.graph and not profiled)
         if want_pmc and world == 1:
             traffic, info = measure_traffic(a, "lsq::" + kb)
             if traffic is not None:
