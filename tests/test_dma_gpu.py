@@ -82,6 +82,35 @@ def test_ring_equals_register_loops(E, dtype, mode):
                     assert float((u.double() - v.double()).abs().max()) <= tol, ("ds/db", what)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float64])
+def test_row_group_windows_equal_256_lane_windows(E, dtype):
+    """last-axis shapes: the row-group decomposition (constants in registers, fixed-order combine) against the 256-lane
+    windows with their LDS channel table (variant bit 11), forward and backward"""
+    from torchlsq import synth
+    dev = torch.device("cuda:0")
+    pdt = torch.float64 if dtype == torch.float64 else torch.float32
+    legacy = 1 << 11
+    for k, (shape, axis) in enumerate([((1030, 4096), 1), ((1001, 768), 1), ((333, 7, 256), 2), ((50, 8), 1), ((4100, 1024), 1),
+                                       ((7, 512), 1), ((3000, 128), 1), ((129, 6144), 1)]):
+        n = int(np.prod(shape))
+        x = synth.normal_like(n, 900 + k, 0.4, 1.0, dtype=dtype, device=dev).view(shape)
+        g = synth.normal_like(n, 950 + k, 0.0, 1e-2, dtype=dtype, device=dev).view(shape).abs()     # no cancellation: plain rtol
+        C = shape[axis]
+        s = synth.uniform_like(C, 970 + k, 0.02, 0.2, device=dev, dtype=pdt)
+        b = synth.normal_like(C, 990 + k, 0.0, 0.1, device=dev, dtype=pdt)
+        q = (-8, 7, -128, 127, True, 1.0, False, False, False)
+        for bpc in (2, 8):
+            base = 4 | (3 << 8) | (bpc << 16) | REG
+            y_new = E.hip_forward_per_channel(x, s, b, axis, *q, variant=base)
+            y_old = E.hip_forward_per_channel(x, s, b, axis, *q, variant=base | legacy)
+            r_new = E.hip_backward_per_channel(g, x, s, b, axis, *q, variant=base)
+            r_old = E.hip_backward_per_channel(g, x, s, b, axis, *q, variant=base | legacy)
+            torch.cuda.synchronize()
+            assert _bits(y_new) == _bits(y_old) and _bits(r_new[0]) == _bits(r_old[0]), (shape, str(dtype), bpc)
+            for u, v in ((r_new[1], r_old[1]), (r_new[2], r_old[2])):
+                assert torch.allclose(u.double(), v.double(), rtol=2e-6 if dtype == torch.bfloat16 else 1e-6, atol=1e-30), (shape, str(dtype), bpc)
+
+
 def test_default_policy_takes_the_ring_on_large_shapes(E):
     """the launch note of the window-mode backward reports the grid; with the ring a [256,2048,7,7] bf16 backward is
     sized for 4 resident workgroups per CU (LDS-bound) and fills one round"""
