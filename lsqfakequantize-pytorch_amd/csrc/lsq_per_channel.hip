@@ -112,9 +112,7 @@ struct LaneChannels {
 // ------------------------------------------------------------------------------------------------
 // DMA > 0: the rows arrive through an LDS-DMA ring of DMA stages per wave (see bwd_pc_kernel): DMA rows in flight per
 // wave and no load registers.
-// WW: row-group windows (make_geom_ww: inner == 1, CPL == V): the lane's channels are its own, their constants go from
-// global memory into registers -- no LDS table, no barrier (see bwd_pc_kernel).
-template <typename IO, int V, int CPL, bool INIT, bool LEVELS, int UNROLL, bool NTL, bool NTS, int DMA = 0, bool WW = false>
+template <typename IO, int V, int CPL, bool INIT, bool LEVELS, int UNROLL, bool NTL, bool NTS, int DMA = 0>
 __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                         int8_t* __restrict__ levels, int level_bias, int aux_kind, PcGeom g,
                                                         const typename IO::arith* __restrict__ scale,
@@ -123,11 +121,9 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
     using T = typename IO::arith;
     using E = typename IO::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    static_assert(!WW || (CPL == V && V > 1), "row-group windows: one channel per packet component");
     QSlot<T>* table = reinterpret_cast<QSlot<T>*>(smem);
 
-    int32_t lane_in_group = 0;
-    const LaneSite site = WW ? lane_site_ww(g, V, lane_in_group) : lane_site(g, V);
+    const LaneSite site = lane_site(g, V);
     const RowWalk walk(g, site);
     // the first group of loads does not depend on the channel constants: put it in flight before the
     // table build (global loads of scale/shift + a division + a barrier) so the two latencies overlap
@@ -141,7 +137,7 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
     static_assert(DMA == 0 || V * sizeof(E) == 16, "the LDS-DMA ring moves 16-byte packets");
     constexpr int kStage = 64 * 16;
     const int64_t dma_n = walk.n_tiles_split;
-    const uint32_t front = WW ? 0u : (static_cast<uint32_t>(g.k_slots) * static_cast<uint32_t>(sizeof(QSlot<T>)) + 1023u) & ~1023u;
+    const uint32_t front = (static_cast<uint32_t>(g.k_slots) * static_cast<uint32_t>(sizeof(QSlot<T>)) + 1023u) & ~1023u;
     unsigned char* ring = smem + front + (threadIdx.x >> 6) * (DMA * kStage);
     const uint32_t ring_lds = DMA > 0 ? __builtin_amdgcn_readfirstlane(lds_offset_of(ring)) : 0u;
     auto dma_issue = [&](int64_t i) {
@@ -153,20 +149,10 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
     if constexpr (DMA > 0) {
         for (int64_t i = 0; i < DMA && i < dma_n; ++i) dma_issue(i);
     }
+    build_channel_table<T>(table, g.k_slots, site.c_lo, g.C, scale, shift, r);
+    __syncthreads();
     LaneChannels<T, V, CPL> ch;
-    if constexpr (WW) {
-        ch.split = (CPL == 2) ? 1 : V;     // V == 2: LaneChannels' two-channel form, component 1 = channel 1
-#pragma unroll
-        for (int j = 0; j < LaneChannels<T, V, CPL>::N; ++j) {
-            const int64_t c = site.live ? site.p0 + j : 0;
-            ch.q[j] = make_qparams<T>(sanitize_scale_per_channel<T>(scale[c]), shift[c], r);
-            ch.key[j] = 0;
-        }
-    } else {
-        build_channel_table<T>(table, g.k_slots, site.c_lo, g.C, scale, shift, r);
-        __syncthreads();
-        ch.init(table, site, g);
-    }
+    ch.init(table, site, g);
     const T bias = static_cast<T>(level_bias);
 
     auto emit_row = [&](int64_t oo, const E (&in)[V], bool valid) {
@@ -984,29 +970,28 @@ constexpr int kDmaFwdBlocksPerCU = sizeof(typename IO::elem) < 4 ? 4 : 8;
 constexpr int kFwdDmaDepth = 8;      // one 1 KiB stage per row and wave in the forward (x only); the backward rings are 4 deep
 
 // ---- forward --------------------------------------------------------------------------------------
-template <typename IO, int V, int CPL, bool INIT, bool LEVELS, bool WW = false>
+template <typename IO, int V, int CPL, bool INIT, bool LEVELS>
 static hipError_t launch_fwd_pc(const void* x, void* y, int8_t* levels, int bias, int aux_kind, const PcGeom& g, const void* scale,
                                 const void* shift, const lsq_params& p, const Variant& v, hipStream_t stream) {
     using T = typename IO::arith;
     const Range<T> r = make_range<T>(p);
     const dim3 grid(static_cast<unsigned>(g.n_windows), static_cast<unsigned>(g.splits));
-    const size_t lds = WW ? 0 : static_cast<size_t>(g.k_slots) * sizeof(QSlot<T>);
+    const size_t lds = static_cast<size_t>(g.k_slots) * sizeof(QSlot<T>);
     // LDS-DMA ring (16-byte packets): forward_per_channel decided (v.dma == 2) and sized the grid for it
     constexpr bool kDmaAble = V * sizeof(typename IO::elem) == 16;
     constexpr int kDmaDepth = kFwdDmaDepth;
     if constexpr (kDmaAble) {
-        const size_t lds_dma = ((lds + 1023) & ~size_t(1023)) + static_cast<size_t>(g.block_threads / 64) * kDmaDepth * 1024;
+        const size_t lds_dma = ((lds + 1023) & ~size_t(1023)) + static_cast<size_t>(kBlock / 64) * kDmaDepth * 1024;
         if (v.dma == 2 && lds_dma <= 64 * 1024) {
-            hipLaunchKernelGGL((fwd_pc_kernel<IO, V, CPL, INIT, LEVELS, 1, true, true, kDmaDepth, WW>), grid, dim3(g.block_threads),
-                               lds_dma, stream, x, y, levels, bias, aux_kind, g, static_cast<const T*>(scale),
-                               static_cast<const T*>(shift), r);
+            hipLaunchKernelGGL((fwd_pc_kernel<IO, V, CPL, INIT, LEVELS, 1, true, true, kDmaDepth>), grid, dim3(kBlock), lds_dma, stream,
+                               x, y, levels, bias, aux_kind, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r);
             return hipGetLastError();
         }
     }
 #define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                       \
-    hipLaunchKernelGGL((fwd_pc_kernel<IO, V, CPL, INIT, LEVELS, U, NTLF, NTSF, 0, WW>), grid, dim3(g.block_threads), lds, stream, \
-                       x, y, levels, bias, aux_kind, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r)
-    [[maybe_unused]] constexpr bool kFull = !WW && !INIT && !LEVELS && V > 1 && !std::is_same<IO, io_f64>::value &&
+    hipLaunchKernelGGL((fwd_pc_kernel<IO, V, CPL, INIT, LEVELS, U, NTLF, NTSF>), grid, dim3(kBlock), lds, stream, x, y, levels, \
+                       bias, aux_kind, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r)
+    [[maybe_unused]] constexpr bool kFull = !INIT && !LEVELS && V > 1 && !std::is_same<IO, io_f64>::value &&
                                             !std::is_same<IO, io_f16>::value;
     LSQ_DISPATCH_VARIANT(kFull, 4, v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH
@@ -1028,15 +1013,15 @@ static hipError_t launch_fwd_seg(const void* x, void* y, int8_t* levels, int bia
     return hipGetLastError();
 }
 
-template <typename IO, int V, int CPL, bool WW = false>
+template <typename IO, int V, int CPL>
 static hipError_t fwd_pc_modes(const void* x, void* y, int8_t* levels, int bias, int aux_kind, const PcGeom& g, const void* scale,
                                const void* shift, const lsq_params& p, const Variant& v, hipStream_t stream) {
     if (p.init_mode) {
-        return levels ? launch_fwd_pc<IO, V, CPL, true, true, WW>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream)
-                      : launch_fwd_pc<IO, V, CPL, true, false, WW>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream);
+        return levels ? launch_fwd_pc<IO, V, CPL, true, true>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream)
+                      : launch_fwd_pc<IO, V, CPL, true, false>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream);
     }
-    return levels ? launch_fwd_pc<IO, V, CPL, false, true, WW>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream)
-                  : launch_fwd_pc<IO, V, CPL, false, false, WW>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream);
+    return levels ? launch_fwd_pc<IO, V, CPL, false, true>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream)
+                  : launch_fwd_pc<IO, V, CPL, false, false>(x, y, levels, bias, aux_kind, g, scale, shift, p, v, stream);
 }
 
 template <typename IO>
@@ -1064,26 +1049,6 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
                       : launch_fwd_seg<IO, false, false>(x, y, levels, bias, aux_kind, sg, scale, shift, p, v, stream);
     }
     const int cpl = pick_cpl(vec, inner);
-    // the quantized axis is the last one: row-group windows, constants in registers (as in the backward; variant bit 11
-    // forces the 256-lane windows with their LDS table, for A/B runs)
-    if (vec > 1 && cpl == vec && inner == 1 && !(variant & (1 << 11)) && (variant != 0 || outer * channels < (int64_t{1} << 27))) {
-        constexpr int kMinRows = 8;       // per workgroup: amortises the lane's VEC divisions
-        const bool split64 = sizeof(typename IO::elem) >= 4 ? g_ww_split64.load() != 2 : g_ww_split64.load() == 1;
-        Variant vw = v;
-        vw.dma = 1;
-        PcGeom gw = make_geom_ww(outer, channels, vec, target, kMinRows, 0, split64);
-        if (v.dma != 1 && (v.dma == 2 || kFwdDmaDefault<IO>)) {
-            const int tgt = variant == 0 ? dev.cu_count * kDmaFwdBlocksPerCU<IO> : target;
-            const PcGeom gd = make_geom_ww(outer, channels, vec, tgt, kMinRows, 0, split64);
-            const int64_t tiles_each = gd.n_tiles / std::max(1, gd.splits);
-            if (v.dma == 2 || (tiles_each >= kFwdDmaDepth && tiles_each <= 64)) {
-                gw = gd;
-                vw.dma = 2;
-            }
-        }
-        if (!grid_fits(gw)) return hipErrorInvalidConfiguration;
-        return fwd_pc_modes<IO, IO::VEC, IO::VEC, true>(x, y, levels, bias, aux_kind, gw, scale, shift, p, vw, stream);
-    }
     PcGeom g = make_geom(outer, channels, inner, vec, target, kFwdPerSlotRows<IO>);
     // LDS-DMA ring (profiles/r02_dma_ab.txt): the default when a workgroup of the grid the ring likes walks at least as
     // many rows as the ring is deep; not for small last-axis tensors, whose per-workgroup channel-table build wants many
@@ -1184,11 +1149,8 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
         };
         // the LDS a workgroup needs does not depend on the split count: size it first, then the residency, then the grid
         const size_t lds = lds_of(geom(0));
-        if (lds > 64 * 1024) {
-            if (dma_depth > 0) return false;      // no room for the ring next to a very wide channel table: register loop
-            result = hipErrorInvalidConfiguration;
-            return true;
-        }
+        if (dma_depth > 0 && lds > 64 * 1024) return false;   // no room for the ring next to a very wide channel table: register loop
+        if (lds > 160 * 1024) { result = hipErrorInvalidConfiguration; return true; }   // (gfx950: 160 KiB of LDS per workgroup)
         const int per_cu = c.whole_rounds ? resident_blocks_per_cu(reinterpret_cast<const void*>(kern), lds) : 0;
         const PcGeom g = geom(per_cu * dev.cu_count);
         const int64_t tiles_each = g.n_tiles / std::max<int64_t>(1, g.splits);
