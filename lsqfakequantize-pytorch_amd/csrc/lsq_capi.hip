@@ -224,6 +224,7 @@ int lsq_hip_backward_from_mask(int dtype, const void* grad, const void* mask, vo
 
 void lsq_hip_debug_set_observe_wg_per_cu(int v) { lsq::set_observe_wg_per_cu(v); }
 
+void lsq_hip_debug_force_ring(int v) { lsq::forced_dma().store(v < 0 || v > 2 ? 0 : v); }
 void lsq_hip_debug_set_ww_min_rows(int v) { lsq::set_ww_min_rows(v); }
 void lsq_hip_debug_set_ww_split64(int v) { lsq::set_ww_split64(v); }
 void lsq_hip_debug_set_fin_ch(int v) { lsq::set_fin_ch(v); }

@@ -26,6 +26,9 @@ int lsq_hip_backward_per_channel_ex(int dtype, const void* grad, const void* x, 
 /* tools only: [grid x, grid y, resident workgroups per CU used for the geometry, numRegs] of this thread's last
  * window-mode backward launch */
 void lsq_hip_debug_last_launch(int* out4);
+/* tests / tools only: loop form of the window-mode per-channel kernels for calls that do not choose one (variant bits 12-13
+ * zero): 0 = the built-in policy, 1 = register loops, 2 = LDS-DMA ring whatever the shape */
+void lsq_hip_debug_force_ring(int v);
 /* tools only: rows a row-group-window workgroup walks at least (0 = the built-in rule) */
 void lsq_hip_debug_set_ww_min_rows(int v);
 /* tools only: row-group windows cut rows of 128 / 192 / 256 lanes into 64-lane windows (4 row groups each) */

@@ -51,6 +51,12 @@ constexpr int kDefaultPcBwdNarrowVariant = encode_variant(1, true, true, 4) | (1
 constexpr int kDefaultPcSegVariant = encode_variant(4, true, true, 16);
 constexpr int kDefaultPcSegNarrowVariant = encode_variant(1, true, true, 16);   // bf16 / fp16 storage
 
+// tests / tools only (lsq_hip_debug_force_ring): the loop form of the window-mode kernels when the caller leaves it open
+inline std::atomic<int>& forced_dma() {
+    static std::atomic<int> v{0};
+    return v;
+}
+
 inline Variant decode_variant(int code, int dflt) {
     if (code == 0) code = dflt;
     Variant v;
@@ -60,6 +66,7 @@ inline Variant decode_variant(int code, int dflt) {
     v.blocks_per_cu = (code >> 16) & 0xff;
     v.chunked = ((code >> 10) & 1) != 0;
     v.dma = (code >> 12) & 3;
+    if (v.dma == 0) v.dma = forced_dma().load(std::memory_order_relaxed);
     if (v.unroll != 1 && v.unroll != 2 && v.unroll != 4 && v.unroll != 8) v.unroll = 4;
     if (v.blocks_per_cu < 1) v.blocks_per_cu = 1;
     if (v.blocks_per_cu > kMaxBlocksPerCU) v.blocks_per_cu = kMaxBlocksPerCU;

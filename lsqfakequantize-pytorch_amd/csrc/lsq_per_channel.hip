@@ -1185,7 +1185,10 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
     // as many row tiles as the ring is deep -- with the grid the ring likes, kDmaBwdBlocksPerCU workgroups per CU;
     // variant bits 12-13 force either path for A/B runs (1 = registers, 2 = ring).
     constexpr bool kDmaAble = V * sizeof(typename IO::elem) == 16;
-    constexpr int kDmaDepth = 4;
+#ifndef LSQ_BWD_DMA_DEPTH
+#define LSQ_BWD_DMA_DEPTH 4
+#endif
+    constexpr int kDmaDepth = LSQ_BWD_DMA_DEPTH;
     if constexpr (kDmaAble) {
         // (4- and 8-byte storage with one channel per lane, CPL == 1, keeps its register loop: it already has eight loads
         // in flight per lane and few registers, the ring only adds its LDS round trip -- measured 3-6 % slower)
