@@ -143,7 +143,7 @@ def cpu_baseline(shape, workload):
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--shape", ",".join(str(s) for s in shape),
            "--workload", workload]
     try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
         for line in reversed(out.stdout.strip().splitlines()):
             if line.startswith("{"):
                 return json.loads(line)
@@ -183,7 +183,7 @@ def measure_traffic(a, kernel_substr):
             cmd = [rocprof, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "bench", "--", sys.executable,
                    os.path.abspath(__file__), "--workload", a.workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
                    "--no-measure-traffic", "--no-yardstick", "--host-binding", a.host_binding]
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd="/tmp", env=env)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=180, cwd="/tmp", env=env)
             got = _pmc_mean(d, ctr, kernel_substr)
             if got is None:
                 return None, "%s pass produced no counter rows for %s (exit %d): %s" % (ctr, kernel_substr, r.returncode,
