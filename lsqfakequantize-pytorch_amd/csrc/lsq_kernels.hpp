@@ -291,6 +291,7 @@ void set_observe_wg_per_cu(int v);
 void set_ww_min_rows(int v);
 int get_ww_min_rows();
 void set_ww_split64(int v);
+void set_ww_big(int v);
 void set_fin_ch(int v);
 size_t minmax_workspace_bytes(int io_vec, int elem_arith_bytes, int64_t outer, int64_t channels, int64_t inner);
 template <typename IO>

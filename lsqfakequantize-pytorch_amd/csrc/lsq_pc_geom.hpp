@@ -195,18 +195,19 @@ static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec,
 // are its own: their constants live in registers, there is no LDS table, and the epilogue is a fixed-order sum of the
 // row groups through LDS.
 static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_blocks, int min_rows, int resident_blocks,
-                                  bool split64 = false) {
+                                  bool split64 = false, int block = kBlock) {
     PcGeom g;
     g.outer = outer; g.C = C; g.inner = 1; g.L = C; g.vec = vec;
     g.fits32 = (g.L + static_cast<int64_t>(kBlock) * vec) < 0x7fffffffLL ? 1 : 0;
     const int64_t lanes_per_row = g.L / vec;
-    if (lanes_per_row <= kBlock && !(split64 && lanes_per_row >= 128 && lanes_per_row % 64 == 0)) {
+    // (block > kBlock: the 1024-lane workgroups of mid-sized tensors -- more row groups per workgroup, never narrower windows)
+    if (lanes_per_row <= kBlock && !(block == kBlock && split64 && lanes_per_row >= 128 && lanes_per_row % 64 == 0)) {
         g.ww_lanes = static_cast<int32_t>(lanes_per_row);
-        g.R = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(kBlock / lanes_per_row, outer)));
+        g.R = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(block / lanes_per_row, outer)));
         g.n_windows = 1;
     } else {
         g.ww_lanes = 64;
-        g.R = kBlock / 64;
+        g.R = block / 64;
         g.n_windows = (lanes_per_row + 63) / 64;
     }
     g.block_threads = static_cast<int32_t>((static_cast<int64_t>(g.R) * g.ww_lanes + 63) / 64 * 64);

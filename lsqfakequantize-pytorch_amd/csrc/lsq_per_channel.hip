@@ -257,8 +257,8 @@ __device__ __forceinline__ void segmented_wave_accumulate(int key, double s, dou
 // kernel, which has the registers, streams the same tensor 20 % faster when all of a workgroup's loads are issued up
 // front: profiles/r02_pc_variants_eval.txt).
 template <typename IO, int V, int CPL, bool SYM, bool INIT, bool EVAL, int UNROLL, bool NTL, bool NTS, bool PIPE, bool WW = false,
-          int DMA = 0>
-__global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__ grad, const void* __restrict__ x,
+          int DMA = 0, int BLOCK = kBlock>
+__global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ grad, const void* __restrict__ x,
                                                         void* __restrict__ dx, PcGeom g,
                                                         const typename IO::arith* __restrict__ scale,
                                                         const typename IO::arith* __restrict__ shift,
@@ -269,6 +269,7 @@ __global__ __launch_bounds__(kBlock) void bwd_pc_kernel(const void* __restrict__
     using LC = LaneChannels<T, V, CPL>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     static_assert(!WW || (CPL == V && V > 1), "row-group windows: one channel per packet component");
+    static_assert(BLOCK == kBlock || (WW && DMA > 0), "768/1024-lane workgroups: row-group windows on the ring only");
     QSlot<T>* table = reinterpret_cast<QSlot<T>*>(smem);
     double* lds_s = reinterpret_cast<double*>(smem + static_cast<size_t>(g.k_slots) * sizeof(QSlot<T>));
     double* lds_b = lds_s + g.k_slots;
@@ -911,7 +912,12 @@ static std::atomic<int> g_ww_min_rows_override{0};          // tools only (lsq_h
 void set_ww_min_rows(int v) { g_ww_min_rows_override.store(v); }
 static std::atomic<int> g_ww_split64{0};                   // tools only: rows of 128 / 192 / 256 lanes as 64-lane windows
 void set_ww_split64(int v) { g_ww_split64.store(v); }
-int get_ww_min_rows() { return g_ww_min_rows_override.load() | (g_ww_split64.load() << 16); }   // (the geometry knobs, as one key)
+static std::atomic<int> g_ww_big{0};                       // tools only: 1024-lane workgroups, 0 = policy, 1 = always, 2 = never
+void set_ww_big(int v) { g_ww_big.store(v); }
+int get_ww_min_rows() { return g_ww_min_rows_override.load() | (g_ww_split64.load() << 16) | (g_ww_big.load() << 20); }   // (the geometry knobs, as one key)
+// (16-bit storage: 768 lanes -- its kernel needs ~140 registers, 1024 lanes would cap it at 128 and spill)
+template <int ELEM_BYTES>
+constexpr int kBigBlockOf = ELEM_BYTES < 4 ? 768 : 1024;
 constexpr int kWwBwdBlocksPerCU = 4;     // row-group windows: one full round for every storage type (3-4 resident per CU)
 // Rows a forward workgroup walks at least, per unit of its per-workgroup overhead (make_geom): that overhead is only
 // the channel-table build -- VEC channels per lane when the quantized axis is the last one, so twice as heavy per
@@ -938,10 +944,11 @@ size_t bwd_pc_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64
             }
             if (vi == 0 && inner == 1 && io_vec > 1 && channels % io_vec == 0) {
                 const int ovr = g_ww_min_rows_override.load(std::memory_order_relaxed);
-                const int min_rows = ovr > 0 ? ovr : (107 + (16 / io_vec) - 1) / (16 / io_vec);   // kWwMinRows of the storage type
+                const int min_rows = ovr > 0 ? ovr : (io_vec > 4 ? 16 : (107 + (16 / io_vec) - 1) / (16 / io_vec));   // kWwMinRows of the storage type
                 for (int res = 0; res <= 8; ++res) {
-                    for (int s64 = 0; s64 < 2; ++s64) {
-                        const PcGeom g = make_geom_ww(outer, channels, io_vec, dev.cu_count * bpc, min_rows, dev.cu_count * res, s64 != 0);
+                    for (int s64 = 0; s64 < 3; ++s64) {     // whole rows, 64-lane windows, 1024-lane workgroups
+                        const PcGeom g = make_geom_ww(outer, channels, io_vec, dev.cu_count * bpc, min_rows, dev.cu_count * res, s64 == 1,
+                                                      s64 == 2 ? (io_vec > 4 ? kBigBlockOf<2> : kBigBlockOf<4>) : kBlock);
                         need = std::max(need, static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2));
                     }
                 }
@@ -1100,9 +1107,14 @@ struct BwdPcCall {
 };
 
 
-// rows a row-group-window workgroup walks at least: keeps its 16-byte-per-slot partial row under ~5 % of what it streams
+// rows a row-group-window workgroup walks at least.  4- and 8-byte storage: enough to keep its 16-byte-per-slot partial
+// row under ~5 % of what it streams.  16-bit storage: 16 -- the tensors this floor binds on (fewer rows than workgroups
+// wanted x floor) are latency-bound, every row a wave walks is another ~0.6 us on its serial chain, and the extra partial
+// bytes cost less than that ([3152,768] bf16 21 -> 13.5 us, [4096,1024] 22 -> 14.6 us, profiles/r02_ww_rows_per_workgroup.txt)
 template <typename IO>
-constexpr int kWwMinRows = (107 + static_cast<int>(sizeof(typename IO::elem)) - 1) / static_cast<int>(sizeof(typename IO::elem));
+constexpr int kWwMinRows = sizeof(typename IO::elem) < 4
+                               ? 16
+                               : (107 + static_cast<int>(sizeof(typename IO::elem)) - 1) / static_cast<int>(sizeof(typename IO::elem));
 template <typename IO>
 static inline int ww_min_rows() {
     const int o = g_ww_min_rows_override.load(std::memory_order_relaxed);
@@ -1128,13 +1140,14 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
     // The geometry depends on how many workgroups of the chosen instantiation fit on the chip at once, so it is built
     // here, where the kernel is known, together with the launch and the finalize.
     // returns false (nothing launched) when `min_tiles` is asked for and a workgroup would walk fewer row tiles than that
-    auto run = [&](auto kern, int dma_depth, int target_blocks, int64_t min_tiles, int64_t max_tiles = INT64_MAX) -> bool {
+    auto run = [&](auto kern, int dma_depth, int target_blocks, int64_t min_tiles, int64_t max_tiles = INT64_MAX,
+                   int block = kBlock) -> bool {
         const DeviceInfo& dev = device_info();
         auto geom = [&](int resident) {
             // rows of 128 / 192 / 256 lanes: 4- and 8-byte storage cuts them into 64-lane windows of four row groups
             // ([65536,1024] fp32 backward 157 -> 140 us, profiles/r02_ww_split64_ab.txt); 16-bit storage gains nothing
             const bool split64 = sizeof(typename IO::elem) >= 4 ? g_ww_split64.load() != 2 : g_ww_split64.load() == 1;
-            return WW ? make_geom_ww(c.outer, c.C, V, target_blocks, ww_min_rows<IO>(), resident, split64)
+            return WW ? make_geom_ww(c.outer, c.C, V, target_blocks, ww_min_rows<IO>(), resident, split64, block)
                       : make_geom(c.outer, c.C, c.inner, V, target_blocks, 27, resident);
         };
         auto lds_of = [&](const PcGeom& gg) {
@@ -1148,10 +1161,16 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
             return b;
         };
         // the LDS a workgroup needs does not depend on the split count: size it first, then the residency, then the grid
-        const size_t lds = lds_of(geom(0));
-        if (dma_depth > 0 && lds > 64 * 1024) return false;   // no room for the ring next to a very wide channel table: register loop
+        const PcGeom g0 = geom(0);
+        const size_t lds = lds_of(g0);
+        // no room for the ring next to a very wide channel table: register loop (a 1024-lane workgroup has the CU to itself)
+        if (dma_depth > 0 && lds > (block > kBlock ? 160 : 64) * 1024) return false;
         if (lds > 160 * 1024) { result = hipErrorInvalidConfiguration; return true; }   // (gfx950: 160 KiB of LDS per workgroup)
-        const int per_cu = c.whole_rounds ? resident_blocks_per_cu(reinterpret_cast<const void*>(kern), lds) : 0;
+        int per_cu = c.whole_rounds ? resident_blocks_per_cu(reinterpret_cast<const void*>(kern), lds) : 0;
+        if (block > kBlock && per_cu > 0) {      // the register bound counts four-wave workgroups: convert it
+            const int by_regs = resident_blocks_by_registers(reinterpret_cast<const void*>(kern)) * 4 / std::max(1, g0.block_threads / 64);
+            per_cu = std::max(1, std::min(per_cu, by_regs));
+        }
         const PcGeom g = geom(per_cu * dev.cu_count);
         const int64_t tiles_each = g.n_tiles / std::max<int64_t>(1, g.splits);
         if (tiles_each < min_tiles || tiles_each > max_tiles) return false;
@@ -1201,6 +1220,22 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
             // profiles/r02_ww_min_rows_sweep.txt)
             const bool big_wide = WW && sizeof(typename IO::elem) >= 4 &&
                                   c.outer * c.C * static_cast<int64_t>(sizeof(typename IO::elem)) > (int64_t{160} << 20);
+            if constexpr (WW && !EVAL) {
+                // Mid-sized tensors whose rows fit one window (8 M .. 48 M elements: [64,197,768], [256,197,768], NHWC
+                // [16,56,56,256]): ONE 768/1024-lane workgroup per CU instead of three or four 3-4-wave ones -- the same
+                // waves in flight, evenly over the four SIMDs (3-wave workgroups load them 3:2:2:2), a third of the partial
+                // rows, constants and epilogues.  6-12 % faster there, slower below (a [16,197,768] wants many short
+                // workgroups) and no gain above (profiles/r02_ww_big_ab.txt).
+                const int big = g_ww_big.load(std::memory_order_relaxed);
+                const int64_t elems = c.outer * c.C;
+                const bool use_big = big == 1 || (big == 0 && c.default_variant && c.C / V <= kBlock &&
+                                                  elems >= (int64_t{1} << 23) && elems < (int64_t{3} << 24));
+                constexpr int kBigBlock = kBigBlockOf<sizeof(typename IO::elem)>;
+                if (use_big &&
+                    run(bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, 1, true, true, false, WW, kDmaDepth, kBigBlock>, kDmaDepth,
+                        device_info().cu_count, big == 1 ? 0 : 2, INT64_MAX, kBigBlock))
+                    return result;
+            }
             if (!(big_wide && c.v.dma != 2) &&
                 run(bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, 1, true, true, false, WW, kDmaDepth>, kDmaDepth, target,
                     c.v.dma == 2 ? 0 : kDmaDepth))

@@ -111,6 +111,50 @@ def test_row_group_windows_equal_256_lane_windows(E, dtype):
                 assert torch.allclose(u.double(), v.double(), rtol=2e-6 if dtype == torch.bfloat16 else 1e-6, atol=1e-30), (shape, str(dtype), bpc)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float64, torch.float16])
+@pytest.mark.parametrize("mode", ["train", "sym", "init"])
+def test_768_and_1024_lane_row_group_workgroups(E, dtype, mode):
+    """last-axis shapes: one 768/1024-lane workgroup per CU (the policy's choice for 8 M .. 48 M elements, forced here on
+    small and ragged shapes: fewer rows than row groups, rows per group < ring depth, every window width) against the
+    3-4-wave workgroups.  dx bit-identical; d_scale / d_shift: the same terms summed in another order."""
+    from torchlsq import synth
+    dev = torch.device("cuda:0")
+    lib = E.library()
+    pdt = torch.float64 if dtype == torch.float64 else torch.float32
+    sym, init = mode == "sym", mode == "init"
+    try:
+        for k, (shape, axis) in enumerate([((1030, 4096), 1), ((1001, 768), 1), ((333, 7, 256), 2), ((50, 8), 1), ((4100, 1024), 1),
+                                           ((7, 512), 1), ((3000, 128), 1), ((3, 2048), 1), ((20000, 384), 1), ((1, 768), 1)]):
+            n = int(np.prod(shape))
+            x = synth.normal_like(n, 1900 + k, 0.4, 1.0, dtype=dtype, device=dev).view(shape)
+            g = synth.normal_like(n, 1950 + k, 0.0, 1e-2, dtype=dtype, device=dev).view(shape)
+            C = shape[axis]
+            s = synth.uniform_like(C, 1970 + k, 0.02, 0.2, device=dev, dtype=pdt)
+            b = synth.normal_like(C, 1990 + k, 0.0, 0.1, device=dev, dtype=pdt)
+            q = (-8, 7, -128, 127, False, 1.0, sym, False, init)       # no gradient scaler: |term| <= 8 |g|
+            outs = {}
+            for knob in (2, 1):
+                lib.lsq_hip_debug_set_ww_big(knob)
+                E._WS_BYTES_PC.clear()
+                outs[knob] = E.hip_backward_per_channel(g, x, s, b, axis, *q)
+                torch.cuda.synchronize()
+            assert _bits(outs[1][0]) == _bits(outs[2][0]), (shape, str(dtype), mode)
+            # 16-bit storage pre-sums rows in fp32 and the row sets differ with the workgroup size: the bar is the parity
+            # bar, 1e-6 of the sum of the |terms| (bounded here by 8 sum|g| per channel); wider storage sums in fp64
+            drive = (2.0 * (x.double().abs() + 1.6)) if init else g.double().abs()     # init mode: 2 (y - x) drives the terms
+            bound = 8.0 * drive.movedim(axis, -1).reshape(-1, C).sum(0)
+            tol = (1e-6 if dtype in (torch.bfloat16, torch.float16) else 1e-12) * bound + 1e-30
+            for u, v in ((outs[1][1], outs[2][1]), (outs[1][2], outs[2][2])):
+                if dtype in (torch.float32, torch.float64):
+                    assert torch.allclose(u.double(), v.double(), rtol=1e-6, atol=0) or bool(((u.double() - v.double()).abs() <= tol).all()), \
+                        (shape, str(dtype), mode)
+                else:
+                    assert bool(((u.double() - v.double()).abs() <= tol).all()), (shape, str(dtype), mode)
+    finally:
+        lib.lsq_hip_debug_set_ww_big(0)
+        E._WS_BYTES_PC.clear()
+
+
 def test_default_policy_takes_the_ring_on_large_shapes(E):
     """the launch note of the window-mode backward reports the grid; with the ring a [256,2048,7,7] bf16 backward is
     sized for 4 resident workgroups per CU (LDS-bound) and fills one round"""

@@ -112,7 +112,10 @@ def test_random_cases_against_the_oracle(seed):
         # picks by shape: force either one on a share of the cases so that both meet every kind of input
         loop_form = int(rng.choice([0, 0, 1, 2, 2]))
         extension.library().lsq_hip_debug_force_ring(loop_form)
-        tag += " loop=%d" % loop_form
+        # ... and the row-group windows (quantized axis last) two workgroup sizes: 768/1024 lanes on a share of the cases
+        ww_big = int(rng.choice([0, 0, 1]))
+        extension.library().lsq_hip_debug_set_ww_big(ww_big)
+        tag += " loop=%d big=%d" % (loop_form, ww_big)
         extension.set_host_binding(binding)
         try:
             xt = _layout(rng, torch.from_numpy(xs).to(dev).to(dtype), kind).requires_grad_(True)
@@ -126,6 +129,7 @@ def test_random_cases_against_the_oracle(seed):
         finally:
             extension.set_host_binding("native")
             extension.library().lsq_hip_debug_force_ring(0)
+            extension.library().lsq_hip_debug_set_ww_big(0)
         if narrow:      # parity for 16-bit storage is defined by the build: the fp32 result rounded to the storage type
             want_y = torch.from_numpy(np.ascontiguousarray(oy)).to(dtype)
             want_dx = torch.from_numpy(np.ascontiguousarray(r.dx)).to(dtype)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run forward + backward of ONE per-channel shape a few times (to be wrapped in rocprofv3 --kernel-trace --stats).
-usage: python3 tools/exp_one_shape.py 64,197,768 2 float32"""
+usage: python3 tools/exp_one_shape.py 64,197,768 2 float32 [ww_big knob: 0 policy / 1 always / 2 never]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
@@ -11,6 +11,11 @@ shape = tuple(int(v) for v in sys.argv[1].split(","))
 axis = int(sys.argv[2])
 dt = getattr(torch, sys.argv[3]) if len(sys.argv) > 3 else torch.float32
 dev = torch.device("cuda:0")
+if len(sys.argv) > 4:
+    import ctypes
+    from torchlsq import extension as E
+    E.library().lsq_hip_debug_set_ww_big.argtypes = [ctypes.c_int]
+    E.library().lsq_hip_debug_set_ww_big(int(sys.argv[4]))
 n = 1
 for d in shape: n *= d
 x = synth.normal_like(n, 1, 0.5, 1.0, device=dev, dtype=dt).view(shape)
