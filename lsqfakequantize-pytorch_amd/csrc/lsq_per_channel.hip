@@ -1070,9 +1070,15 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
         const int64_t tiles_each = gd.n_tiles / std::max(1, gd.splits);
         // (not on very long walks either: [32,2048,4096] fp32, 128 rows per workgroup, 380 us with the register loops,
         // 450-580 us on the ring, profiles/r02_dma_ab_big_shapes.txt)
+        // A 16-bit last-axis window has 2048 channels, a 32 KiB table: the ring does not fit next to it.  Those shapes still
+        // take the ring's grid -- half the workgroups, half the table builds -- with the register loop
+        // ([8192,4096] bf16 28.8 us against 34.3 us on the usual grid, [16384,2048] 29.3 against 34.6,
+        // profiles/r02_fwd_lastaxis_grid.txt).
+        const size_t lds_ring = ((static_cast<size_t>(gd.k_slots) * sizeof(QSlot<typename IO::arith>) + 1023) & ~size_t(1023)) +
+                                static_cast<size_t>(kBlock / 64) * kFwdDmaDepth * 1024;
         if (v.dma == 2 || (tiles_each >= kFwdDmaDepth && tiles_each <= 64 && !small_last_axis)) {
             g = gd;
-            vv.dma = 2;
+            vv.dma = lds_ring <= 64 * 1024 ? 2 : 1;
         }
     }
     if (!grid_fits(g)) return hipErrorInvalidConfiguration;
