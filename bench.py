@@ -72,6 +72,9 @@ def parse_args(argv=None):
     ap.add_argument("--measure-traffic", dest="measure_traffic", action="store_true", default=None,
                     help="measure roofline.traffic in this run with two rocprofv3 --pmc child passes (default at N = 1)")
     ap.add_argument("--no-measure-traffic", dest="measure_traffic", action="store_false")
+    ap.add_argument("--buffers", type=int, default=0,
+                    help="input buffer sets the steps rotate through (0 = auto: as many as make the streamed working set exceed "
+                         "1 GiB, so that the 256 MB Infinity Cache cannot serve the reads of a small workload; 1 = re-use one set)")
     ap.add_argument("--no-yardstick", action="store_true", help="skip the ATen add / copy rates measured after the timed region")
     ap.add_argument("--host-binding", default="auto", choices=["auto", "native", "ctypes"],
                     help="host layer above the C ABI: the C++ torch binding (_lsq_torch.so) or the Python/ctypes one")
@@ -275,6 +278,19 @@ def run_rank(a):
         raise SystemExit("--graph is a 1-GPU measurement")
     x, g, scale, shift = synth.make_inputs(c, device=dev, dtype=dt, shape=shape)
     n_local = x.numel()
+    # Small workloads re-using one set of buffers are partly served by the 256 MB Infinity Cache (config 5 streams 308 MB per
+    # step in fp32, 154 MB in bf16), which is not the HBM rate the roofline is about: the steps rotate through `n_sets`
+    # copies of (x, grad), more than 1 GiB of inputs in total.  Config 2 (2.4 GB per step) needs one set.
+    set_bytes = 2 * n_local * esz
+    n_sets = a.buffers if a.buffers > 0 else max(1, min(16, -(-(1 << 30) // set_bytes)))
+    xs, gs = [x], [g]
+    for _ in range(n_sets - 1):
+        xs.append(x.clone())
+        gs.append(g.clone())
+    cur = [0]
+
+    def bset():       # the backward works on a set the forward touched n_sets / 2 steps ago: not on lines the forward just read
+        return (cur[0] + n_sets // 2) % n_sets
     n_global = n_local * world
     q = (c["qmin"], c["qmax"], c["tmin"], c["tmax"])
     sym = not c["affine"]
@@ -284,11 +300,11 @@ def run_rank(a):
     def fwd():
         if a.variant_fwd:
             if per_channel:
-                return extension.hip_forward_per_channel(x, scale, shift, axis, *tail, variant=a.variant_fwd)
-            return extension.hip_forward_per_tensor(x, scale, shift, *tail, variant=a.variant_fwd)
+                return extension.hip_forward_per_channel(xs[cur[0]], scale, shift, axis, *tail, variant=a.variant_fwd)
+            return extension.hip_forward_per_tensor(xs[cur[0]], scale, shift, *tail, variant=a.variant_fwd)
         if per_channel:
-            return ops.lsq_forward_per_channel(x, scale, shift, axis, *tail)
-        return ops.lsq_forward_per_tensor(x, scale, shift, *tail)
+            return ops.lsq_forward_per_channel(xs[cur[0]], scale, shift, axis, *tail)
+        return ops.lsq_forward_per_tensor(xs[cur[0]], scale, shift, *tail)
 
     pending = []   # N > 1: the previous step's in-flight all-reduce (RCCL runs it on its own stream)
 
@@ -296,16 +312,16 @@ def run_rank(a):
         if world == 1:
             if a.variant_bwd:
                 if per_channel:
-                    return extension.hip_backward_per_channel(g, x, scale, shift, axis, *tail, variant=a.variant_bwd)
-                return extension.hip_backward_per_tensor(g, x, scale, shift, *tail, variant=a.variant_bwd)
+                    return extension.hip_backward_per_channel(gs[bset()], xs[bset()], scale, shift, axis, *tail, variant=a.variant_bwd)
+                return extension.hip_backward_per_tensor(gs[bset()], xs[bset()], scale, shift, *tail, variant=a.variant_bwd)
             if per_channel:
-                return ops.lsq_backward_per_channel(g, x, scale, shift, axis, *tail)
-            return ops.lsq_backward_per_tensor(g, x, scale, shift, *tail)
+                return ops.lsq_backward_per_channel(gs[bset()], xs[bset()], scale, shift, axis, *tail)
+            return ops.lsq_backward_per_tensor(gs[bset()], xs[bset()], scale, shift, *tail)
         # batch-sharded: local fused backward with the GLOBAL numel in the gradient scaler, then ONE
         # all-reduce of the packed fp64 [d_scale, d_shift] sums.  The collective is issued async and
         # consumed one step later (d_scale/d_shift are only needed by the optimizer), so its latency
         # hides behind the next step's kernels; every reduction is completed inside the timed region.
-        dx, wide, work = sharded_backward(g, x, scale, shift, *q, axis, True, 1.0, c["affine"], per_channel, False, False,
+        dx, wide, work = sharded_backward(gs[bset()], xs[bset()], scale, shift, *q, axis, True, 1.0, c["affine"], per_channel, False, False,
                                           None, n_global, async_op=True)
         drain()
         pending.append((wide, work))
@@ -318,20 +334,25 @@ def run_rank(a):
             ds_db = wide.to(torch.float32)                # the rounding to the parameter type
         return None
 
-    step_graph = None
+    step_graphs = None
     if a.graph:
         st = torch.cuda.Stream()
+        step_graphs = []
         with torch.cuda.stream(st):
-            fwd(); bwd()
-            step_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(step_graph, stream=st):
-                y = fwd()
-                r = bwd()
+            for k in range(n_sets):          # one captured step per buffer set
+                cur[0] = k
+                fwd(); bwd()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=st):
+                    y = fwd()
+                    r = bwd()
+                step_graphs.append(gr)
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        if step_graph is not None:
-            step_graph.replay()
+    for i in range(a.warmup):
+        cur[0] = i % n_sets
+        if step_graphs is not None:
+            step_graphs[cur[0]].replay()
         else:
             y = fwd()
             r = bwd()
@@ -348,11 +369,12 @@ def run_rank(a):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if step_graph is not None:
+    if step_graphs is not None:
         for i in range(a.steps):
-            step_graph.replay()
+            step_graphs[i % n_sets].replay()
     else:
         for i in range(a.steps):
+            cur[0] = i % n_sets
             e = ev[i]
             if e is None:
                 y = fwd()
@@ -369,9 +391,10 @@ def run_rank(a):
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if step_graph is not None:
-        for e in ev:
+    if step_graphs is not None:
+        for i, e in enumerate(ev):
             if e is not None:
+                cur[0] = i % n_sets
                 e[0].record(); y = fwd(); e[1].record(); r = bwd(); e[2].record()
         torch.cuda.synchronize()
 
@@ -434,7 +457,11 @@ def run_rank(a):
                        "storage": dtype_name, "arithmetic": "float32",
                        "elements_per_gpu": n_local, "global_elements": n_global,
                        "parallelism": "dp%d" % world, "host_binding": binding,
-                       "launch": "hip-graph replay" if a.graph else "eager"},
+                       "launch": "hip-graph replay" if a.graph else "eager",
+                       "input_buffer_sets": n_sets,
+                       "input_buffers_note": ("the steps rotate through %d copies of (x, grad), %.2f GB of inputs: reads come from HBM, "
+                                              "not from the 256 MB Infinity Cache" % (n_sets, n_sets * set_bytes / 1e9)) if n_sets > 1 else
+                                             "one set of input buffers (%.2f GB per step streamed, beyond the 256 MB Infinity Cache)" % (5 * n_local * esz / 1e9)},
             "roofline": {"bound": "hbm", "kernel": "lsq::%s<%s> (fused dx + d_scale/d_shift reduction)" % (kb, io),
                          "achieved": round(bwd_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(bwd_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
@@ -455,19 +482,20 @@ def run_rank(a):
             # vendor's own kernels on the same two traffic shapes (ATen's vectorised add = 2 reads : 1 write like the
             # backward; its copy = 1 read : 1 write like the forward).  Not part of `value`.
             try:
-                def _gbs(fn, bytes_per_elem, reps=5):
-                    fn()
+                def _gbs(fn, bytes_per_elem):
+                    reps = max(5, n_sets)
+                    fn(0)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    for _ in range(reps):
-                        fn()
+                    for k in range(reps):
+                        fn(k % n_sets)
                     e1.record()
                     e1.synchronize()
                     return round(bytes_per_elem * n_local / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9, 1)
                 scratch = torch.empty_like(x)
                 line["roofline"]["same_box_reference_kernels"] = {
-                    "aten_add_2r1w_GBps": _gbs(lambda: torch.add(g, x, out=scratch), bytes_bwd),
-                    "aten_copy_1r1w_GBps": _gbs(lambda: scratch.copy_(x), bytes_fwd)}
+                    "aten_add_2r1w_GBps": _gbs(lambda k: torch.add(gs[k], xs[k], out=scratch), bytes_bwd),
+                    "aten_copy_1r1w_GBps": _gbs(lambda k: scratch.copy_(xs[k]), bytes_fwd)}
                 del scratch
             except Exception as e:      # context only: never let it break the bench line
                 line["roofline"]["same_box_reference_kernels"] = {"error": repr(e)}

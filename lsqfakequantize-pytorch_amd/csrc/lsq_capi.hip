@@ -228,6 +228,7 @@ void lsq_hip_debug_force_ring(int v) { lsq::forced_dma().store(v < 0 || v > 2 ? 
 void lsq_hip_debug_set_ww_min_rows(int v) { lsq::set_ww_min_rows(v); }
 void lsq_hip_debug_set_ww_split64(int v) { lsq::set_ww_split64(v); }
 void lsq_hip_debug_set_ww_big(int v) { lsq::set_ww_big(v); }
+void lsq_hip_debug_set_ring_nt(int v) { lsq::set_ring_nt(v); }
 void lsq_hip_debug_set_fin_ch(int v) { lsq::set_fin_ch(v); }
 
 void lsq_hip_debug_last_launch(int* out4) {

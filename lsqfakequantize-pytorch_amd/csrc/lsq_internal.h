@@ -33,6 +33,7 @@ void lsq_hip_debug_force_ring(int v);
 void lsq_hip_debug_set_ww_min_rows(int v);
 /* tools only: row-group windows cut rows of 128 / 192 / 256 lanes into 64-lane windows (4 row groups each) */
 void lsq_hip_debug_set_ww_split64(int v);   /* 0 = default (on for 4/8-byte storage), 1 = on for all, 2 = off */
+void lsq_hip_debug_set_ring_nt(int v);      /* streaming hint on the LDS-DMA copies: 0 = policy, 1 = on, 2 = off */
 void lsq_hip_debug_set_ww_big(int v);       /* 1024-lane row-group workgroups: 0 = policy, 1 = always, 2 = never */
 /* tools only: channels (slots) per finalize workgroup, a power of two <= 32 (0 = the built-in rule) */
 void lsq_hip_debug_set_fin_ch(int v);

@@ -292,6 +292,7 @@ void set_ww_min_rows(int v);
 int get_ww_min_rows();
 void set_ww_split64(int v);
 void set_ww_big(int v);
+void set_ring_nt(int v);
 void set_fin_ch(int v);
 size_t minmax_workspace_bytes(int io_vec, int elem_arith_bytes, int64_t outer, int64_t channels, int64_t inner);
 template <typename IO>

@@ -61,12 +61,24 @@ __device__ __forceinline__ void store_elems(void* base, int64_t e, const typenam
 // VGPR, which is the point: a streaming kernel whose registers are taken by its arithmetic can still keep several rows
 // of HBM requests outstanding per wave.  hipcc does not count asm memory operations in its s_waitcnt bookkeeping:
 // the reader orders itself with wait_vm<N>() below (cdna_hip_programming.md: LDS-DMA recipe, M0 rule).
+template <bool NT = false>
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
+    if constexpr (NT) {     // streaming hint, as global_load ... nt
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gsrc), "s"(lds_dst)
+                     : "memory");
+    } else {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gsrc), "s"(lds_dst)
+                     : "memory");
+    }
+}
+__device__ __forceinline__ void glds16_rt(const void* gsrc, uint32_t lds_dst, int nt) {     // nt wave-uniform
+    if (nt) glds16<true>(gsrc, lds_dst);
+    else glds16<false>(gsrc, lds_dst);
 }
 // Wait until at most N of this wave's vector-memory operations are outstanding.  They complete in issue order on gfx9
 // (loads, stores and LDS-DMA share the one counter), so "at most N outstanding" = "everything but the youngest N is done".
@@ -113,6 +125,7 @@ struct PcGeom {
     int32_t fits32;          // L < 2^31: index divisions in 32 bits
     int32_t ww_lanes;        // row-group windows (make_geom_ww): lanes per row group; 0 otherwise
     int32_t block_threads;   // workgroup size to launch (kBlock except for row-group windows)
+    int32_t ring_nt;         // LDS-DMA ring: issue its copies with the streaming hint (global_load_lds ... nt)
 };
 
 // How many workgroups along the row axis?  `want` is what the caller asked for (workgroups per CU x CUs / windows).
@@ -167,6 +180,7 @@ static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec,
     g.n_tiles = (outer + g.R - 1) / g.R;
     g.ww_lanes = 0;
     g.block_threads = kBlock;
+    g.ring_nt = 0;
     // keep the partial-sum traffic (16 B per slot per workgroup) below ~5 % of the streamed bytes -- except for small
     // tensors (< 2 M elements), which are latency- not traffic-bound: there a workgroup takes as few rows as the grid
     // target allows ([128, 768]: 128 workgroups of one row instead of 7 walking 21 rows one group after the other)
@@ -197,6 +211,7 @@ static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec,
 static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_blocks, int min_rows, int resident_blocks,
                                   bool split64 = false, int block = kBlock) {
     PcGeom g;
+    g.ring_nt = 0;
     g.outer = outer; g.C = C; g.inner = 1; g.L = C; g.vec = vec;
     g.fits32 = (g.L + static_cast<int64_t>(kBlock) * vec) < 0x7fffffffLL ? 1 : 0;
     const int64_t lanes_per_row = g.L / vec;

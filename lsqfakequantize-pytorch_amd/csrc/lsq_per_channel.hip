@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
         int64_t row = walk.row(i);
         row = row < g.outer ? row : g.outer - 1;
         const int64_t e = row * g.L + (site.live ? site.p0 : 0);
-        glds16(static_cast<const E*>(x) + e, ring_lds + static_cast<uint32_t>(i % (DMA > 0 ? DMA : 1)) * kStage);
+        glds16_rt(static_cast<const E*>(x) + e, ring_lds + static_cast<uint32_t>(i % (DMA > 0 ? DMA : 1)) * kStage, g.ring_nt);
     };
     if constexpr (DMA > 0) {
         for (int64_t i = 0; i < DMA && i < dma_n; ++i) dma_issue(i);
@@ -301,8 +301,8 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
         row = row < g.outer ? row : g.outer - 1;
         const int64_t e = row * g.L + (site.live ? site.p0 : 0);
         const uint32_t dst = ring_lds + static_cast<uint32_t>(i % (DMA > 0 ? DMA : 1)) * kDmaStageBytes;
-        glds16(static_cast<const E*>(grad) + e, dst);
-        glds16(static_cast<const E*>(x) + e, dst + 64 * 16);
+        glds16_rt(static_cast<const E*>(grad) + e, dst, g.ring_nt);
+        glds16_rt(static_cast<const E*>(x) + e, dst + 64 * 16, g.ring_nt);
     };
     if constexpr (DMA > 0) {
         for (int64_t i = 0; i < DMA && i < dma_n; ++i) dma_issue(i);    // in flight before the constants are built
@@ -912,9 +912,20 @@ static std::atomic<int> g_ww_min_rows_override{0};          // tools only (lsq_h
 void set_ww_min_rows(int v) { g_ww_min_rows_override.store(v); }
 static std::atomic<int> g_ww_split64{0};                   // tools only: rows of 128 / 192 / 256 lanes as 64-lane windows
 void set_ww_split64(int v) { g_ww_split64.store(v); }
+static std::atomic<int> g_ring_nt{0};                      // tools only: streaming hint on the ring's copies, 0 = policy, 1 = on, 2 = off
+void set_ring_nt(int v) { g_ring_nt.store(v); }
+// Policy (profiles/r02_ring_nt_ab.txt, cold buffers): on for the 256-lane-window BACKWARD of tensors too big to still sit in
+// the 256 MB Infinity Cache when the backward runs (> 64 MB): config 5 fp32 64.9 -> 59.8 us, bf16 37.1 -> 34.3 us,
+// [64,64,112,112] bf16 64.3 -> 60.3 us.  Off for the forward (every shape 10-20 % slower with the hint) and for row-group
+// windows ([8192,4096] fp32 71 -> 80 us).
+static inline int ring_nt_for(int64_t tensor_bytes, bool backward, bool row_groups) {
+    const int k = g_ring_nt.load(std::memory_order_relaxed);
+    if (k != 0) return k == 1 ? 1 : 0;
+    return backward && !row_groups && tensor_bytes > (int64_t{64} << 20) ? 1 : 0;
+}
 static std::atomic<int> g_ww_big{0};                       // tools only: 1024-lane workgroups, 0 = policy, 1 = always, 2 = never
 void set_ww_big(int v) { g_ww_big.store(v); }
-int get_ww_min_rows() { return g_ww_min_rows_override.load() | (g_ww_split64.load() << 16) | (g_ww_big.load() << 20); }   // (the geometry knobs, as one key)
+int get_ww_min_rows() { return g_ww_min_rows_override.load() | (g_ww_split64.load() << 16) | (g_ww_big.load() << 20) | (g_ring_nt.load() << 24); }   // (the geometry knobs, as one key)
 // (16-bit storage: 768 lanes -- its kernel needs ~140 registers, 1024 lanes would cap it at 128 and spill)
 template <int ELEM_BYTES>
 constexpr int kBigBlockOf = ELEM_BYTES < 4 ? 768 : 1024;
@@ -1076,9 +1087,16 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
         // profiles/r02_fwd_lastaxis_grid.txt).
         const size_t lds_ring = ((static_cast<size_t>(gd.k_slots) * sizeof(QSlot<typename IO::arith>) + 1023) & ~size_t(1023)) +
                                 static_cast<size_t>(kBlock / 64) * kFwdDmaDepth * 1024;
-        if (v.dma == 2 || (tiles_each >= kFwdDmaDepth && tiles_each <= 64 && !small_last_axis)) {
+        // 4- and 8-byte storage: only tensors of at most 64 MB, whose input is likely still in the 256 MB Infinity Cache when
+        // the forward runs (config 5 fp32 with its buffers re-used: 35.2 -> 32.2 us).  From HBM the register loops at 16
+        // workgroups per CU are 7-10 % faster (cold buffers, profiles/r02_cold_buffers_pc.txt: config 5 fp32 36.0 vs 39.0 us,
+        // [128,512,28,28] 69.1 vs 74.6 us); 16-bit storage keeps the ring either way (18.5 vs 19.6 us).
+        const bool wide_cold = sizeof(typename IO::elem) >= 4 &&
+                               outer * channels * inner * static_cast<int64_t>(sizeof(typename IO::elem)) > (int64_t{64} << 20);
+        if (v.dma == 2 || (tiles_each >= kFwdDmaDepth && tiles_each <= 64 && !small_last_axis && !wide_cold)) {
             g = gd;
             vv.dma = lds_ring <= 64 * 1024 ? 2 : 1;
+            g.ring_nt = ring_nt_for(outer * channels * inner * static_cast<int64_t>(sizeof(typename IO::elem)), false, false);
         }
     }
     if (!grid_fits(g)) return hipErrorInvalidConfiguration;
@@ -1177,7 +1195,8 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
             const int by_regs = resident_blocks_by_registers(reinterpret_cast<const void*>(kern)) * 4 / std::max(1, g0.block_threads / 64);
             per_cu = std::max(1, std::min(per_cu, by_regs));
         }
-        const PcGeom g = geom(per_cu * dev.cu_count);
+        PcGeom g = geom(per_cu * dev.cu_count);
+        g.ring_nt = ring_nt_for(c.outer * c.C * c.inner * static_cast<int64_t>(sizeof(typename IO::elem)), true, WW);
         const int64_t tiles_each = g.n_tiles / std::max<int64_t>(1, g.splits);
         if (tiles_each < min_tiles || tiles_each > max_tiles) return false;
         if (!grid_fits(g)) { result = hipErrorInvalidConfiguration; return true; }

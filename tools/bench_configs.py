@@ -43,7 +43,7 @@ def main():
         n = 1
         for d in shape:
             n *= d
-        ring = max(1, min(16, int(600e6 // (3 * n * esz)) + 1)) if 3 * n * esz < 300e6 else 1
+        ring = max(2, min(16, int(1.2e9 // (3 * n * esz)) + 1)) if 3 * n * esz < 1e9 else 1
         sets = []
         for r in range(ring):
             x, g, scale, shift = synth.make_inputs(c, device=dev, dtype=dt, shape=shape)
