@@ -1253,7 +1253,10 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
                 // workgroups) and no gain above (profiles/r02_ww_big_ab.txt).
                 const int big = g_ww_big.load(std::memory_order_relaxed);
                 const int64_t elems = c.outer * c.C;
-                const bool use_big = big == 1 || (big == 0 && c.default_variant && c.C / V <= kBlock &&
+                // (4- and 8-byte storage only up to 64 MB -- tensors that are usually still cache-resident; from HBM the
+                // usual workgroups win there: [256,197,768] fp32 cold 91.5 vs 102.7 us, profiles/r02_cold_buffers_pc.txt)
+                const bool fits = sizeof(typename IO::elem) < 4 || elems * static_cast<int64_t>(sizeof(typename IO::elem)) <= (int64_t{64} << 20);
+                const bool use_big = big == 1 || (big == 0 && c.default_variant && c.C / V <= kBlock && fits &&
                                                   elems >= (int64_t{1} << 23) && elems < (int64_t{3} << 24));
                 constexpr int kBigBlock = kBigBlockOf<sizeof(typename IO::elem)>;
                 if (use_big &&
