@@ -914,14 +914,14 @@ static std::atomic<int> g_ww_split64{0};                   // tools only: rows o
 void set_ww_split64(int v) { g_ww_split64.store(v); }
 static std::atomic<int> g_ring_nt{0};                      // tools only: streaming hint on the ring's copies, 0 = policy, 1 = on, 2 = off
 void set_ring_nt(int v) { g_ring_nt.store(v); }
-// Policy (profiles/r02_ring_nt_ab.txt, cold buffers): on for the 256-lane-window BACKWARD of tensors too big to still sit in
-// the 256 MB Infinity Cache when the backward runs (> 64 MB): config 5 fp32 64.9 -> 59.8 us, bf16 37.1 -> 34.3 us,
-// [64,64,112,112] bf16 64.3 -> 60.3 us.  Off for the forward (every shape 10-20 % slower with the hint) and for row-group
-// windows ([8192,4096] fp32 71 -> 80 us).
+// Policy (profiles/r02_ring_nt_ab.txt, cold buffers): on for the 256-lane-window BACKWARD of tensors of more than 32 MB --
+// the x a backward reads was saved by a forward long ago and is not in the 256 MB Infinity Cache any more, whatever the
+// gradient is: config 5 fp32 64.9 -> 59.8 us, bf16 (51 MB) 37.1 -> 34.3 us, [64,64,112,112] bf16 64.3 -> 60.3 us.  Off for
+// the forward (every shape 10-20 % slower with the hint) and for row-group windows ([8192,4096] fp32 71 -> 80 us).
 static inline int ring_nt_for(int64_t tensor_bytes, bool backward, bool row_groups) {
     const int k = g_ring_nt.load(std::memory_order_relaxed);
     if (k != 0) return k == 1 ? 1 : 0;
-    return backward && !row_groups && tensor_bytes > (int64_t{64} << 20) ? 1 : 0;
+    return backward && !row_groups && tensor_bytes > (int64_t{32} << 20) ? 1 : 0;
 }
 static std::atomic<int> g_ww_big{0};                       // tools only: 1024-lane workgroups, 0 = policy, 1 = always, 2 = never
 void set_ww_big(int v) { g_ww_big.store(v); }
@@ -974,9 +974,10 @@ size_t bwd_pc_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64
 }
 
 
-// LDS-DMA ring in the window-mode kernels by default (A/B on one box, profiles/r02_dma_ab.txt: 8-16 % faster on every
-// large shape in both directions -- fp32 forward 6.4 TB/s, dx-only backward 6.3 TB/s -- and even on the rest), with the
-// grid it likes: fewer, longer workgroups than the register loops (it needs rows to keep its ring full).
+// LDS-DMA ring in the window-mode kernels by default, with the grid it likes: fewer, longer workgroups than the register
+// loops (it needs rows to keep its ring full).  A/B on one box, profiles/r02_dma_ab.txt: 8-16 % faster on every large shape
+// in both directions when the tensors are cache-resident; on cold buffers (profiles/r02_cold_buffers_pc.txt) it keeps that
+// lead for 16-bit storage only, hence the size rules further down (forward_per_channel, ring_nt_for).
 template <typename IO>
 constexpr bool kDmaDefault = true;
 template <typename IO>
@@ -1087,15 +1088,16 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
         // profiles/r02_fwd_lastaxis_grid.txt).
         const size_t lds_ring = ((static_cast<size_t>(gd.k_slots) * sizeof(QSlot<typename IO::arith>) + 1023) & ~size_t(1023)) +
                                 static_cast<size_t>(kBlock / 64) * kFwdDmaDepth * 1024;
-        // 4- and 8-byte storage: only tensors of at most 64 MB, whose input is likely still in the 256 MB Infinity Cache when
-        // the forward runs (config 5 fp32 with its buffers re-used: 35.2 -> 32.2 us).  From HBM the register loops at 16
-        // workgroups per CU are 7-10 % faster (cold buffers, profiles/r02_cold_buffers_pc.txt: config 5 fp32 36.0 vs 39.0 us,
-        // [128,512,28,28] 69.1 vs 74.6 us); 16-bit storage keeps the ring either way (18.5 vs 19.6 us).
-        const bool wide_cold = sizeof(typename IO::elem) >= 4 &&
-                               outer * channels * inner * static_cast<int64_t>(sizeof(typename IO::elem)) > (int64_t{64} << 20);
-        if (v.dma == 2 || (tiles_each >= kFwdDmaDepth && tiles_each <= 64 && !small_last_axis && !wide_cold)) {
+        // Only tensors of at most 64 MB, whose input is likely still in the 256 MB Infinity Cache when the forward runs
+        // (config 5 with its buffers re-used: fp32 35.2 -> 32.2 us, bf16 19.7 -> 18.4 us).  From HBM the register loops at
+        // 16 workgroups per CU are 6-14 % faster for every storage type (cold buffers, profiles/r02_cold_buffers_pc.txt:
+        // config 5 fp32 36.0 vs 38.7 us, bf16 19.3 vs 21.6 us, [128,512,28,28] bf16 36.8 vs 39.1 us, [256,197,768] bf16
+        // 33.2 vs 38.2 us).  The big-table case above keeps the ring's grid at any size ([8192,4096] bf16 cold 29.3 vs 35.3 us).
+        const bool cold = outer * channels * inner * static_cast<int64_t>(sizeof(typename IO::elem)) > (int64_t{64} << 20);
+        const bool table_big = lds_ring > 64 * 1024;
+        if (v.dma == 2 || (tiles_each >= kFwdDmaDepth && tiles_each <= 64 && !small_last_axis && (table_big || !cold))) {
             g = gd;
-            vv.dma = lds_ring <= 64 * 1024 ? 2 : 1;
+            vv.dma = table_big ? 1 : 2;
             g.ring_nt = ring_nt_for(outer * channels * inner * static_cast<int64_t>(sizeof(typename IO::elem)), false, false);
         }
     }

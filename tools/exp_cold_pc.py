@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Window-mode per-channel kernels on COLD buffers (rotated through > 600 MB so that the 256 MB Infinity Cache cannot serve
-them): register loops vs LDS-DMA ring (plain / nt copies) x workgroups per CU.  GPU-side us per call (HIP graph)."""
+"""Window-mode per-channel kernels on COLD buffers (x and grad each rotated through > 1 GiB so that the 256 MB Infinity Cache cannot
+serve them): register loops vs LDS-DMA ring (plain / nt copies) x workgroups per CU.  GPU-side us per call (HIP graph)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
@@ -39,13 +39,13 @@ for shape, axis in SHAPES:
         n = 1
         for d in shape: n *= d
         esz = 4 if dt == torch.float32 else 2
-        copies = max(2, min(8, (700 << 20) // (n * esz * 3) + 1))
+        copies = max(2, min(24, -(-(1100 << 20) // (n * esz))))      # > 1 GiB of x alone: cold for the forward too
         xs = [synth.normal_like(n, 1 + k, 0.5, 1.0, device=dev, dtype=dt).view(shape) for k in range(copies)]
         gs = [synth.normal_like(n, 100 + k, 0.0, 1e-3, device=dev, dtype=dt).view(shape) for k in range(copies)]
         C = shape[axis]
         s = synth.uniform_like(C, 3, 0.02, 0.05, device=dev); b = synth.normal_like(C, 4, 0.0, 0.1, device=dev)
         q = (-8, 7, -128, 127, True, 1.0, False, False, False)
-        reps = 4 * copies
+        reps = 2 * copies
         def run_b(v):
             E._WS_BYTES_PC.clear()
             return timeit([(lambda k=k: E.hip_backward_per_channel(gs[k], xs[k], s, b, axis, *q, variant=v)) for k in range(copies)], reps)
