@@ -981,8 +981,6 @@ size_t bwd_pc_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64
 template <typename IO>
 constexpr bool kDmaDefault = true;
 template <typename IO>
-constexpr bool kFwdDmaDefault = true;
-template <typename IO>
 constexpr int kDmaBwdBlocksPerCU = sizeof(typename IO::elem) < 4 ? 4 : 8;
 template <typename IO>
 constexpr int kDmaFwdBlocksPerCU = sizeof(typename IO::elem) < 4 ? 4 : 8;
@@ -1069,33 +1067,26 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
     }
     const int cpl = pick_cpl(vec, inner);
     PcGeom g = make_geom(outer, channels, inner, vec, target, kFwdPerSlotRows<IO>);
-    // LDS-DMA ring (profiles/r02_dma_ab.txt): the default when a workgroup of the grid the ring likes walks at least as
-    // many rows as the ring is deep; not for small last-axis tensors, whose per-workgroup channel-table build wants many
-    // short workgroups ([64,197,768]: 14.7 us with 4-row workgroups, 17 us with the ring).  Bits 12-13 of the variant
-    // force either path (A/B runs).
+    // The forward's LDS-DMA ring is NOT a default any more: it wins only when the same buffers are read again and again
+    // (profiles/r02_dma_ab.txt: config 5 fp32 35.2 -> 32.2 us).  On input the previous kernel has just written
+    // (profiles/r02_producer_consumer.txt: config 5 bf16 14.2 us with the register loops at 16 workgroups per CU, 17.5 us on
+    // the ring; [32,256,56,56] bf16 14.3 vs 18.3 us) and on cold input (profiles/r02_cold_buffers_pc.txt: 6-14 % behind for
+    // every storage type) the register loops are faster.  Variant bits 12-13 = 2 still select it (A/B runs, tests).
+    // What stays from its tuning is the grid for one case: a 16-bit last-axis window has 2048 channels, a 32 KiB table, and
+    // building half as many tables pays -- those shapes take the ring's grid (4 workgroups per CU) with the register loop
+    // ([8192,4096] bf16 28.8 us against 34.3 us on the usual grid, cold 29.3 vs 35.3 us, after a producer 21.8 vs 24.7 us;
+    // profiles/r02_fwd_lastaxis_grid.txt).
     Variant vv = v;
     vv.dma = 1;
-    if (vec > 1 && vec * sizeof(typename IO::elem) == 16 && v.dma != 1 && (v.dma == 2 || kFwdDmaDefault<IO>)) {
+    if (vec > 1 && vec * sizeof(typename IO::elem) == 16 && v.dma != 1) {
         const int tgt = variant == 0 ? dev.cu_count * kDmaFwdBlocksPerCU<IO> : target;
         const PcGeom gd = make_geom(outer, channels, inner, vec, tgt, kFwdPerSlotRows<IO>);
         const bool small_last_axis = cpl == vec && outer * channels * inner < (int64_t{1} << 24);
         const int64_t tiles_each = gd.n_tiles / std::max(1, gd.splits);
-        // (not on very long walks either: [32,2048,4096] fp32, 128 rows per workgroup, 380 us with the register loops,
-        // 450-580 us on the ring, profiles/r02_dma_ab_big_shapes.txt)
-        // A 16-bit last-axis window has 2048 channels, a 32 KiB table: the ring does not fit next to it.  Those shapes still
-        // take the ring's grid -- half the workgroups, half the table builds -- with the register loop
-        // ([8192,4096] bf16 28.8 us against 34.3 us on the usual grid, [16384,2048] 29.3 against 34.6,
-        // profiles/r02_fwd_lastaxis_grid.txt).
         const size_t lds_ring = ((static_cast<size_t>(gd.k_slots) * sizeof(QSlot<typename IO::arith>) + 1023) & ~size_t(1023)) +
                                 static_cast<size_t>(kBlock / 64) * kFwdDmaDepth * 1024;
-        // Only tensors of at most 64 MB, whose input is likely still in the 256 MB Infinity Cache when the forward runs
-        // (config 5 with its buffers re-used: fp32 35.2 -> 32.2 us, bf16 19.7 -> 18.4 us).  From HBM the register loops at
-        // 16 workgroups per CU are 6-14 % faster for every storage type (cold buffers, profiles/r02_cold_buffers_pc.txt:
-        // config 5 fp32 36.0 vs 38.7 us, bf16 19.3 vs 21.6 us, [128,512,28,28] bf16 36.8 vs 39.1 us, [256,197,768] bf16
-        // 33.2 vs 38.2 us).  The big-table case above keeps the ring's grid at any size ([8192,4096] bf16 cold 29.3 vs 35.3 us).
-        const bool cold = outer * channels * inner * static_cast<int64_t>(sizeof(typename IO::elem)) > (int64_t{64} << 20);
         const bool table_big = lds_ring > 64 * 1024;
-        if (v.dma == 2 || (tiles_each >= kFwdDmaDepth && tiles_each <= 64 && !small_last_axis && (table_big || !cold))) {
+        if (v.dma == 2 || (table_big && tiles_each >= kFwdDmaDepth && tiles_each <= 64 && !small_last_axis)) {
             g = gd;
             vv.dma = table_big ? 1 : 2;
             g.ring_nt = ring_nt_for(outer * channels * inner * static_cast<int64_t>(sizeof(typename IO::elem)), false, false);
