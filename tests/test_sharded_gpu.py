@@ -28,7 +28,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, per_channel, dtype_name, out_q):
+def _worker(rank, world, port, per_channel, dtype_name, out_q, shape=(64, 48, 14, 14)):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -50,13 +50,13 @@ def _worker(rank, world, port, per_channel, dtype_name, out_q):
             return real_all_reduce(*a, **k)
         dist.all_reduce = counting_all_reduce
 
-        shape = (64, 48, 14, 14)
+        C = shape[1]
         n = int(np.prod(shape))
         x = synth.normal_like(n, 71, 0.3, 1.0, dtype=dtype, device=dev).view(shape)
         g = synth.normal_like(n, 72, 0.0, 1e-2, dtype=dtype, device=dev).view(shape).abs()     # no cancellation: plain rtol
         if per_channel:
-            scale = synth.uniform_like(48, 73, 0.05, 0.3, device=dev)
-            shift = synth.normal_like(48, 74, 0.0, 0.1, device=dev)
+            scale = synth.uniform_like(C, 73, 0.05, 0.3, device=dev)
+            shift = synth.normal_like(C, 74, 0.0, 0.1, device=dev)
             kw = dict(quant_min=-8, quant_max=7, type_min=-128, type_max=127, axis=1, is_perchannel=True)
         else:
             scale, shift = torch.tensor([0.03], device=dev), torch.tensor([0.05], device=dev)
@@ -94,6 +94,25 @@ def test_sharded_equals_unsharded_on_the_gpu(per_channel, dtype_name):
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok, ncalls, err_s, err_b in res:
+        assert ok, "rank %d: sharded != unsharded (all_reduce calls %d, rel err ds %g db %g)" % (rank, ncalls, err_s, err_b)
+
+
+def test_config4_per_rank_shard_over_two_ranks():
+    """BASELINE config 4 is [1024,1024,14,14] over 8 GPUs: [128,1024,14,14] per rank.  Two ranks with exactly that shard
+    (a [256,1024,14,14] global batch, 51 M elements) against the unsharded op on the whole batch: the kernels, grid and
+    gradient-scaler count a rank of the 8-GPU job runs, with the collective over gloo."""
+    assert torch.cuda.is_available()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, False, "float32", q, (256, 1024, 14, 14))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
