@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- GElem/s of the LSQ fake-quantize hot path (forward op + backward op) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg1|cfg3|cfg4|cfg5|cfg5_bf16|cfg5_axis0]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg1|cfg3|cfg4|cfg5|cfg5_bf16|cfg5_axis0|tok|tok_bf16|vit|vit_bf16]
 
 One "step" = one forward op + one backward op (training mode) over one batch of synthetic input already resident
 in HBM.  The default workload is BASELINE.json config 2 -- per-tensor quint8, fp32 [128,512,56,56] (205.5 M elements,
@@ -62,6 +62,9 @@ WORKLOADS = {
     "cfg5": ("cfg5", "float32", None),
     "cfg5_bf16": ("cfg5", "bfloat16", None),
     "cfg5_axis0": ("cfg5", "float32", 0),
+    # not BASELINE configs: token-layout activations (quantized axis last), the shapes the round-1 review asked about
+    "tok": ("tok", "float32", None), "tok_bf16": ("tok", "bfloat16", None),
+    "vit": ("vit", "float32", None), "vit_bf16": ("vit", "bfloat16", None),
 }
 
 
@@ -72,7 +75,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
                     help="cfg2 (default; weak-scaled per GPU) | cfg4 (strong: [1024,1024,14,14] split over the ranks) | "
-                         "cfg1 | cfg3, cfg5, cfg5_bf16, cfg5_axis0 (per-channel)")
+                         "cfg1 | cfg3, cfg5, cfg5_bf16, cfg5_axis0 (per-channel) | tok, vit (+ _bf16): [8192,4096] / [64,197,768], last axis")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--measure-traffic", dest="measure_traffic", action="store_true", default=None,
                     help="measure roofline.traffic in this run with two rocprofv3 --pmc child passes (default at N = 1)")

@@ -95,6 +95,12 @@ CONFIGS = {
     "cfg5": dict(shape=(256, 2048, 7, 7), per_channel=True, axis=1, qmin=-8, qmax=7, tmin=-128, tmax=127,
                  affine=True, x_mean=0.0, x_std=1.0, scale=(0.05, 0.35), shift=("normal", 0.0, 0.1),
                  dtype="bfloat16"),
+    # NOT in BASELINE.json: the token-layout activation shapes the round-1 review singled out (the quantized axis is the
+    # last one: row-group windows), per-channel quint8, as bench.py workloads `tok` / `vit` (+ `_bf16`)
+    "tok": dict(shape=(8192, 4096), per_channel=True, axis=1, qmin=0, qmax=127, tmin=0, tmax=255,
+                affine=True, x_mean=0.5, x_std=1.0, scale=(0.01, 0.05), shift=("normal", 0.0, 0.1), dtype="float32"),
+    "vit": dict(shape=(64, 197, 768), per_channel=True, axis=2, qmin=0, qmax=127, tmin=0, tmax=255,
+                affine=True, x_mean=0.5, x_std=1.0, scale=(0.01, 0.05), shift=("normal", 0.0, 0.1), dtype="float32"),
 }
 
 SEED_X, SEED_G, SEED_SCALE, SEED_SHIFT = 11, 23, 37, 41

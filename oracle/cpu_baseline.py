@@ -26,7 +26,8 @@ sys.path.insert(0, ROOT)
 
 # bench.py workload -> (synth config, channel axis override)
 WORKLOADS = {"cfg1": ("cfg1", None), "cfg2": ("cfg2", None), "cfg3": ("cfg3", None), "cfg4": ("cfg4", None),
-             "cfg5": ("cfg5", None), "cfg5_bf16": ("cfg5", None), "cfg5_axis0": ("cfg5", 0)}
+             "cfg5": ("cfg5", None), "cfg5_bf16": ("cfg5", None), "cfg5_axis0": ("cfg5", 0),
+             "tok": ("tok", None), "tok_bf16": ("tok", None), "vit": ("vit", None), "vit_bf16": ("vit", None)}
 
 
 def load_synth():

@@ -20,6 +20,16 @@ for W in cfg3 cfg5 cfg5_bf16; do
   python3 tools/rocprof_summary.py $O/prof_$W > $O/r02_bench_${W}_kernel_stats.txt; rm -rf $O/prof_$W
   head -4 $O/r02_bench_${W}_kernel_stats.txt | cut -c1-200
 done
+# token-layout shapes (not BASELINE configs): bench line with live PMC traffic + kernel stats of the row-group-window kernels
+if [ -z "$SKIP_TOKEN_SHAPES" ]; then
+for W in tok tok_bf16 vit vit_bf16; do
+  python3 bench.py --workload $W --steps 200 --warmup 20 > $O/r02_bench_${W}_n1.json 2> $O/r02_bench_${W}_n1.err
+  tail -1 $O/r02_bench_${W}_n1.json | cut -c1-260
+  rocprofv3 --kernel-trace --stats -d $O/prof_$W -o bench -- python3 bench.py --workload $W --steps 100 --warmup 20 --no-cpu-baseline --no-measure-traffic --no-yardstick > $O/r02_bench_${W}_under_rocprof.json 2>/dev/null
+  python3 tools/rocprof_summary.py $O/prof_$W > $O/r02_bench_${W}_kernel_stats.txt; rm -rf $O/prof_$W
+  head -5 $O/r02_bench_${W}_kernel_stats.txt | cut -c1-200
+done
+fi
 SQ1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
 SQ2="SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS"
 for W in cfg5_bf16 cfg5; do
