@@ -91,6 +91,7 @@ C_ABI = {
 C_ABI_INTERNAL = {
     "lsq_hip_debug_force_ring": (None, [_int]),
     "lsq_hip_debug_set_ww_big": (None, [_int]),
+    "lsq_hip_debug_set_ring_nt": (None, [_int]),
     "lsq_hip_forward_per_tensor_ex": (_int, C_ABI["lsq_hip_forward_per_tensor"][1] + [_int]),
     "lsq_hip_backward_per_tensor_ex": (_int, C_ABI["lsq_hip_backward_per_tensor"][1] + [_int]),
     "lsq_hip_forward_per_channel_ex": (_int, C_ABI["lsq_hip_forward_per_channel"][1] + [_int]),

@@ -115,7 +115,10 @@ def test_random_cases_against_the_oracle(seed):
         # ... and the row-group windows (quantized axis last) two workgroup sizes: 768/1024 lanes on a share of the cases
         ww_big = int(rng.choice([0, 0, 1]))
         extension.library().lsq_hip_debug_set_ww_big(ww_big)
-        tag += " loop=%d big=%d" % (loop_form, ww_big)
+        # ... and the ring's copies with or without the streaming hint (the policy uses it above 32 MB only)
+        ring_nt = int(rng.choice([0, 1, 2]))
+        extension.library().lsq_hip_debug_set_ring_nt(ring_nt)
+        tag += " loop=%d big=%d nt=%d" % (loop_form, ww_big, ring_nt)
         extension.set_host_binding(binding)
         try:
             xt = _layout(rng, torch.from_numpy(xs).to(dev).to(dtype), kind).requires_grad_(True)
@@ -130,6 +133,7 @@ def test_random_cases_against_the_oracle(seed):
             extension.set_host_binding("native")
             extension.library().lsq_hip_debug_force_ring(0)
             extension.library().lsq_hip_debug_set_ww_big(0)
+            extension.library().lsq_hip_debug_set_ring_nt(0)
         if narrow:      # parity for 16-bit storage is defined by the build: the fp32 result rounded to the storage type
             want_y = torch.from_numpy(np.ascontiguousarray(oy)).to(dtype)
             want_dx = torch.from_numpy(np.ascontiguousarray(r.dx)).to(dtype)
