@@ -467,8 +467,12 @@ def run_rank(a):
                        "parallelism": "dp%d" % world, "host_binding": binding,
                        "launch": "hip-graph replay" if a.graph else "eager",
                        "input_buffer_sets": n_sets,
-                       "input_buffers_note": ("the steps rotate through %d copies of (x, grad), %.2f GB of inputs: reads come from HBM, "
-                                              "not from the 256 MB Infinity Cache" % (n_sets, n_sets * set_bytes / 1e9)) if n_sets > 1 else
+                       "input_buffers_note": (("the steps rotate through %d copies of (x, grad), %.2f GB of inputs: reads come from HBM, "
+                                               "not from the 256 MB Infinity Cache" % (n_sets, n_sets * set_bytes / 1e9))
+                                              if n_sets * set_bytes >= (1 << 30) else
+                                              ("the steps rotate through %d copies of (x, grad) (the cap), only %.2f GB of inputs: still partly "
+                                               "cache-resident -- a launch-latency-bound workload either way" % (n_sets, n_sets * set_bytes / 1e9)))
+                                             if n_sets > 1 else
                                              "one set of input buffers (%.2f GB per step streamed, beyond the 256 MB Infinity Cache)" % (5 * n_local * esz / 1e9)},
             "roofline": {"bound": "hbm", "kernel": "lsq::%s<%s> (fused dx + d_scale/d_shift reduction)" % (kb, io),
                          "achieved": round(bwd_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
