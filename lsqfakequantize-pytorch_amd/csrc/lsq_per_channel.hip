@@ -914,14 +914,17 @@ static std::atomic<int> g_ww_split64{0};                   // tools only: rows o
 void set_ww_split64(int v) { g_ww_split64.store(v); }
 static std::atomic<int> g_ring_nt{0};                      // tools only: streaming hint on the ring's copies, 0 = policy, 1 = on, 2 = off
 void set_ring_nt(int v) { g_ring_nt.store(v); }
-// Policy (profiles/r02_ring_nt_ab.txt, cold buffers): on for the 256-lane-window BACKWARD of tensors of more than 32 MB --
-// the x a backward reads was saved by a forward long ago and is not in the 256 MB Infinity Cache any more, whatever the
-// gradient is: config 5 fp32 64.9 -> 59.8 us, bf16 (51 MB) 37.1 -> 34.3 us, [64,64,112,112] bf16 64.3 -> 60.3 us.  Off for
-// the forward (every shape 10-20 % slower with the hint) and for row-group windows ([8192,4096] fp32 71 -> 80 us).
+// Policy: on for the BACKWARD of tensors of more than 32 MB -- the x a backward reads was saved by a forward long ago and
+// is not in the 256 MB Infinity Cache any more, whatever the gradient is, and nt copies still hit the lines a producer left
+// there.  256-lane windows, cold (profiles/r02_ring_nt_ab.txt): config 5 fp32 64.9 -> 59.8 us, bf16 (51 MB) 37.1 -> 34.3 us.
+// Row-group windows with the gradient fresh from a producer kernel and x cold (profiles/r02_ww_nt_ab.txt): [8192,4096] fp32
+// 78 -> 68 us, [256,197,768] fp32 91 -> 80 us, [65536,1024] bf16 82 -> 76 us; never slower, cold included.  (An earlier A/B that
+// found the hint harmful for row groups and for the forward re-read one set of buffers: the hint kept them out of the cache.)
 static inline int ring_nt_for(int64_t tensor_bytes, bool backward, bool row_groups) {
     const int k = g_ring_nt.load(std::memory_order_relaxed);
     if (k != 0) return k == 1 ? 1 : 0;
-    return backward && !row_groups && tensor_bytes > (int64_t{32} << 20) ? 1 : 0;
+    (void)row_groups;
+    return backward && tensor_bytes > (int64_t{32} << 20) ? 1 : 0;
 }
 static std::atomic<int> g_ww_big{0};                       // tools only: 1024-lane workgroups, 0 = policy, 1 = always, 2 = never
 void set_ww_big(int v) { g_ww_big.store(v); }
