@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Per-channel activation quantizer (window mode mostly) on typical activation shapes: GPU-side forward / backward time (HIP
-graph).  Two columns: `hot` re-uses one set of buffers (the 256 MB Infinity Cache serves part or all of the reads of the
-smaller shapes -- what a layer sees when its input was just produced), `cold` rotates through buffer sets of more than
-1.2 GB in total (what the HBM roofline is about); shapes streaming more than 1 GB per step have one column."""
+graph).  Two columns.  `cold`: x and grad rotate through buffer sets of more than 1.2 GB in total, so the 256 MB Infinity
+Cache cannot serve them -- what the HBM roofline is about.  `fresh`: what a layer sees in a training step -- a producer
+kernel (ATen add, also rotated) has just written the forward's x / the backward's gradient, the backward's x is cold; op
+time = graph(producer + op) - graph(producer), +-1 us.  (Re-reading ONE set of buffers, the "hot" column of earlier
+versions, favours whatever keeps lines cached and is not a situation a training step has.)  Shapes streaming more than
+1 GB per step have the cold column only."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
@@ -36,21 +39,33 @@ for dt in (torch.float32, torch.bfloat16):
         n = 1
         for d in shape: n *= d
         esz = 4 if dt == torch.float32 else 2
-        copies = 1 if 3 * n * esz > 1e9 else max(2, min(16, int(1.2e9 // (3 * n * esz)) + 1))
+        big = 3 * n * esz > 1e9
+        copies = 2 if big else max(3, min(16, int(1.2e9 // (3 * n * esz)) + 1))
         xs = [synth.normal_like(n, 1 + k, 0.5, 1.0, device=dev, dtype=dt).view(shape) for k in range(copies)]
         gs = [synth.normal_like(n, 50 + k, 0.0, 1e-3, device=dev, dtype=dt).view(shape) for k in range(copies)]
         C = shape[axis]
         s = synth.uniform_like(C, 3, 0.02, 0.05, device=dev)
         b = synth.normal_like(C, 4, 0.0, 0.1, device=dev)
         q = (0, 127, 0, 255)
-        cols = []
-        for mode in (("hot", "cold") if copies > 1 else ("cold",)):
-            ks = range(copies) if mode == "cold" else (0,)
-            reps = 8 if n > 1e8 else max(24, 2 * copies)
-            tf = timeit([(lambda k=k: ops.lsq_forward_per_channel(xs[k], s, b, axis, *q, True, 1.0, False, False, False)) for k in ks], reps)
-            tb = timeit([(lambda k=k: ops.lsq_backward_per_channel(gs[k], xs[k], s, b, axis, *q, True, 1.0, False, False, False)) for k in ks], reps)
-            cols.append("%s: fwd %7.2f us %5.0f GB/s  bwd %7.2f us %5.0f GB/s  fwd+bwd %5.1f GElem/s %4.1f%% of 8 TB/s" %
-                        (mode if copies > 1 else "(> 1 GB per step)", tf, 2 * esz * n / tf / 1e3, tb, 3 * esz * n / tb / 1e3, n / (tf + tb) / 1e3,
-                         5 * esz * n / (tf + tb) / 1e3 / 80))
+        K = copies
+        reps = 8 if n > 1e8 else max(24, 2 * K)
+        fwd = lambda k: ops.lsq_forward_per_channel(xs[k % K], s, b, axis, *q, True, 1.0, False, False, False)
+        bwd = lambda k: ops.lsq_backward_per_channel(gs[k % K], xs[(k + K // 2) % K], s, b, axis, *q, True, 1.0, False, False, False)
+        tf = timeit([(lambda k=k: fwd(k)) for k in range(K)], reps)
+        tb = timeit([(lambda k=k: bwd(k)) for k in range(K)], reps)
+        def col(name, tf, tb):
+            return "%s: fwd %7.2f us %5.0f GB/s  bwd %7.2f us %5.0f GB/s  fwd+bwd %5.1f GElem/s %4.1f%% of 8 TB/s" % (
+                name, tf, 2 * esz * n / tf / 1e3, tb, 3 * esz * n / tb / 1e3, n / (tf + tb) / 1e3, 5 * esz * n / (tf + tb) / 1e3 / 80)
+        cols = [col("cold" if not big else "(> 1 GB per step)", tf, tb)]
+        if not big:
+            outs = [torch.empty_like(xs[0]) for _ in range(K)]          # what the producer writes
+            prod = lambda k: torch.add(xs[k % K], gs[k % K], out=outs[k % K])
+            tp = timeit([(lambda k=k: prod(k)) for k in range(K)], reps)
+            tfp = timeit([(lambda k=k: (prod(k), ops.lsq_forward_per_channel(outs[k % K], s, b, axis, *q, True, 1.0, False, False, False)))
+                          for k in range(K)], reps) - tp
+            tbp = timeit([(lambda k=k: (prod(k), ops.lsq_backward_per_channel(outs[k % K], xs[(k + K // 2) % K], s, b, axis, *q, True, 1.0, False, False, False)))
+                          for k in range(K)], reps) - tp
+            cols.append(col("fresh", tfp, tbp))
+            del outs
         print("%-9s %-20s axis %d n=%10d | %s" % (str(dt).replace("torch.", ""), shape, axis, n, " | ".join(cols)), flush=True)
         del xs, gs
