@@ -155,6 +155,46 @@ def test_768_and_1024_lane_row_group_workgroups(E, dtype, mode):
         E._WS_BYTES_PC.clear()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_row_group_workgroup_sizes_on_random_last_axis_shapes(E, dtype):
+    """60 seeded random [rows, C] shapes (C a multiple of the packet, 8 .. 8192; 1 .. 6000 rows): 768/1024-lane workgroups and
+    the streaming hint forced on against the 3-4-wave workgroups without it.  dx bit-identical, d_scale / d_shift within the
+    parity bar."""
+    from torchlsq import synth
+    dev = torch.device("cuda:0")
+    lib = E.library()
+    rng = np.random.default_rng(20260902)
+    vec = 8 if dtype == torch.bfloat16 else 4
+    try:
+        for k in range(60):
+            C = int(rng.integers(1, 8192 // vec + 1)) * vec
+            rows = int(rng.integers(1, 6001)) if C <= 2048 else int(rng.integers(1, 1200))
+            n = rows * C
+            x = synth.normal_like(n, 3000 + k, 0.4, 1.0, dtype=dtype, device=dev).view(rows, C)
+            g = synth.normal_like(n, 3100 + k, 0.0, 1e-2, dtype=dtype, device=dev).view(rows, C)
+            s = synth.uniform_like(C, 3200 + k, 0.02, 0.2, device=dev)
+            b = synth.normal_like(C, 3300 + k, 0.0, 0.1, device=dev)
+            q = (-8, 7, -128, 127, False, 1.0, False, False, False)
+            outs = {}
+            for big, nt in ((2, 2), (1, 1)):
+                lib.lsq_hip_debug_set_ww_big(big)
+                lib.lsq_hip_debug_set_ring_nt(nt)
+                E._WS_BYTES_PC.clear()
+                outs[big] = E.hip_backward_per_channel(g, x, s, b, 1, *q)
+                torch.cuda.synchronize()
+            assert _bits(outs[1][0]) == _bits(outs[2][0]), (rows, C, str(dtype))
+            bound = 8.0 * g.double().abs().sum(0)
+            tol = (1e-6 if dtype == torch.bfloat16 else 1e-12) * bound + 1e-30
+            for u, v in ((outs[1][1], outs[2][1]), (outs[1][2], outs[2][2])):
+                d = (u.double() - v.double()).abs()
+                assert bool((d <= tol).all()) or (dtype == torch.float32 and torch.allclose(u.double(), v.double(), rtol=1e-6, atol=0)), \
+                    (rows, C, str(dtype))
+    finally:
+        lib.lsq_hip_debug_set_ww_big(0)
+        lib.lsq_hip_debug_set_ring_nt(0)
+        E._WS_BYTES_PC.clear()
+
+
 def test_default_policy_takes_the_ring_on_large_shapes(E):
     """the launch note of the window-mode backward reports the grid; with the ring a [256,2048,7,7] bf16 backward is
     sized for 4 resident workgroups per CU (LDS-bound) and fills one round"""
