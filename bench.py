@@ -68,6 +68,9 @@ WORKLOADS = {
 }
 
 
+SECONDARY = ("cfg1", "cfg3", "cfg5", "cfg5_bf16")    # timed after the headline region of the default run
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +86,9 @@ def parse_args(argv=None):
     ap.add_argument("--buffers", type=int, default=0,
                     help="input buffer sets the steps rotate through (0 = auto: as many as make the streamed working set exceed "
                          "1 GiB, so that the 256 MB Infinity Cache cannot serve the reads of a small workload; 1 = re-use one set)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default run (cfg2, N = 1) only: skip the secondary records (cfg1, cfg3, cfg5, cfg5_bf16 timed in-process)")
+    ap.add_argument("--secondary-steps", type=int, default=200, help=argparse.SUPPRESS)
     ap.add_argument("--no-yardstick", action="store_true", help="skip the ATen add / copy rates measured after the timed region")
     ap.add_argument("--host-binding", default="auto", choices=["auto", "native", "ctypes"],
                     help="host layer above the C ABI: the C++ torch binding (_lsq_torch.so) or the Python/ctypes one")
@@ -265,157 +271,171 @@ def run_rank(a):
     # the ops of the hot path on the chosen host layer: torch.ops.torchlsq_native.* (C++ binding) or torch.ops.torchlsq.*
     # (Python torch.library registration over ctypes); both end in the same C-ABI call
     ops = torch.ops.torchlsq_native if binding == "native" else torch.ops.torchlsq
+    ops_of = {"native": getattr(torch.ops, "torchlsq_native", None), "ctypes": torch.ops.torchlsq}
 
-    cfg_name, dtype_name, axis_override = WORKLOADS[a.workload]
-    c = dict(synth.CONFIGS[cfg_name])
-    if axis_override is not None:
-        c["axis"] = axis_override
-    dt = getattr(torch, dtype_name)
-    esz = 2 if dt in (torch.bfloat16, torch.float16) else 4
-    per_channel = c["per_channel"]
-    shape = list(c["shape"])
-    scaling = "weak"
-    if a.workload == "cfg4":           # strong scaling: fixed global batch split over the ranks
-        assert shape[0] % world == 0
-        shape[0] //= world
-        scaling = "strong"
-    if world > 1 and per_channel and c["axis"] == 0:
-        raise SystemExit("workload %s quantises along dim 0, the sharded dim: a weight is replicated under data "
-                         "parallelism, there is nothing to shard -- run it with --gpus 1" % a.workload)
-    if a.graph and world > 1:
-        raise SystemExit("--graph is a 1-GPU measurement")
-    x, g, scale, shift = synth.make_inputs(c, device=dev, dtype=dt, shape=shape)
-    n_local = x.numel()
-    # Small workloads re-using one set of buffers are partly served by the 256 MB Infinity Cache (config 5 streams 308 MB per
-    # step in fp32, 154 MB in bf16), which is not the HBM rate the roofline is about: the steps rotate through `n_sets`
-    # copies of (x, grad), more than 1 GiB of inputs in total.  Config 2 (2.4 GB per step) needs one set.
-    set_bytes = 2 * n_local * esz
-    n_sets = a.buffers if a.buffers > 0 else max(1, min(16, -(-(1 << 30) // set_bytes)))
-    xs, gs = [x], [g]
-    for _ in range(n_sets - 1):
-        xs.append(x.clone())
-        gs.append(g.clone())
-    cur = [0]
+    def measure(workload, steps, warmup, graph=False, buffers=0, ops=ops):
+        """Time `steps` steps (forward op + backward op) of one workload after `warmup` untimed ones; returns the raw
+        measurements (K-step wall time bracketed by barrier + synchronize, max over ranks; per-op HIP-event times)."""
+        cfg_name, dtype_name, axis_override = WORKLOADS[workload]
+        c = dict(synth.CONFIGS[cfg_name])
+        if axis_override is not None:
+            c["axis"] = axis_override
+        dt = getattr(torch, dtype_name)
+        esz = 2 if dt in (torch.bfloat16, torch.float16) else 4
+        per_channel = c["per_channel"]
+        shape = list(c["shape"])
+        scaling = "weak"
+        if workload == "cfg4":           # strong scaling: fixed global batch split over the ranks
+            assert shape[0] % world == 0
+            shape[0] //= world
+            scaling = "strong"
+        if world > 1 and per_channel and c["axis"] == 0:
+            raise SystemExit("workload %s quantises along dim 0, the sharded dim: a weight is replicated under data "
+                             "parallelism, there is nothing to shard -- run it with --gpus 1" % workload)
+        if graph and world > 1:
+            raise SystemExit("--graph is a 1-GPU measurement")
+        x, g, scale, shift = synth.make_inputs(c, device=dev, dtype=dt, shape=shape)
+        n_local = x.numel()
+        # Small workloads re-using one set of buffers are partly served by the 256 MB Infinity Cache (config 5 streams 308 MB per
+        # step in fp32, 154 MB in bf16), which is not the HBM rate the roofline is about: the steps rotate through `n_sets`
+        # copies of (x, grad), more than 1 GiB of inputs in total.  Config 2 (2.4 GB per step) needs one set.
+        set_bytes = 2 * n_local * esz
+        n_sets = buffers if buffers > 0 else max(1, min(16, -(-(1 << 30) // set_bytes)))
+        xs, gs = [x], [g]
+        for _ in range(n_sets - 1):
+            xs.append(x.clone())
+            gs.append(g.clone())
+        cur = [0]
 
-    def bset():       # the backward works on a set the forward touched n_sets / 2 steps ago: not on lines the forward just read
-        return (cur[0] + n_sets // 2) % n_sets
-    n_global = n_local * world
-    q = (c["qmin"], c["qmax"], c["tmin"], c["tmax"])
-    sym = not c["affine"]
-    axis = c["axis"]
-    tail = q + (True, 1.0, sym, False, False)
+        def bset():       # the backward works on a set the forward touched n_sets / 2 steps ago: not on lines the forward just read
+            return (cur[0] + n_sets // 2) % n_sets
+        n_global = n_local * world
+        q = (c["qmin"], c["qmax"], c["tmin"], c["tmax"])
+        sym = not c["affine"]
+        axis = c["axis"]
+        tail = q + (True, 1.0, sym, False, False)
 
-    def fwd():
-        if a.variant_fwd:
-            if per_channel:
-                return extension.hip_forward_per_channel(xs[cur[0]], scale, shift, axis, *tail, variant=a.variant_fwd)
-            return extension.hip_forward_per_tensor(xs[cur[0]], scale, shift, *tail, variant=a.variant_fwd)
-        if per_channel:
-            return ops.lsq_forward_per_channel(xs[cur[0]], scale, shift, axis, *tail)
-        return ops.lsq_forward_per_tensor(xs[cur[0]], scale, shift, *tail)
-
-    pending = []   # N > 1: the previous step's in-flight all-reduce (RCCL runs it on its own stream)
-
-    def bwd():
-        if world == 1:
-            if a.variant_bwd:
+        def fwd():
+            if a.variant_fwd:
                 if per_channel:
-                    return extension.hip_backward_per_channel(gs[bset()], xs[bset()], scale, shift, axis, *tail, variant=a.variant_bwd)
-                return extension.hip_backward_per_tensor(gs[bset()], xs[bset()], scale, shift, *tail, variant=a.variant_bwd)
+                    return extension.hip_forward_per_channel(xs[cur[0]], scale, shift, axis, *tail, variant=a.variant_fwd)
+                return extension.hip_forward_per_tensor(xs[cur[0]], scale, shift, *tail, variant=a.variant_fwd)
             if per_channel:
-                return ops.lsq_backward_per_channel(gs[bset()], xs[bset()], scale, shift, axis, *tail)
-            return ops.lsq_backward_per_tensor(gs[bset()], xs[bset()], scale, shift, *tail)
-        # batch-sharded: local fused backward with the GLOBAL numel in the gradient scaler, then ONE
-        # all-reduce of the packed fp64 [d_scale, d_shift] sums.  The collective is issued async and
-        # consumed one step later (d_scale/d_shift are only needed by the optimizer), so its latency
-        # hides behind the next step's kernels; every reduction is completed inside the timed region.
-        dx, wide, work = sharded_backward(gs[bset()], xs[bset()], scale, shift, *q, axis, True, 1.0, c["affine"], per_channel, False, False,
-                                          None, n_global, async_op=True)
+                return ops.lsq_forward_per_channel(xs[cur[0]], scale, shift, axis, *tail)
+            return ops.lsq_forward_per_tensor(xs[cur[0]], scale, shift, *tail)
+
+        pending = []   # N > 1: the previous step's in-flight all-reduce (RCCL runs it on its own stream)
+
+        def bwd():
+            if world == 1:
+                if a.variant_bwd:
+                    if per_channel:
+                        return extension.hip_backward_per_channel(gs[bset()], xs[bset()], scale, shift, axis, *tail, variant=a.variant_bwd)
+                    return extension.hip_backward_per_tensor(gs[bset()], xs[bset()], scale, shift, *tail, variant=a.variant_bwd)
+                if per_channel:
+                    return ops.lsq_backward_per_channel(gs[bset()], xs[bset()], scale, shift, axis, *tail)
+                return ops.lsq_backward_per_tensor(gs[bset()], xs[bset()], scale, shift, *tail)
+            # batch-sharded: local fused backward with the GLOBAL numel in the gradient scaler, then ONE
+            # all-reduce of the packed fp64 [d_scale, d_shift] sums.  The collective is issued async and
+            # consumed one step later (d_scale/d_shift are only needed by the optimizer), so its latency
+            # hides behind the next step's kernels; every reduction is completed inside the timed region.
+            dx, wide, work = sharded_backward(gs[bset()], xs[bset()], scale, shift, *q, axis, True, 1.0, c["affine"], per_channel, False, False,
+                                              None, n_global, async_op=True)
+            drain()
+            pending.append((wide, work))
+            return dx
+
+        def drain():
+            while pending:
+                wide, work = pending.pop()
+                work.wait()                                   # stream-level wait, the host does not block
+                ds_db = wide.to(torch.float32)                # the rounding to the parameter type
+            return None
+
+        step_graphs = None
+        if graph:
+            st = torch.cuda.Stream()
+            step_graphs = []
+            with torch.cuda.stream(st):
+                for k in range(n_sets):          # one captured step per buffer set
+                    cur[0] = k
+                    fwd(); bwd()
+                    gr = torch.cuda.CUDAGraph()
+                    with torch.cudgraph(gr, stream=st):
+                        y = fwd()
+                        r = bwd()
+                    step_graphs.append(gr)
+            torch.cuda.synchronize()
+
+        for i in range(warmup):
+            cur[0] = i % n_sets
+            if step_graphs is not None:
+                step_graphs[cur[0]].replay()
+            else:
+                y = fwd()
+                r = bwd()
         drain()
-        pending.append((wide, work))
-        return dx
+        torch.cuda.synchronize()
 
-    def drain():
-        while pending:
-            wide, work = pending.pop()
-            work.wait()                                   # stream-level wait, the host does not block
-            ds_db = wide.to(torch.float32)                # the rounding to the parameter type
-        return None
-
-    step_graphs = None
-    if a.graph:
-        st = torch.cuda.Stream()
-        step_graphs = []
-        with torch.cuda.stream(st):
-            for k in range(n_sets):          # one captured step per buffer set
-                cur[0] = k
-                fwd(); bwd()
-                gr = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gr, stream=st):
+        # HIP events bracket the forward and the backward op on every `stride`-th step of the timed region (an
+        # event record drains the queue, so bracketing every op of every step would itself cost a few % of a
+        # 0.7 ms step); at least 10 steps are sampled.  (Under --graph the ops are nodes of one graph launch, so the
+        # per-op split comes from a second, un-timed pass of eager launches.)
+        stride = max(1, min(4, steps // 10))
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] if i % stride == 0 else None for i in range(steps)]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if step_graphs is not None:
+            for i in range(steps):
+                step_graphs[i % n_sets].replay()
+        else:
+            for i in range(steps):
+                cur[0] = i % n_sets
+                e = ev[i]
+                if e is None:
                     y = fwd()
                     r = bwd()
-                step_graphs.append(gr)
+                else:
+                    e[0].record()
+                    y = fwd()
+                    e[1].record()
+                    r = bwd()
+                    e[2].record()
+        drain()
         torch.cuda.synchronize()
-
-    for i in range(a.warmup):
-        cur[0] = i % n_sets
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
         if step_graphs is not None:
-            step_graphs[cur[0]].replay()
-        else:
-            y = fwd()
-            r = bwd()
-    drain()
-    torch.cuda.synchronize()
+            for i, e in enumerate(ev):
+                if e is not None:
+                    cur[0] = i % n_sets
+                    e[0].record(); y = fwd(); e[1].record(); r = bwd(); e[2].record()
+            torch.cuda.synchronize()
 
-    # HIP events bracket the forward and the backward op on every `stride`-th step of the timed region (an
-    # event record drains the queue, so bracketing every op of every step would itself cost a few % of a
-    # 0.7 ms step); at least 10 steps are sampled.  (Under --graph the ops are nodes of one graph launch, so the
-    # per-op split comes from a second, un-timed pass of eager launches.)
-    stride = max(1, min(4, a.steps // 10))
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] if i % stride == 0 else None for i in range(a.steps)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if step_graphs is not None:
-        for i in range(a.steps):
-            step_graphs[i % n_sets].replay()
-    else:
-        for i in range(a.steps):
-            cur[0] = i % n_sets
-            e = ev[i]
-            if e is None:
-                y = fwd()
-                r = bwd()
-            else:
-                e[0].record()
-                y = fwd()
-                e[1].record()
-                r = bwd()
-                e[2].record()
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if step_graphs is not None:
-        for i, e in enumerate(ev):
-            if e is not None:
-                cur[0] = i % n_sets
-                e[0].record(); y = fwd(); e[1].record(); r = bwd(); e[2].record()
-        torch.cuda.synchronize()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_max = float(t.item())
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed_max = float(t.item())
+        fwd_ms = sorted(e[0].elapsed_time(e[1]) for e in ev if e is not None)
+        bwd_ms = sorted(e[1].elapsed_time(e[2]) for e in ev if e is not None)
+        fwd_avg = sum(fwd_ms) / len(fwd_ms)
+        bwd_avg = sum(bwd_ms) / len(bwd_ms)
 
-    fwd_ms = sorted(e[0].elapsed_time(e[1]) for e in ev if e is not None)
-    bwd_ms = sorted(e[1].elapsed_time(e[2]) for e in ev if e is not None)
-    fwd_avg = sum(fwd_ms) / len(fwd_ms)
-    bwd_avg = sum(bwd_ms) / len(bwd_ms)
+        return dict(workload=workload, c=c, dtype_name=dtype_name, esz=esz, per_channel=per_channel, shape=shape, axis=axis,
+                    scaling=scaling, n_local=n_local, n_global=n_global, n_sets=n_sets, set_bytes=set_bytes, steps=steps,
+                    warmup=warmup, elapsed_max=elapsed_max, fwd_ms=fwd_ms, bwd_ms=bwd_ms, fwd_avg=fwd_avg, bwd_avg=bwd_avg,
+                    xs=xs, gs=gs, x=x)
 
+    m = measure(a.workload, a.steps, a.warmup, a.graph, a.buffers)
+    c, dtype_name, esz, per_channel, shape, axis = m["c"], m["dtype_name"], m["esz"], m["per_channel"], m["shape"], m["axis"]
+    scaling, n_local, n_global, n_sets, set_bytes = m["scaling"], m["n_local"], m["n_global"], m["n_sets"], m["set_bytes"]
+    elapsed_max, fwd_ms, bwd_ms, fwd_avg, bwd_avg = m["elapsed_max"], m["fwd_ms"], m["bwd_ms"], m["fwd_avg"], m["bwd_avg"]
+    xs, gs, x = m["xs"], m["gs"], m["x"]
     if rank == 0:
         bytes_fwd, bytes_bwd = 2 * esz, 3 * esz   # algorithmic bytes per element (SURVEY.md section 8(d)): R x + W y; R grad + R x + W dx
         value = n_global * a.steps / elapsed_max / 1e9
@@ -513,6 +533,40 @@ def run_rank(a):
                 line["roofline"]["same_box_reference_kernels"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(shape, a.workload)
+        if world == 1 and a.workload == "cfg2" and not a.graph and not a.no_secondary:
+            # The other single-GPU BASELINE configs (the small per-tensor one and the per-channel half of the path), timed in
+            # this process right after the headline region, the same way: eager launches, rotated input buffers, per-op HIP
+            # events.  `value` / `ms_per_step` are wall-clock over the K steps; the fractions are of the 8 TB/s peak.
+            del xs, gs, x, m
+            torch.cuda.empty_cache()
+            t_sec = time.perf_counter()
+            sec = []
+            for w in SECONDARY:
+                try:
+                    sm = measure(w, a.secondary_steps, 20)
+                    sb_f, sb_b = 2 * sm["esz"], 3 * sm["esz"]
+                    rec = {"workload": w, "shape": sm["shape"], "storage": sm["dtype_name"],
+                           "value": round(sm["n_global"] * sm["steps"] / sm["elapsed_max"] / 1e9, 3), "unit": "GElem/s",
+                           "steps": sm["steps"], "ms_per_step": round(sm["elapsed_max"] / sm["steps"] * 1e3, 5),
+                           "fwd_ms": round(sm["fwd_avg"], 5), "bwd_ms": round(sm["bwd_avg"], 5),
+                           "bwd_frac": round(sb_b * sm["n_local"] / (sm["bwd_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "fwd_frac": round(sb_f * sm["n_local"] / (sm["fwd_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "step_frac": round((sb_f + sb_b) * sm["n_local"] / ((sm["fwd_avg"] + sm["bwd_avg"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "step_frac_wall": round((sb_f + sb_b) * sm["n_local"] / (sm["elapsed_max"] / sm["steps"]) / 1e9 / HBM_PEAK_GBS, 4),
+                           "launch": "eager", "host_binding": binding, "input_buffer_sets": sm["n_sets"]}
+                    n_small = sm["n_local"] < (1 << 23)
+                    del sm
+                    if n_small and binding == "native":
+                        # launch-bound sizes: the Python / ctypes host layer next to the C++ binding (same kernels)
+                        sm = measure(w, a.secondary_steps, 20, ops=ops_of["ctypes"])
+                        rec["ms_per_step_ctypes_binding"] = round(sm["elapsed_max"] / sm["steps"] * 1e3, 5)
+                        del sm
+                    torch.cuda.empty_cache()
+                    sec.append(rec)
+                except Exception as e:      # never let a secondary record break the headline line
+                    sec.append({"workload": w, "error": repr(e)})
+            line["secondary"] = sec
+            line["secondary_wall_s"] = round(time.perf_counter() - t_sec, 2)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -73,9 +73,31 @@ __device__ __forceinline__ QParams<T> make_qparams(T s_sanitized, T shift, const
 
 // ---- forward (lsq_kernel.h:6-14) ---------------------------------------------------------------
 // the integer level, still in floating point: FASTROUND(FMIN(qmax, FMAX(qmin, x*inv_s + zp)))
+// The two clamps of the reference differ in their order, hence in where a NaN ends up:
+//   forward  (lsq_kernel.h:13)   fmin(qmax, fmax(qmin, t))   NaN -> qmin
+//   backward (lsq_kernel.h:108)  fmax(fmin(t, qmax), qmin)   NaN -> qmax
+// fp32: ONE v_med3_f32 each instead of v_max + v_min.  v_med3_f32 returns min3 of its operands when one of them is a NaN
+// (t is an arithmetic result, hence quiet), i.e. qmin -- the forward's answer; the backward's clamp is the same
+// instruction on the negated values, -med3(-t, -qmax, -qmin): a NaN goes to min3 = -qmax, and the negations fold into
+// source modifiers of the instructions around it.  Signed zeros order as in v_min / v_max (-0 < +0), so a clamp to a zero
+// bound gives the same zero as the two-instruction form.  Held to the reference bit for bit, NaN / +-inf / +-0 included,
+// by the golden cases of tests/test_parity_gpu.py.  fp64 has no med3 and keeps the two-instruction form.
+__device__ __forceinline__ float clamp_fwd(float t, float qmin, float qmax) { return __builtin_amdgcn_fmed3f(t, qmin, qmax); }
+__device__ __forceinline__ double clamp_fwd(double t, double qmin, double qmax) { return fmin_(qmax, fmax_(qmin, t)); }
+// -xq = med3(-t, -qmax, -qmin).  The (empty) asm keeps the result opaque: the compiler otherwise pushes a later negation
+// through the intrinsic -- "-med3(-a, -b, -c) == med3(a, b, c)", true for numbers, not for a NaN, which would end up on
+// qmin like in the forward (found by the NaN golden case).
+__device__ __forceinline__ float neg_clamp_bwd(float t, float nqmin, float nqmax) {
+    float m = __builtin_amdgcn_fmed3f(-t, nqmax, nqmin);
+    asm("" : "+v"(m));
+    return m;
+}
+__device__ __forceinline__ float clamp_bwd(float t, float qmin, float qmax) { return -neg_clamp_bwd(t, -qmin, -qmax); }
+__device__ __forceinline__ double clamp_bwd(double t, double qmin, double qmax) { return fmax_(fmin_(t, qmax), qmin); }
+
 template <typename T>
 __device__ __forceinline__ T clamped(T x, const QParams<T>& q, const Range<T>& r) {
-    return fmin_(r.qmax, fmax_(r.qmin, x * q.inv_s + q.zp));
+    return clamp_fwd(x * q.inv_s + q.zp, r.qmin, r.qmax);
 }
 template <typename T>
 __device__ __forceinline__ T level(T x, const QParams<T>& q, const Range<T>& r) {
@@ -104,15 +126,21 @@ __device__ __forceinline__ T dequant(T lvl, const QParams<T>& q) {
 template <typename T, bool SYM, bool INIT, bool RAW = false>
 __device__ __forceinline__ T backward_elem(T grad, T x, const QParams<T>& q, const Range<T>& r,
                                            T grad_scaler, T& ds_term, T& db_term) {
-    const T xq = fmax_(fmin_(x * q.inv_s + q.zp, r.qmax), r.qmin);  // :108, clamp = min then max, unrounded
-    const bool inside = (r.qmin < xq) && (xq < r.qmax);            // :109
+    const T xq = clamp_bwd(x * q.inv_s + q.zp, r.qmin, r.qmax);    // :108, clamp = min then max, unrounded
+    const bool inside = (r.qmin < xq) & (xq < r.qmax);             // :109
     const T mask = inside ? static_cast<T>(1) : static_cast<T>(0);
     const T dX = INIT ? grad : grad * mask;                        // :112 (a real multiply: inf*0 = NaN)
-    const T xfq = (rne(xq) - q.zp) * q.s;                          // :115
+    const T d = rne(xq) - q.zp;
+    const T xfq = d * q.s;                                         // :115
     const T err = xfq - x;
     const T g_ = INIT ? static_cast<T>(2) * err : grad;            // :116
-    const T border = (xq <= r.qmin) ? g_ * (r.qmin - q.zp) : g_ * (r.qmax - q.zp);  // :120
-    const T dS = inside ? g_ * err * q.inv_s : border;             // :121
+    // :120 border = xq <= qmin ? g_ * (qmin - zp) : g_ * (qmax - zp).  An element that is not inside sits exactly ON a
+    // border (the clamp put it there, a NaN on qmax), the borders are integers, so rne(xq) == xq == that border and `d`
+    // already IS (qmin - zp) resp. (qmax - zp), the same subtraction of the same two values: no comparison, no second
+    // constant.
+    const T border = g_ * d;
+    const T inner = g_ * err * q.inv_s;                            // (both arms are values: the ternary below is a select)
+    const T dS = inside ? inner : border;                          // :121
     ds_term = RAW ? dS : dS * grad_scaler;                         // :122
     if (SYM) {
         db_term = static_cast<T>(0);                               // :118 (0 * scaler)
@@ -127,9 +155,67 @@ __device__ __forceinline__ T backward_elem(T grad, T x, const QParams<T>& q, con
 template <typename T, bool INIT>
 __device__ __forceinline__ T backward_elem_eval(T grad, T x, const QParams<T>& q, const Range<T>& r) {
     if (INIT) return grad;
-    const T xq = fmax_(fmin_(x * q.inv_s + q.zp, r.qmax), r.qmin);
+    const T xq = clamp_bwd(x * q.inv_s + q.zp, r.qmin, r.qmax);
     const bool inside = (r.qmin < xq) && (xq < r.qmax);
     return grad * (inside ? static_cast<T>(1) : static_cast<T>(0));
+}
+
+// ---- the same arithmetic on PAIRS of fp32 elements ------------------------------------------------------------------
+// gfx950 has packed fp32 multiply / add (v_pk_mul_f32, v_pk_add_f32: two lanes' worth of one IEEE operation per
+// instruction, each half individually rounded -- no contraction, same bits as the scalar forms) but no packed min / max /
+// round / compare / select.  The streaming kernels whose time is instruction issue rather than HBM (16-bit storage: half
+// the bytes per element) therefore compute on explicit 2-vectors: every multiply and add of lsq_kernel.h below is ONE
+// packed instruction per two elements, the rest one instruction per element.  Element for element this is
+// backward_elem / level / dequant above, operation by operation (the negated clamp only moves signs into source
+// modifiers: rne(-v) == -rne(v), (-a) - b == -(a + b) bit for bit under round-to-nearest-even).
+using f2 = __attribute__((ext_vector_type(2))) float;
+
+struct QPair {   // the constants of two adjacent elements (the same channel or two channels)
+    f2 s, inv_s, zp;
+};
+__device__ __forceinline__ QPair make_qpair(const QParams<float>& a, const QParams<float>& b) {
+    QPair q;
+    q.s = f2{a.s, b.s}; q.inv_s = f2{a.inv_s, b.inv_s}; q.zp = f2{a.zp, b.zp};
+    return q;
+}
+__device__ __forceinline__ f2 select2(bool c0, bool c1, f2 a, f2 b) { return f2{c0 ? a.x : b.x, c1 ? a.y : b.y}; }
+
+// forward (lsq_kernel.h:6-14): the clamped, unrounded level position c (what aux_byte wants) and y
+__device__ __forceinline__ f2 forward_pair(f2 x, const QPair& q, const Range<float>& r, f2& c) {
+    const f2 t = x * q.inv_s + q.zp;
+    c = f2{clamp_fwd(t.x, r.qmin, r.qmax), clamp_fwd(t.y, r.qmin, r.qmax)};
+    const f2 lvl = f2{rne(c.x), rne(c.y)};
+    return (lvl - q.zp) * q.s;
+}
+
+// backward (lsq_kernel.h:94-123): returns dX; ds / db are the per-element terms WITHOUT the gradient scaler (the caller
+// multiplies terms or sums, see backward_elem's RAW)
+template <bool SYM, bool INIT>
+__device__ __forceinline__ f2 backward_pair(f2 grad, f2 x, const QPair& q, const Range<float>& r, f2& ds, f2& db) {
+    const float nqmin = -r.qmin, nqmax = -r.qmax;
+    const f2 t = x * q.inv_s + q.zp;
+    const f2 nxq = f2{neg_clamp_bwd(t.x, nqmin, nqmax), neg_clamp_bwd(t.y, nqmin, nqmax)};                        // -xq, :108
+    const bool in0 = (nxq.x < nqmin) & (nqmax < nxq.x), in1 = (nxq.y < nqmin) & (nqmax < nxq.y);                  // :109
+    const f2 mask = f2{in0 ? 1.0f : 0.0f, in1 ? 1.0f : 0.0f};
+    const f2 dX = INIT ? grad : grad * mask;                      // :112
+    const f2 d = -f2{rne(nxq.x), rne(nxq.y)} - q.zp;              // rne(xq) - zp
+    const f2 err = d * q.s - x;                                   // :115 xfq - x
+    const f2 g_ = INIT ? 2.0f * err : grad;                       // :116
+    const f2 border = g_ * d;                                     // :120 (see backward_elem: d IS the border constant)
+    const f2 inner = g_ * err * q.inv_s;
+    ds = select2(in0, in1, inner, border);                        // :121
+    db = SYM ? f2{0.0f, 0.0f} : (1.0f - mask) * g_;               // :118
+    return dX;
+}
+
+template <bool INIT>
+__device__ __forceinline__ f2 backward_pair_eval(f2 grad, f2 x, const QPair& q, const Range<float>& r) {
+    if (INIT) return grad;
+    const float nqmin = -r.qmin, nqmax = -r.qmax;
+    const f2 t = x * q.inv_s + q.zp;
+    const f2 nxq = f2{neg_clamp_bwd(t.x, nqmin, nqmax), neg_clamp_bwd(t.y, nqmin, nqmax)};
+    const bool in0 = (nxq.x < nqmin) & (nqmax < nxq.x), in1 = (nxq.y < nqmin) & (nqmax < nxq.y);
+    return grad * f2{in0 ? 1.0f : 0.0f, in1 ? 1.0f : 0.0f};
 }
 
 // ---- storage types: 16-byte vectors in HBM, arithmetic type in registers ------------------------

@@ -105,6 +105,24 @@ struct LaneChannels {
         }
         return q[j < N ? j : 0];
     }
+    // constants of the component pair (2 pr, 2 pr + 1), fp32 arithmetic: what backward_pair / forward_pair take.  Built
+    // field by field from scalars (selects for the two-channel form) -- once, before the row loop.
+    __device__ __forceinline__ QPair pair(int pr) const {
+        static_assert(std::is_same<T, float>::value || N == 0, "pairs are an fp32 construct");
+        QPair o;
+        if (N == 1) {
+            o.s = f2{q[0].s, q[0].s}; o.inv_s = f2{q[0].inv_s, q[0].inv_s}; o.zp = f2{q[0].zp, q[0].zp};
+        } else if (CPL == 2) {
+            const bool h0 = 2 * pr >= split, h1 = 2 * pr + 1 >= split;
+            o.s = f2{h0 ? q[N - 1].s : q[0].s, h1 ? q[N - 1].s : q[0].s};
+            o.inv_s = f2{h0 ? q[N - 1].inv_s : q[0].inv_s, h1 ? q[N - 1].inv_s : q[0].inv_s};
+            o.zp = f2{h0 ? q[N - 1].zp : q[0].zp, h1 ? q[N - 1].zp : q[0].zp};
+        } else {
+            const int a = 2 * pr < N ? 2 * pr : 0, b = 2 * pr + 1 < N ? 2 * pr + 1 : 0;
+            o.s = f2{q[a].s, q[b].s}; o.inv_s = f2{q[a].inv_s, q[b].inv_s}; o.zp = f2{q[a].zp, q[b].zp};
+        }
+        return o;
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -155,17 +173,40 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
     ch.init(table, site, g);
     const T bias = static_cast<T>(level_bias);
 
+    // fp32 arithmetic on packets: two elements at a time (forward_pair: packed multiplies and adds), the lane's constants
+    // per component pair in registers for the whole walk
+    constexpr bool PAIRS = std::is_same<T, float>::value && V >= 2;
+    QPair qp[PAIRS ? V / 2 : 1];
+    if constexpr (PAIRS) {
+#pragma unroll
+        for (int pr = 0; pr < V / 2; ++pr) qp[pr] = ch.pair(pr);
+    }
     auto emit_row = [&](int64_t oo, const E (&in)[V], bool valid) {
         const int64_t e = oo * g.L + site.p0;
         E out[V];
         LevelPack<V> lv;
+        if constexpr (PAIRS) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            const QParams<T> q = ch.params(j);
-            const T xv = static_cast<T>(in[j]);
-            const T c = clamped<T>(xv, q, r);
-            out[j] = IO::to_elem(INIT ? xv : dequant<T>(rne(c), q));
-            if (LEVELS) lv.b[j] = aux_byte<T>(c, r, bias, aux_kind);
+            for (int pr = 0; pr < V / 2; ++pr) {
+                const f2 xv = f2{static_cast<T>(in[2 * pr]), static_cast<T>(in[2 * pr + 1])};
+                f2 c;
+                const f2 yv = forward_pair(xv, qp[pr], r, c);
+                out[2 * pr] = IO::to_elem(INIT ? xv.x : yv.x);
+                out[2 * pr + 1] = IO::to_elem(INIT ? xv.y : yv.y);
+                if (LEVELS) {
+                    lv.b[2 * pr] = aux_byte<T>(c.x, r, bias, aux_kind);
+                    lv.b[2 * pr + 1] = aux_byte<T>(c.y, r, bias, aux_kind);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const QParams<T> q = ch.params(j);
+                const T xv = static_cast<T>(in[j]);
+                const T c = clamped<T>(xv, q, r);
+                out[j] = IO::to_elem(INIT ? xv : dequant<T>(rne(c), q));
+                if (LEVELS) lv.b[j] = aux_byte<T>(c, r, bias, aux_kind);
+            }
         }
         if (valid) {
             store_elems<IO, V, NTS>(y, e, out);
@@ -331,54 +372,103 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
 
     // CPL == 1: one accumulator pair.  CPL == 2 / V: one pair per COMPONENT of the packet (a cvt + an add per
     // term in the loop, no selects); CPL == 2 folds them into its two channels after the walk, by `split`.
-    constexpr int kAcc = (LC::N == 1) ? 1 : V;
+    // PAIRS (fp32 arithmetic on packets): the row is computed two elements at a time (backward_pair: packed multiplies and
+    // adds) and the accumulators are 2-vectors too; CPL == 1 then keeps TWO accumulators (even / odd components), added
+    // up after the walk.
+    constexpr bool PAIRS = std::is_same<T, float>::value && V >= 2;
+    constexpr int kAcc = (LC::N == 1) ? (PAIRS ? 2 : 1) : V;
     double acc_s[kAcc], acc_b[kAcc];
 #pragma unroll
     for (int j = 0; j < kAcc; ++j) { acc_s[j] = 0.0; acc_b[j] = 0.0; }
     // PRE32 (16-bit storage on the LDS-DMA ring): the kernel is VALU-bound (profiles/r02_sq_counters_before_cfg5_bf16.txt)
     // and every wave64 VALU instruction costs ~4 cycles whatever its width (profiles/r02_valu_issue_rates.txt), so the
     // reduction is made cheaper per term, within the parity bar of 1e-6 x sum|terms| (profiles/r02_pre32_ab.txt: -6 %):
-    //  * the terms of up to kPreRows consecutive rows are first added per component in fp32 (one packed add for the
-    //    d_scale / d_shift pair), then the pre-sum joins the fp64 accumulator -- a convert and an fp64 add per kPreRows
+    //  * the terms of up to kPreRows consecutive rows are first added per component in fp32 (one packed add for two
+    //    components), then the pre-sum joins the fp64 accumulator -- a convert and an fp64 add per kPreRows
     //    terms instead of per term; at most kPreRows - 1 fp32 roundings per pre-sum, <= 1.8e-7 of the sum of the |terms|
     //    in the worst case, ~1e-9 typically;
     //  * the gradient scaler multiplies the fp64 sums once (backward_elem<.., RAW>) instead of every term.
     constexpr bool PRE32 = DMA > 0 && sizeof(E) < 4 && !EVAL;
+    static_assert(!PRE32 || PAIRS, "16-bit storage on the ring moves packets of 8");
     constexpr int kPreRows = 4;
-    T pre_s[PRE32 ? kAcc : 1], pre_b[PRE32 ? kAcc : 1];
+    f2 pre_s[PRE32 ? kAcc / 2 : 1], pre_b[PRE32 ? kAcc / 2 : 1];
 #pragma unroll
-    for (int j = 0; j < (PRE32 ? kAcc : 1); ++j) { pre_s[j] = static_cast<T>(0); pre_b[j] = static_cast<T>(0); }
-    auto flush_pre = [&]() {
+    for (int j = 0; j < (PRE32 ? kAcc / 2 : 1); ++j) { pre_s[j] = f2{0.0f, 0.0f}; pre_b[j] = f2{0.0f, 0.0f}; }
+    // the lane's constants per component pair, in registers for the whole walk
+    QPair qp[PAIRS ? V / 2 : 1];
+    if constexpr (PAIRS) {
+#pragma unroll
+        for (int pr = 0; pr < V / 2; ++pr) qp[pr] = ch.pair(pr);
+    }
+
+    // CLEAR = false: the caller's next row ASSIGNS the pre-sums (emit_row_at's `first`), so they need no zeroing
+    auto flush_pre = [&](auto clear) {
         if constexpr (PRE32) {
 #pragma unroll
-            for (int j = 0; j < kAcc; ++j) {
-                acc_s[j] += static_cast<double>(pre_s[j]);
-                pre_s[j] = static_cast<T>(0);
+            for (int a = 0; a < kAcc / 2; ++a) {
+                acc_s[2 * a] += static_cast<double>(pre_s[a].x);
+                acc_s[2 * a + 1] += static_cast<double>(pre_s[a].y);
+                if (decltype(clear)::value) pre_s[a] = f2{0.0f, 0.0f};
                 if (!SYM) {
-                    acc_b[j] += static_cast<double>(pre_b[j]);
-                    pre_b[j] = static_cast<T>(0);
+                    acc_b[2 * a] += static_cast<double>(pre_b[a].x);
+                    acc_b[2 * a + 1] += static_cast<double>(pre_b[a].y);
+                    if (decltype(clear)::value) pre_b[a] = f2{0.0f, 0.0f};
                 }
             }
         }
     };
 
-    auto emit_row = [&](int64_t oo, const E (&gi)[V], const E (&xi)[V], bool valid) {
-        const int64_t e = oo * g.L + site.p0;
+    // one row of this lane: V elements at element offset e.  `first` (compile time): the row opens a pre-sum group, its
+    // terms are assigned instead of added (no zeroing, no add).
+    auto emit_row_at = [&](int64_t e, const E (&gi)[V], const E (&xi)[V], bool valid, auto first) {
         E out[V];
+        if constexpr (PAIRS) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            const QParams<T> q = ch.params(j);
-            const T gv = static_cast<T>(gi[j]), xv = static_cast<T>(xi[j]);
-            if (EVAL) {
-                out[j] = IO::to_elem(backward_elem_eval<T, INIT>(gv, xv, q, r));
-            } else {
-                T ds_t, db_t;
-                out[j] = IO::to_elem(backward_elem<T, SYM, INIT, PRE32>(gv, xv, q, r, grad_scaler, ds_t, db_t));
-                if (!valid) { ds_t = static_cast<T>(0); db_t = static_cast<T>(0); }
-                if constexpr (PRE32) {
-                    pre_s[j < kAcc ? j : 0] += ds_t;
-                    if (!SYM) pre_b[j < kAcc ? j : 0] += db_t;
+            for (int pr = 0; pr < V / 2; ++pr) {
+                const QPair& q = qp[pr];
+                const f2 gv = f2{static_cast<T>(gi[2 * pr]), static_cast<T>(gi[2 * pr + 1])};
+                const f2 xv = f2{static_cast<T>(xi[2 * pr]), static_cast<T>(xi[2 * pr + 1])};
+                f2 dxv;
+                if constexpr (EVAL) {
+                    dxv = backward_pair_eval<INIT>(gv, xv, q, r);
                 } else {
+                    f2 ds_t, db_t;
+                    dxv = backward_pair<SYM, INIT>(gv, xv, q, r, ds_t, db_t);
+                    if (!valid) { ds_t = f2{0.0f, 0.0f}; db_t = f2{0.0f, 0.0f}; }
+                    const int a = (LC::N == 1) ? 0 : pr;           // accumulator pair of this component pair (unrolled: a constant)
+                    if constexpr (PRE32) {
+                        if (decltype(first)::value && (LC::N != 1 || pr == 0)) {
+                            pre_s[a] = ds_t;
+                            if (!SYM) pre_b[a] = db_t;
+                        } else {
+                            pre_s[a] += ds_t;
+                            if (!SYM) pre_b[a] += db_t;
+                        }
+                    } else {
+                        ds_t *= grad_scaler;                        // :122, every term individually (reference bits)
+                        acc_s[2 * a] += static_cast<double>(ds_t.x);
+                        acc_s[2 * a + 1] += static_cast<double>(ds_t.y);
+                        if (!SYM) {
+                            db_t *= grad_scaler;
+                            acc_b[2 * a] += static_cast<double>(db_t.x);
+                            acc_b[2 * a + 1] += static_cast<double>(db_t.y);
+                        }
+                    }
+                }
+                out[2 * pr] = IO::to_elem(dxv.x);
+                out[2 * pr + 1] = IO::to_elem(dxv.y);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const QParams<T> q = ch.params(j);
+                const T gv = static_cast<T>(gi[j]), xv = static_cast<T>(xi[j]);
+                if (EVAL) {
+                    out[j] = IO::to_elem(backward_elem_eval<T, INIT>(gv, xv, q, r));
+                } else {
+                    T ds_t, db_t;
+                    out[j] = IO::to_elem(backward_elem<T, SYM, INIT>(gv, xv, q, r, grad_scaler, ds_t, db_t));
+                    if (!valid) { ds_t = static_cast<T>(0); db_t = static_cast<T>(0); }
                     const double a = static_cast<double>(ds_t), c = static_cast<double>(db_t);
                     acc_s[j < kAcc ? j : 0] += a;
                     if (!SYM) acc_b[j < kAcc ? j : 0] += c;
@@ -386,6 +476,9 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
             }
         }
         if (valid) store_elems<IO, V, NTS>(dx, e, out);
+    };
+    auto emit_row = [&](int64_t oo, const E (&gi)[V], const E (&xi)[V], bool valid) {
+        emit_row_at(oo * g.L + site.p0, gi, xi, valid, std::false_type{});
     };
 
     auto emit_full = [&](int64_t i0, const E (&gb)[UNROLL][V], const E (&xb)[UNROLL][V]) {
@@ -419,18 +512,52 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
                 emit_row(walk.row(it) < g.outer ? walk.row(it) : g.outer - 1, gi, xi, it < walk.n_rows);
             }
         };
-        auto loop = [&](auto all_valid) {
-            for (; i + DMA < dma_n; ++i) {           // steady state: the ring is full, one refill per row, no branches
+        auto loop = [&](auto all_valid, auto nt) {
+            if constexpr (decltype(all_valid)::value) {
+                // Steady state in blocks of DMA rows: the ring stage of a row is a compile-time constant (its LDS addresses
+                // are instruction offsets), the lane's row addresses advance by one add (every lane walks every row: no
+                // clamping), and -- PRE32 -- the first row of a block assigns the pre-sums, which are flushed un-cleared at
+                // its end.  Row i + u was requested DMA rows ago; the copies counted by the wait are those of the DMA - 1
+                // rows after it.
+                static_assert(!PRE32 || DMA <= kPreRows, "a pre-sum group is at most kPreRows rows");
+                const int64_t step_e = walk.step * g.L;
+                int64_t e_cur = walk.row(0) * g.L + site.p0;          // i == 0 here
+                for (; i + 2 * DMA <= dma_n; i += DMA) {
+#pragma unroll
+                    for (int u = 0; u < DMA; ++u) {
+                        wait_vm<2 * (DMA - 1)>();
+                        const unsigned char* stage = ring + u * kDmaStageBytes + lane * 16;
+                        const V4 graw = *reinterpret_cast<const V4*>(stage);
+                        const V4 xraw = *reinterpret_cast<const V4*>(stage + 64 * 16);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the stage is in registers: refill it
+                        const int64_t e_next = e_cur + DMA * step_e;
+                        glds16<decltype(nt)::value>(static_cast<const E*>(grad) + e_next, ring_lds + u * kDmaStageBytes);
+                        glds16<decltype(nt)::value>(static_cast<const E*>(x) + e_next, ring_lds + u * kDmaStageBytes + 64 * 16);
+                        E gi[V], xi[V];
+                        __builtin_memcpy(&gi[0], &graw, 16);
+                        __builtin_memcpy(&xi[0], &xraw, 16);
+                        if (u == 0) emit_row_at(e_cur, gi, xi, true, std::true_type{});
+                        else emit_row_at(e_cur, gi, xi, true, std::false_type{});
+                        e_cur += step_e;
+                    }
+                    flush_pre(std::false_type{});
+                }
+                if constexpr (PRE32) {
+#pragma unroll
+                    for (int j = 0; j < kAcc / 2; ++j) { pre_s[j] = f2{0.0f, 0.0f}; pre_b[j] = f2{0.0f, 0.0f}; }
+                }
+            }
+            for (; i + DMA < dma_n; ++i) {           // the ring is full, one refill per row
                 wait_vm<2 * (DMA - 1)>();
                 consume(i, true, all_valid);
-                if (PRE32 && (i & (kPreRows - 1)) == kPreRows - 1) flush_pre();
+                if (PRE32 && (i & (kPreRows - 1)) == kPreRows - 1) flush_pre(std::true_type{});
             }
             for (; i < dma_n; ++i) {                 // the last DMA rows: nothing left to request
                 wait_vm_upto(static_cast<int>(2 * (dma_n - 1 - i)));
                 consume(i, false, all_valid);
-                if (PRE32 && (i & (kPreRows - 1)) == kPreRows - 1) flush_pre();
+                if (PRE32 && (i & (kPreRows - 1)) == kPreRows - 1) flush_pre(std::true_type{});
             }
-            flush_pre();
+            flush_pre(std::true_type{});
             if constexpr (PRE32) {           // the gradient scaler, once per sum
 #pragma unroll
                 for (int j = 0; j < kAcc; ++j) {
@@ -440,8 +567,12 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
             }
         };
         // every lane of this wave walks all dma_n rows (no dead lane, no ragged last tile): no per-row validity selects
-        if (__builtin_amdgcn_readfirstlane(__all(site.live && walk.n_rows == dma_n) ? 1 : 0)) loop(std::true_type{});
-        else loop(std::false_type{});
+        if (__builtin_amdgcn_readfirstlane(__all(site.live && walk.n_rows == dma_n) ? 1 : 0)) {
+            if (g.ring_nt) loop(std::true_type{}, std::true_type{});
+            else loop(std::true_type{}, std::false_type{});
+        } else {
+            loop(std::false_type{}, std::false_type{});
+        }
     } else if (PIPE) {
         // Software pipeline, two register buffers: the loads of group k+1 are issued BEFORE the arithmetic of
         // group k, so every wave keeps HBM requests in flight while it computes (for 16-bit storage the VALU time
@@ -495,6 +626,10 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
         if constexpr (UNROLL >= 2) if (i < walk.n_rows) group(i, std::integral_constant<int, 1>{});
     }
     if (EVAL) return;
+    if constexpr (PAIRS && LC::N == 1) {     // one channel per lane: even + odd components
+        acc_s[0] += acc_s[1];
+        acc_b[0] += acc_b[1];
+    }
 
     if constexpr (WW) {
         // R row groups, R interleaved row sets of the same w x V channels: groups 1..R-1 park their sums in LDS

@@ -107,11 +107,45 @@ SEED_X, SEED_G, SEED_SCALE, SEED_SHIFT = 11, 23, 37, 41
 GRAD_STD = 1e-3
 
 
+def ds_term_sign(x, scale, shift, c):
+    """+1 / -1 per element: the sign of the factor the d_scale term of the element multiplies its gradient with
+    (reference lsq_kernel.h:115-121: (x_r - x) / s inside the range, quant_min - zp or quant_max - zp on a border).
+
+    Single IEEE fp32 operations only, the per-channel constants (a division) always on the CPU, so the CPU and the GPU
+    give the same bits.  Used for the `abs_grad="dspos"` gradients below; finite inputs only."""
+    f32 = torch.float32
+    eps = torch.finfo(f32).eps
+    sc, sh = scale.detach().to("cpu", f32), shift.detach().to("cpu", f32)
+    s = torch.clamp(sc.abs(), min=eps)
+    inv_s = 1.0 / s
+    zp = torch.round(torch.clamp(-sh * inv_s, min=float(c["tmin"]), max=float(c["tmax"])))
+    if c["per_channel"]:
+        view = [1] * x.dim()
+        view[c["axis"]] = x.shape[c["axis"]]
+        s, inv_s, zp = (t.view(view).to(x.device) for t in (s, inv_s, zp))
+    else:
+        s, inv_s, zp = (t.to(x.device) for t in (s, inv_s, zp))
+    xf = x.detach().to(f32)
+    t = xf * inv_s
+    t = t + zp
+    xq = torch.clamp(t, min=float(c["qmin"]), max=float(c["qmax"]))
+    inside = (xq > float(c["qmin"])) & (xq < float(c["qmax"]))
+    d = torch.round(xq) - zp
+    err = d * s
+    err = err - xf
+    coef = torch.where(inside, err, d)
+    return torch.where(coef < 0, -torch.ones_like(coef), torch.ones_like(coef))
+
+
 def make_inputs(cfg, device="cpu", dtype=None, shape=None, abs_grad=False):
     """(x, grad, scale, shift) for a CONFIGS entry (or a dict of the same keys).
 
     `shape` overrides the configured shape (e.g. one rank's shard); `dtype` overrides the storage
     type of x/grad (scale/shift are always fp32 unless dtype is float64).
+    `abs_grad`: False -- grad ~ N(0, GRAD_STD), mixed sign; True -- |grad| (every d_shift term and every border term of one
+    side has one sign: no cancellation in a per-tensor quint8 d_scale, still some in a signed range); "dspos" -- |grad| times
+    the sign of the element's d_scale factor (ds_term_sign): every d_scale term is >= 0, the no-cancellation case of d_scale
+    for any range.
     """
     c = CONFIGS[cfg] if isinstance(cfg, str) else cfg
     shape = tuple(shape if shape is not None else c["shape"])
@@ -121,7 +155,7 @@ def make_inputs(cfg, device="cpu", dtype=None, shape=None, abs_grad=False):
     dt = dtype if dtype is not None else getattr(torch, c["dtype"])
     pdt = torch.float64 if dt == torch.float64 else torch.float32
     x = normal_like(numel, SEED_X, c["x_mean"], c["x_std"], device, dt).view(shape)
-    g = normal_like(numel, SEED_G, 0.0, GRAD_STD, device, dt, absolute=abs_grad).view(shape)
+    g = normal_like(numel, SEED_G, 0.0, GRAD_STD, device, dt, absolute=bool(abs_grad)).view(shape)
     C = shape[c["axis"]] if c["per_channel"] else 1
     sc = c["scale"]
     if isinstance(sc, tuple):
@@ -133,6 +167,8 @@ def make_inputs(cfg, device="cpu", dtype=None, shape=None, abs_grad=False):
         shift = normal_like(C, SEED_SHIFT, sh[1], sh[2], device, pdt)
     else:
         shift = torch.full((C,), float(sh), dtype=pdt, device=device)
+    if abs_grad == "dspos":
+        g = g * ds_term_sign(x, scale, shift, c).to(g.dtype)
     return x, g, scale, shift
 
 

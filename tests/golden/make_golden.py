@@ -371,7 +371,7 @@ def digest_config(ref, name, cfg_key, bf16=False, abs_grad=False):
     return rec
 
 
-def make_digests(ref, big):
+def make_digests(ref, big, only=None):
     path = os.path.join(HERE, "config_digests.json")
     out = {}
     if os.path.isfile(path):
@@ -379,11 +379,17 @@ def make_digests(ref, big):
             out = json.load(f).get("configs", {})
     jobs = [("cfg1", "cfg1", False, False), ("cfg1_absgrad", "cfg1", False, True),
             ("cfg3", "cfg3", False, False), ("cfg3_absgrad", "cfg3", False, True),
-            ("cfg5_fp32", "cfg5", False, False), ("cfg5_bf16", "cfg5", True, False)]
+            ("cfg5_fp32", "cfg5", False, False), ("cfg5_bf16", "cfg5", True, False),
+            ("cfg5_absgrad", "cfg5", False, True), ("cfg5_bf16_absgrad", "cfg5", True, True),
+            # |grad| x the sign of each element's d_scale factor: every d_scale term >= 0 (synth.ds_term_sign)
+            ("cfg3_dspos", "cfg3", False, "dspos"), ("cfg5_dspos", "cfg5", False, "dspos"),
+            ("cfg5_bf16_dspos", "cfg5", True, "dspos")]
     if big:
         jobs += [("cfg2", "cfg2", False, False), ("cfg2_absgrad", "cfg2", False, True),
                  ("cfg4", "cfg4", False, False)]
     for name, key, bf16, absg in jobs:
+        if only and name not in only:
+            continue
         out[name] = digest_config(ref, name, key, bf16, absg)
     with open(path, "w") as f:
         json.dump(dict(generator="tests/golden/make_golden.py", torch=torch.__version__, threads=torch.get_num_threads(),
@@ -396,10 +402,11 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also digest cfg2/cfg4 (205 M elements each)")
     ap.add_argument("--skip-small", action="store_true")
+    ap.add_argument("--only", default="", help="comma-separated digest names to (re)generate; the others are kept as they are")
     a = ap.parse_args()
     import warnings
     warnings.filterwarnings("ignore")
     ref = load_reference()
     if not a.skip_small:
         make_small(ref)
-    make_digests(ref, a.big)
+    make_digests(ref, a.big, set(a.only.split(",")) if a.only else None)

@@ -96,15 +96,34 @@ def tolist(t):
     return None if t is None else [float(v) for v in t.detach().reshape(-1).tolist()]
 
 
-def drive(module_cls, sc):
-    """Run one scenario on `module_cls`; shared by the generator (reference class) and the test."""
+# scenario -> the call after which the reference module's state_dict() is dumped (tests/golden/module_state_dicts.npz):
+# mid-way through the observer-driven init phase, mid-way through the learnable init phase, a learned per-channel weight
+# quantizer, a per-channel observer.  tests/test_host_logic.py loads them into this repository's module.
+STATE_DUMPS = {"act_observer_pt": 1, "act_learnable_pt": 1, "weight_pc_sym": 2, "act_observer_pc": 1, "act_fakequant_only": 2}
+
+
+def state_to_numpy(sd):
+    return {k: v.detach().cpu().numpy().copy() for k, v in sd.items()}     # a copy: the live tensors go on changing
+
+
+def drive(module_cls, sc, dump_state_after=None, resume=None):
+    """Run one scenario on `module_cls`; shared by the generator (reference class) and the test.
+
+    dump_state_after = k: additionally return the module's state_dict() (numpy) taken after call k.
+    resume = (k, state): only the creating call 0 is made, then `state` (a state_dict taken after call k of the same
+    scenario, possibly by ANOTHER implementation of the module) is loaded and the scenario continues with call k + 1."""
     from torch.ao.quantization import observer as obs_mod
     observer = getattr(obs_mod, sc["observer"]) if sc["observer"] else None
     m = module_cls(observer, **build_kwargs(sc["ctor"]))
     m.train()
     n = int(np.prod(sc["shape"]))
     out = []
+    dumped = None
     for i in range(sc["calls"]):
+        if resume is not None and 0 < i <= resume[0]:
+            if i == resume[0]:
+                m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in resume[1].items()})
+            continue
         act = sc.get("actions", {}).get(str(i))
         if act:
             getattr(m, act)()
@@ -129,11 +148,15 @@ def drive(module_cls, sc):
                    fake_quant_enabled=int(m.fake_quant_enabled[0]), learning_enabled=int(m.learning_enabled[0]),
                    n_batches=int(m.n_batches), initialized=bool(m._initialized))
         out.append(rec)
+        if dump_state_after is not None and i == dump_state_after:
+            dumped = state_to_numpy(m.state_dict())
     qp = m.calculate_qparams(verbose=False, need_shift=True)
     final = dict(qparams=[tolist(torch.as_tensor(v, dtype=torch.float64)) for v in qp],
                  state_dict_keys=list(m.state_dict().keys()), quant_min=m.quant_min, quant_max=m.quant_max,
                  ch_axis=m.ch_axis, is_perchannel=bool(m.is_perchannel), is_affine=bool(m.is_affine),
                  init_shift=float(m.init_shift), repr=m.extra_repr())
+    if dump_state_after is not None:
+        return out, final, dumped
     return out, final
 
 
@@ -161,8 +184,17 @@ if __name__ == "__main__":
     ref = import_reference_module()
     assert ref.__file__.startswith(REF_PKG)
     traces = {}
+    states, state_meta = {}, {}
     for sc in SCENARIOS:
-        calls, final = drive(ref.LSQFakeQuantizer, sc)
+        if sc["name"] in STATE_DUMPS:
+            k = STATE_DUMPS[sc["name"]]
+            calls, final, sd = drive(ref.LSQFakeQuantizer, sc, dump_state_after=k)
+            for key, v in sd.items():
+                states[sc["name"] + "/" + key] = v
+            state_meta[sc["name"]] = dict(after_call=k, keys=list(sd.keys()), dtypes={key: str(v.dtype) for key, v in sd.items()},
+                                          shapes={key: list(v.shape) for key, v in sd.items()})
+        else:
+            calls, final = drive(ref.LSQFakeQuantizer, sc)
         traces[sc["name"]] = dict(scenario=sc, calls=calls, final=final)
         print("%-24s %d calls  cur=%s obs=%s rg=%s" % (sc["name"], len(calls), [c["current_batch"] for c in calls],
                                                       [c["observer_enabled"] for c in calls],
@@ -180,5 +212,6 @@ if __name__ == "__main__":
     with open(os.path.join(HERE, "module_traces.json"), "w") as f:
         json.dump(dict(generator="tests/golden/make_module_traces.py", torch=torch.__version__,
                        reference="DeadAt0m/LSQFakeQuantize-PyTorch torchlsq/quantized/modules/observers.py (imported in place)",
-                       traces=traces, extras=extras), f, indent=1)
-    print("wrote module_traces.json")
+                       traces=traces, extras=extras, state_dicts=state_meta), f, indent=1)
+    np.savez(os.path.join(HERE, "module_state_dicts.npz"), **states)
+    print("wrote module_traces.json, module_state_dicts.npz (%d tensors of %d reference state dicts)" % (len(states), len(state_meta)))

@@ -129,6 +129,44 @@ def test_state_dict_roundtrip(oracle_cpu_backend):
     assert torch.equal(a(x), b(x))
 
 
+def _reference_state(traces, name):
+    z = np.load(os.path.join(GOLDEN, "module_state_dicts.npz"))
+    meta = traces["state_dicts"][name]
+    return meta, {k: z[name + "/" + k] for k in meta["keys"]}
+
+
+@pytest.mark.parametrize("name", ["act_observer_pt", "act_learnable_pt", "weight_pc_sym", "act_observer_pc", "act_fakequant_only"])
+def test_state_dict_interchanges_with_the_reference_module(oracle_cpu_backend, traces, name):
+    """Checkpoints interchange (reference observers.py:244-257): a state_dict() the REFERENCE module
+    produced mid-scenario (tests/golden/module_state_dicts.npz, dumped by make_module_traces.py) loads into this module after
+    its creating call, and the scenario then continues exactly as the reference's own trace; this module's state_dict() at
+    the same point has the reference's keys, shapes, dtypes and values."""
+    from torchlsq.quantized import LSQFakeQuantizer
+    drv = _load_driver()
+    t = traces["traces"][name]
+    meta, ref_state = _reference_state(traces, name)
+    k = meta["after_call"]
+    # (1) the reference checkpoint drives this module
+    calls, final = drv.drive(LSQFakeQuantizer, t["scenario"], resume=(k, ref_state))
+    resumed = {c["call"]: c for c in calls}
+    assert sorted(resumed) == [0] + list(range(k + 1, t["scenario"]["calls"]))
+    for want in t["calls"][k + 1:]:
+        got = resumed[want["call"]]
+        tag = "%s resumed, call %d" % (name, want["call"])
+        for key in ("y_is_x", "y_sha", "dx_sha", "scale_requires_grad", "shift_requires_grad", "current_batch",
+                    "observer_enabled", "fake_quant_enabled", "learning_enabled", "initialized"):
+            assert got.get(key) == want.get(key), "%s: %s got %r want %r" % (tag, key, got.get(key), want.get(key))
+        assert got["scale"] == want["scale"] and got["shift"] == want["shift"], tag + " parameters"
+        _close(got["scale_grad"], want["scale_grad"], tag + " scale.grad")
+    assert final["qparams"] == t["final"]["qparams"] and final["state_dict_keys"] == t["final"]["state_dict_keys"]
+    # (2) this module's own checkpoint at the same point is the reference's
+    _, _, own = drv.drive(LSQFakeQuantizer, t["scenario"], dump_state_after=k)
+    assert list(own.keys()) == meta["keys"]
+    for key in meta["keys"]:
+        assert str(own[key].dtype) == meta["dtypes"][key] and list(own[key].shape) == meta["shapes"][key], (name, key)
+        assert own[key].tobytes() == ref_state[key].tobytes(), "%s: state_dict()[%r] differs from the reference's" % (name, key)
+
+
 def test_apply_helpers():
     import torchlsq.quantized as TQ
     from torch.ao.quantization import FakeQuantize

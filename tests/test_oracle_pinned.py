@@ -75,7 +75,7 @@ def test_empty_tensor_contract(small_cases):
     assert e["bwd_scale_passthrough"] == 0.5 and e["bwd_shift_passthrough"] == 0.25
 
 
-@pytest.mark.parametrize("name", ["cfg1", "cfg1_absgrad", "cfg3", "cfg3_absgrad"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg1_absgrad", "cfg3", "cfg3_absgrad", "cfg3_dspos"])
 def test_oracle_matches_reference_config_digests(config_digests, name):
     import torch
     from torchlsq import synth

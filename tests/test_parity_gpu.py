@@ -108,7 +108,29 @@ def _sha_t(t):
     return sha(t.cpu().numpy())
 
 
-@pytest.mark.parametrize("name", ["cfg1", "cfg1_absgrad", "cfg3", "cfg3_absgrad", "cfg5_fp32", "cfg2", "cfg2_absgrad", "cfg4"])
+# Where the sum has no cancellation, "within 1e-6 relative of the reference" is asserted as plain rtol = 1e-6:
+#   d_scale: |grad| inputs of the per-tensor quint8 configs (zero point 0: the low border contributes nothing) and the
+#            "dspos" inputs (|grad| x the sign of each element's d_scale factor, synth.ds_term_sign) of the per-channel ones --
+#            with |grad| alone the two borders of a signed range still cancel (sum|terms| / |sum| up to 1e4 per channel, and
+#            the reference's own fp32 at::sum is 6e-5 relative away from the exact sum there: profiles/r03_reduction_margin.txt);
+#   d_shift: every |grad| input (its terms are the gradients of the saturated elements).
+_STRICT_DS = ("cfg1_absgrad", "cfg2_absgrad", "cfg3_dspos", "cfg5_dspos", "cfg5_bf16_dspos")
+_STRICT_DB = ("cfg1_absgrad", "cfg2_absgrad", "cfg5_absgrad", "cfg5_bf16_absgrad")
+
+
+def _assert_reductions(name, d, scale, shift):
+    ds = scale.grad.cpu().numpy()
+    db = shift.grad.cpu().numpy() if shift.grad is not None else np.zeros(len(d["db"]))
+    assert_reduction_close(ds, d["ds"], d["oracle_abs_ds"], name + " ds")
+    assert_reduction_close(db, d["db"], d["oracle_abs_db"], name + " db")
+    if name in _STRICT_DS:
+        np.testing.assert_allclose(ds.astype(np.float64), np.array(d["ds"]), rtol=TOL, atol=0, err_msg=name + " ds, plain rtol")
+    if name in _STRICT_DB:
+        np.testing.assert_allclose(db.astype(np.float64), np.array(d["db"]), rtol=TOL, atol=0, err_msg=name + " db, plain rtol")
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg1_absgrad", "cfg3", "cfg3_absgrad", "cfg3_dspos", "cfg5_fp32", "cfg5_absgrad",
+                                  "cfg5_dspos", "cfg2", "cfg2_absgrad", "cfg4"])
 def test_baseline_configs_match_reference_digests(dev, config_digests, name):
     """BASELINE.json shapes at FULL size against digests of the reference CPU csrc's outputs."""
     d = config_digests[name]
@@ -117,24 +139,21 @@ def test_baseline_configs_match_reference_digests(dev, config_digests, name):
     assert _sha_t(g) == d["inputs_sha256"]["g"]
     assert _sha_t(y) == d["y_sha256"], name + ": y differs from the reference"
     assert _sha_t(x.grad) == d["dx_sha256"], name + ": dx differs from the reference"
-    assert_reduction_close(scale.grad.cpu().numpy(), d["ds"], d["oracle_abs_ds"], name + " ds")
-    sg = shift.grad.cpu().numpy() if shift.grad is not None else np.zeros(len(d["db"]))
-    assert_reduction_close(sg, d["db"], d["oracle_abs_db"], name + " db")
-    if name in ("cfg1_absgrad", "cfg2_absgrad"):  # border terms dominate, no cancellation: plain 1e-6 relative
-        np.testing.assert_allclose(scale.grad.cpu().numpy().astype(np.float64), np.array(d["ds"]), rtol=TOL, atol=0)
+    _assert_reductions(name, d, scale, shift)
 
 
-def test_bf16_io_config5(dev, config_digests):
+@pytest.mark.parametrize("name", ["cfg5_bf16", "cfg5_bf16_absgrad", "cfg5_bf16_dspos"])
+def test_bf16_io_config5(dev, config_digests, name):
     """BASELINE config 5: bf16 in/out, fp32 math.  Definition: reference fp32 CPU csrc on
     the upcast input, y/dx rounded to bf16 (RNE); ds/db stay fp32."""
-    d = config_digests["cfg5_bf16"]
+    d = config_digests[name]
     x, g, scale, shift, y = _run_config(dev, d, dtype=torch.bfloat16)
     assert y.dtype == torch.bfloat16 and x.grad.dtype == torch.bfloat16 and scale.grad.dtype == torch.float32
     assert _sha_t(x.float()) == d["inputs_sha256"]["x"]
+    assert _sha_t(g.float()) == d["inputs_sha256"]["g"]
     assert _sha_t(y) == d["y_bf16_sha256"]
     assert _sha_t(x.grad) == d["dx_bf16_sha256"]
-    assert_reduction_close(scale.grad.cpu().numpy(), d["ds"], d["oracle_abs_ds"], "cfg5 bf16 ds")
-    assert_reduction_close(shift.grad.cpu().numpy(), d["db"], d["oracle_abs_db"], "cfg5 bf16 db")
+    _assert_reductions(name, d, scale, shift)
 
 
 @pytest.mark.parametrize("name", ["cfg1", "cfg3", "cfg5_fp32", "cfg2"])
