@@ -263,6 +263,11 @@ def run_rank(a):
         else:
             dist.init_process_group(backend=a.backend)
 
+    if a.variant_fwd or a.variant_bwd:      # launch variants: tools build of the library (tools/lsq_tools.py), ctypes host layer
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import lsq_tools
+        lsq_tools.activate()
+        a.host_binding = "ctypes"
     if a.host_binding == "native":
         extension.set_host_binding("native")
     elif a.host_binding == "ctypes":
@@ -377,6 +382,27 @@ def run_rank(a):
         drain()
         torch.cuda.synchronize()
 
+        # N > 1: rank 0's shard step ALONE (same kernels, the global element count in the scaler, no collective) while the
+        # other ranks wait at a barrier -- the numerator of `per_gpu_efficiency`
+        solo_ms = None
+        if world > 1:
+            def bwd_local():
+                if per_channel:
+                    return ops.lsq_backward_per_channel_wide(gs[bset()], xs[bset()], scale, shift, axis, *tail, n_global)
+                return ops.lsq_backward_per_tensor_wide(gs[bset()], xs[bset()], scale, shift, *tail, n_global)
+            dist.barrier()
+            torch.cuda.synchronize()
+            if rank == 0:
+                ts = time.perf_counter()
+                for i in range(steps):
+                    cur[0] = i % n_sets
+                    y = fwd()
+                    r = bwd_local()
+                torch.cuda.synchronize()
+                solo_ms = (time.perf_counter() - ts) / steps * 1e3
+            dist.barrier()
+            torch.cuda.synchronize()
+
         # HIP events bracket the forward and the backward op on every `stride`-th step of the timed region (an
         # event record drains the queue, so bracketing every op of every step would itself cost a few % of a
         # 0.7 ms step); at least 10 steps are sampled.  (Under --graph the ops are nodes of one graph launch, so the
@@ -429,7 +455,7 @@ def run_rank(a):
         return dict(workload=workload, c=c, dtype_name=dtype_name, esz=esz, per_channel=per_channel, shape=shape, axis=axis,
                     scaling=scaling, n_local=n_local, n_global=n_global, n_sets=n_sets, set_bytes=set_bytes, steps=steps,
                     warmup=warmup, elapsed_max=elapsed_max, fwd_ms=fwd_ms, bwd_ms=bwd_ms, fwd_avg=fwd_avg, bwd_avg=bwd_avg,
-                    xs=xs, gs=gs, x=x)
+                    xs=xs, gs=gs, x=x, solo_ms=solo_ms)
 
     m = measure(a.workload, a.steps, a.warmup, a.graph, a.buffers)
     c, dtype_name, esz, per_channel, shape, axis = m["c"], m["dtype_name"], m["esz"], m["per_channel"], m["shape"], m["axis"]
@@ -509,6 +535,11 @@ def run_rank(a):
                          "step_reads_only_achieved": round(step_gbs * 0.6, 1),
                          "step_reads_only_frac": round(step_gbs * 0.6 / HBM_PEAK_GBS, 4)},
         }
+        if world > 1:
+            # rank 0's shard step alone / the same step inside the N-rank job (barrier-bracketed, max over ranks): what the
+            # collective and the co-running ranks cost one GPU.  1.0 = none.
+            line["per_gpu_efficiency"] = round(m["solo_ms"] / (elapsed_max / a.steps * 1e3), 4)
+            line["rank0_shard_alone_ms_per_step"] = round(m["solo_ms"], 5)
         if world == 1 and not a.no_yardstick:
             # Context for the roofline fraction, measured live on THIS box after the timed region: the framework's /
             # vendor's own kernels on the same two traffic shapes (ATen's vectorised add = 2 reads : 1 write like the
@@ -567,6 +598,27 @@ def run_rank(a):
                     sec.append({"workload": w, "error": repr(e)})
             line["secondary"] = sec
             line["secondary_wall_s"] = round(time.perf_counter() - t_sec, 2)
+    strong = None
+    if world > 1 and a.workload == "cfg2" and not a.no_secondary and 1024 % world == 0:
+        # BASELINE config 4 next to the weak-scaled headline: [1024,1024,14,14] split over the ranks (STRONG scaling), the same
+        # sharded step (every rank takes part: collectives inside)
+        del xs, gs, x, m
+        torch.cuda.empty_cache()
+        m4 = measure("cfg4", a.steps, a.warmup)
+        if rank == 0:
+            t4 = m4["elapsed_max"] / m4["steps"]
+            strong = {"workload": "cfg4: per-tensor quint8 float32 %s per GPU (global [1024,1024,14,14]), batch-sharded, "
+                                  "1 RCCL all-reduce of fp64 [ds,db] per step" % m4["shape"],
+                      "scaling": "strong", "value": round(m4["n_global"] / t4 / 1e9, 3), "unit": "GElem/s", "n_gpus": world,
+                      "global_elements": m4["n_global"], "elements_per_gpu": m4["n_local"], "steps": m4["steps"],
+                      "ms_per_step": round(t4 * 1e3, 5), "fwd_ms": round(m4["fwd_avg"], 5), "bwd_ms": round(m4["bwd_avg"], 5),
+                      "step_frac_per_gpu": round(20.0 * m4["n_local"] / ((m4["fwd_avg"] + m4["bwd_avg"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "rank0_shard_alone_ms_per_step": round(m4["solo_ms"], 5),
+                      "per_gpu_efficiency": round(m4["solo_ms"] / (t4 * 1e3), 4), "input_buffer_sets": m4["n_sets"]}
+        del m4
+    if rank == 0:
+        if strong is not None:
+            line["strong_scaled"] = strong
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -24,6 +24,10 @@ extern "C" {
 
 int lsq_cpu_abi_version(void);
 const char* lsq_cpu_last_error(void);
+/* Threads the parallel loops of the CALLING thread's later calls may use (<= 0: OpenMP's default).  The Python layer
+ * passes torch.get_num_threads() before every call, so the kernels follow torch.set_num_threads / a worker's pinning
+ * instead of libgomp's own default (every core).  The result bits do not depend on it (fp64 block sums, block order). */
+void lsq_cpu_set_num_threads(int n);
 
 /* lsq_forward_per_tensor_impl, lsq_cpu.cpp:15-53 */
 int lsq_cpu_forward_per_tensor(int dtype, const void* x, void* y, int64_t n, const void* scale, const void* shift,

@@ -16,7 +16,9 @@
  *    returns without synchronising -- scale/shift are read on the device, never on the host
  *    (the reference's `scale[0].item()` host syncs, lsq_cuda.cu:52-53,120-121, are gone);
  *  - re-entrant, no mutable global state: forward (caller thread) and backward (autograd engine
- *    thread) may run concurrently;
+ *    thread) may run concurrently.  The library keeps only fill-once lookup tables (device
+ *    properties, kernel register counts, per-thread workspace sizes per shape) and exports nothing
+ *    but the symbols declared here -- no tuning or debug entry point (tests/test_abi.py);
  *  - functions return 0 on success, a negative LSQ_E* code for rejected arguments, or a positive
  *    hipError_t value; they never throw.  lsq_hip_last_error() describes the last failure of the
  *    calling thread.
@@ -90,7 +92,12 @@ typedef struct lsq_fwd_extras {
  * bit-reproducible -- and stores d_scale / d_shift itself; without one (extras or ticket NULL) a second, tiny launch
  * does that (2-4 us on a small tensor: half of the backward of a BASELINE-config-1-sized activation).
  * Contract: all zero before its first use; every launch leaves it all zero again (the counters wrap), so it is reused
- * as is; launches that may run CONCURRENTLY (different streams) must not share a ticket -- keep one per stream. */
+ * as is; launches that may run CONCURRENTLY (different streams, or a captured graph replayed next to eager work) must not
+ * share a ticket -- keep one per stream and give captured launches none.
+ * Honoured by lsq_hip_backward_per_tensor only.  lsq_hip_backward_per_channel accepts the argument and IGNORES it (it always
+ * takes the two-launch route -- or a single launch where one workgroup owns a whole channel, e.g. conv / linear weights):
+ * measured on MI355X the folded finalize is not faster than the finalize launch, so the window and
+ * segment kernels never got one. */
 #define LSQ_TICKET_BYTES 4096
 typedef struct lsq_bwd_extras {
     void* ticket;

@@ -12,6 +12,7 @@
 // Not a fallback of the GPU path and not the test oracle (oracle/ is never linked or loaded by the product).
 #include <algorithm>
 #include <cmath>
+#include <omp.h>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -24,6 +25,12 @@
 namespace {
 
 thread_local char g_error[256] = "";
+
+// Threads of the parallel loops: what the caller's framework allows this thread (lsq_cpu_set_num_threads: the Python
+// layer passes torch.get_num_threads() with every call), not whatever libgomp's own default is -- a DataLoader worker or a
+// process pinned to one torch thread must not fan out over every core.  0 = never set: OpenMP's default.
+thread_local int g_threads = 0;
+inline int loop_threads() { return g_threads > 0 ? g_threads : omp_get_max_threads(); }
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -109,7 +116,7 @@ int forward_pt(const void* xv, void* yv, int64_t n, const void* scale, const voi
     auto* y = static_cast<typename IO::elem*>(yv);
     const Quant<T> q = make_quant<T>(sanitize_pt<T>(static_cast<const T*>(scale)[0]), static_cast<const T*>(shift)[0], p);
     const bool init = p.init_mode != 0;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(loop_threads())
     for (int64_t b0 = 0; b0 < n; b0 += kBlock) {
         const int64_t b1 = std::min(n, b0 + kBlock);
         for (int64_t i = b0; i < b1; ++i) IO::store(y, i, fwd_elem<T>(IO::load(x, i), q, init));
@@ -128,7 +135,7 @@ int backward_pt(const void* gv, const void* xv, void* dxv, void* dsv, void* dbv,
     const T gs = grad_scaler<T>(p, n, 0);
     const int64_t n_blocks = (n + kBlock - 1) / kBlock;
     std::vector<double> part(static_cast<size_t>(2 * n_blocks), 0.0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(loop_threads())
     for (int64_t b = 0; b < n_blocks; ++b) {
         const int64_t b0 = b * kBlock, b1 = std::min(n, b0 + kBlock);
         double as = 0.0, ab = 0.0;
@@ -162,7 +169,7 @@ int forward_pc(const void* xv, void* yv, int64_t outer, int64_t C, int64_t inner
     const std::vector<Quant<T>> tab = channel_table<T>(scale, shift, C, p);
     const bool init = p.init_mode != 0;
     const int64_t rows = outer * C;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(loop_threads())
     for (int64_t r = 0; r < rows; ++r) {
         const Quant<T>& q = tab[r % C];
         const int64_t base = r * inner;
@@ -185,7 +192,7 @@ int backward_pc(const void* gv, const void* xv, void* dxv, void* dsv, void* dbv,
     const int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(outer, 256));
     std::vector<double> part(static_cast<size_t>(2 * chunks * C), 0.0);
     const int64_t units = chunks * C;      // (slab, channel) pairs: independent, any thread may take any of them
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(loop_threads())
     for (int64_t u = 0; u < units; ++u) {
         const int64_t k = u / C, c = u % C;
         const int64_t o0 = k * outer / chunks, o1 = (k + 1) * outer / chunks;
@@ -232,6 +239,7 @@ int check(int dtype, const lsq_params* p) {
 extern "C" {
 
 int lsq_cpu_abi_version(void) { return LSQ_HIP_ABI_VERSION; }
+void lsq_cpu_set_num_threads(int n) { g_threads = n > 0 ? n : 0; }
 const char* lsq_cpu_last_error(void) { return g_error; }
 
 int lsq_cpu_forward_per_tensor(int dtype, const void* x, void* y, int64_t n, const void* scale, const void* shift,

@@ -1,15 +1,20 @@
 // lsq_capi.hip -- the extern "C" boundary declared in include/lsq_hip.h.
 //
 // Thin by design: argument validation, dtype dispatch, error bookkeeping.  No tensor memory is
-// allocated or freed here and no state outlives a call (the only statics are an immutable device
-// table and a thread-local error string).
+// allocated or freed here and no state outlives a call (the only statics are immutable-once-filled lookup tables -- device
+// properties, kernel register counts, workspace sizes per shape -- and a thread-local error string).
+// The production library exports exactly the symbols of include/lsq_hip.h.  The `_ex` twins (a trailing launch-variant
+// code) and the lsq_hip_debug_* knobs of lsq_internal.h exist only in the tools build (-DLSQ_TOOLS, `make tools`).
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <unordered_map>
 
 #include <hip/hip_version.h>
 
+#ifdef LSQ_TOOLS
 #include "lsq_internal.h"
+#endif
 #include "lsq_kernels.hpp"
 
 namespace {
@@ -59,6 +64,13 @@ int check_levels(const lsq_params* p, const lsq_fwd_extras* ex) {
         default: { using IO = lsq::io_f16; CALL; } break;        \
     }
 
+// the four ops with a launch-variant code: exported (extern "C") by the tools build only, file-local otherwise
+#ifdef LSQ_TOOLS
+#define LSQ_EX_LINKAGE
+#else
+#define LSQ_EX_LINKAGE static
+#endif
+
 extern "C" {
 
 int lsq_hip_abi_version(void) { return LSQ_HIP_ABI_VERSION; }
@@ -87,27 +99,39 @@ size_t lsq_hip_backward_per_tensor_workspace(int dtype, int64_t n) {
 
 size_t lsq_hip_backward_per_channel_workspace(int dtype, int64_t outer, int64_t channels, int64_t inner) {
     if (!dtype_ok(dtype) || outer <= 0 || channels <= 0 || inner <= 0) return 256;
-    // The size is the maximum over every launch geometry the tuning range allows (a few dozen candidate geometries).
-    // Callers ask once per backward with the same few shapes: remember the last answers of this thread.
-    // (The answer depends on the CU count of the current device, so the device ordinal is part of the key.)
-    struct Memo { int dtype, device, knob; int64_t outer, channels, inner; size_t bytes; };
-    constexpr int kMemo = 8;
-    thread_local Memo memo[kMemo] = {};
-    thread_local int next = 0;
+    // The size is what the launch policy will ask for (lsq::bwd_pc_workspace_bytes: the policy run as a plan); callers ask
+    // once per backward with the same few shapes, so the answers of this thread are kept -- every distinct
+    // (device, dtype, shape) of a model, not just the last few.  (The answer depends on the CU count of the current device.)
+    struct Key {
+        int dtype, device, knob;
+        int64_t outer, channels, inner;
+        bool operator==(const Key& o) const {
+            return dtype == o.dtype && device == o.device && knob == o.knob && outer == o.outer && channels == o.channels && inner == o.inner;
+        }
+    };
+    struct Hash {
+        size_t operator()(const Key& k) const {
+            uint64_t h = 1469598103934665603ull;
+            for (uint64_t v : {static_cast<uint64_t>(k.dtype), static_cast<uint64_t>(k.device), static_cast<uint64_t>(k.knob),
+                               static_cast<uint64_t>(k.outer), static_cast<uint64_t>(k.channels), static_cast<uint64_t>(k.inner)})
+                h = (h ^ v) * 1099511628211ull;
+            return static_cast<size_t>(h);
+        }
+    };
+    thread_local std::unordered_map<Key, size_t, Hash> memo;
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) device = 0;
-    const int knob = lsq::get_ww_min_rows();      // (a tools-only geometry override: part of the key)
-    for (int i = 0; i < kMemo; ++i)
-        if (memo[i].bytes && memo[i].dtype == dtype && memo[i].device == device && memo[i].knob == knob && memo[i].outer == outer &&
-            memo[i].channels == channels && memo[i].inner == inner)
-            return memo[i].bytes;
-    const size_t bytes = lsq::bwd_pc_workspace_bytes(io_vec(dtype), outer, channels, inner);
-    memo[next] = Memo{dtype, device, knob, outer, channels, inner, bytes};
-    next = (next + 1) % kMemo;
+    const Key key{dtype, device, lsq::knob::geometry_key(), outer, channels, inner};
+    const auto hit = memo.find(key);
+    if (hit != memo.end()) return hit->second;
+    size_t bytes = 0;
+    LSQ_DISPATCH_IO(dtype, bytes = lsq::bwd_pc_workspace_bytes<IO>(outer, channels, inner));
+    if (memo.size() >= 65536) memo.clear();
+    memo.emplace(key, bytes);
     return bytes;
 }
 
-int lsq_hip_forward_per_tensor_ex(int dtype, const void* x, void* y, int64_t n, const void* scale, const void* shift,
+LSQ_EX_LINKAGE int lsq_hip_forward_per_tensor_ex(int dtype, const void* x, void* y, int64_t n, const void* scale, const void* shift,
                                   const lsq_params* p, const lsq_fwd_extras* extras, void* stream, int variant) {
     if (int rc = check_common(dtype, p)) return rc;
     if (n < 0) return fail(LSQ_EINVAL, "negative element count %lld", static_cast<long long>(n));
@@ -125,7 +149,7 @@ int lsq_hip_forward_per_tensor(int dtype, const void* x, void* y, int64_t n, con
     return lsq_hip_forward_per_tensor_ex(dtype, x, y, n, scale, shift, p, extras, stream, 0);
 }
 
-int lsq_hip_backward_per_tensor_ex(int dtype, const void* grad, const void* x, void* dx, void* ds, void* db,
+LSQ_EX_LINKAGE int lsq_hip_backward_per_tensor_ex(int dtype, const void* grad, const void* x, void* dx, void* ds, void* db,
                                    double* dsdb_wide, int64_t n, const void* scale, const void* shift,
                                    const lsq_params* p, const lsq_bwd_extras* extras, void* workspace,
                                    size_t workspace_bytes, void* stream, int variant) {
@@ -160,7 +184,7 @@ static int check_ocl(int64_t outer, int64_t channels, int64_t inner) {
     return LSQ_OK;
 }
 
-int lsq_hip_forward_per_channel_ex(int dtype, const void* x, void* y, int64_t outer, int64_t channels, int64_t inner,
+LSQ_EX_LINKAGE int lsq_hip_forward_per_channel_ex(int dtype, const void* x, void* y, int64_t outer, int64_t channels, int64_t inner,
                                    const void* scale, const void* shift, const lsq_params* p,
                                    const lsq_fwd_extras* extras, void* stream, int variant) {
     if (int rc = check_common(dtype, p)) return rc;
@@ -180,7 +204,7 @@ int lsq_hip_forward_per_channel(int dtype, const void* x, void* y, int64_t outer
     return lsq_hip_forward_per_channel_ex(dtype, x, y, outer, channels, inner, scale, shift, p, extras, stream, 0);
 }
 
-int lsq_hip_backward_per_channel_ex(int dtype, const void* grad, const void* x, void* dx, void* ds, void* db,
+LSQ_EX_LINKAGE int lsq_hip_backward_per_channel_ex(int dtype, const void* grad, const void* x, void* dx, void* ds, void* db,
                                     double* dsdb_wide, int64_t outer, int64_t channels, int64_t inner,
                                     const void* scale, const void* shift, const lsq_params* p,
                                     const lsq_bwd_extras* extras, void* workspace, size_t workspace_bytes, void* stream,
@@ -192,11 +216,10 @@ int lsq_hip_backward_per_channel_ex(int dtype, const void* grad, const void* x, 
     if (!grad || !x || !dx || !ds || !db || !scale || !shift) return fail(LSQ_EINVAL, "backward_per_channel: NULL buffer");
     if (!workspace) return fail(LSQ_EWORKSPACE, "backward_per_channel: NULL workspace");
     if (reinterpret_cast<uintptr_t>(workspace) & 15u) return fail(LSQ_EWORKSPACE, "workspace must be 16-byte aligned");
-    uint32_t* ticket = extras ? static_cast<uint32_t*>(extras->ticket) : nullptr;
-    if (reinterpret_cast<uintptr_t>(ticket) & 3u) return fail(LSQ_EINVAL, "ticket must be 4-byte aligned");
+    (void)extras;      // lsq_bwd_extras.ticket: accepted and ignored by the per-channel backward (include/lsq_hip.h)
     hipError_t e = hipSuccess;
     LSQ_DISPATCH_IO(dtype, e = lsq::backward_per_channel<IO>(grad, x, dx, ds, db, dsdb_wide, outer, channels, inner,
-                                                              scale, shift, *p, workspace, workspace_bytes, ticket, variant,
+                                                              scale, shift, *p, workspace, workspace_bytes, nullptr, variant,
                                                               static_cast<hipStream_t>(stream)));
     if (e == hipErrorInvalidValue)
         return fail(LSQ_EWORKSPACE, "backward_per_channel: workspace of %zu bytes is too small (ask "
@@ -222,19 +245,21 @@ int lsq_hip_backward_from_mask(int dtype, const void* grad, const void* mask, vo
     return hip_status(e, "lsq_hip_backward_from_mask");
 }
 
-void lsq_hip_debug_set_observe_wg_per_cu(int v) { lsq::set_observe_wg_per_cu(v); }
+#ifdef LSQ_TOOLS
+void lsq_hip_debug_set_observe_wg_per_cu(int v) { lsq::knob::set(lsq::knob::kObserveWgPerCu, v); }
+void lsq_hip_debug_force_ring(int v) { lsq::knob::set(lsq::knob::kForceRing, v < 0 || v > 2 ? 0 : v); }
+void lsq_hip_debug_set_ww_min_rows(int v) { lsq::knob::set(lsq::knob::kWwMinRows, v); }
+void lsq_hip_debug_set_ww_split64(int v) { lsq::knob::set(lsq::knob::kWwSplit64, v); }
+void lsq_hip_debug_set_ww_big(int v) { lsq::knob::set(lsq::knob::kWwBig, v); }
+void lsq_hip_debug_set_ring_nt(int v) { lsq::knob::set(lsq::knob::kRingNt, v); }
+void lsq_hip_debug_set_fin_ch(int v) { lsq::knob::set(lsq::knob::kFinCh, v); }
 
-void lsq_hip_debug_force_ring(int v) { lsq::forced_dma().store(v < 0 || v > 2 ? 0 : v); }
-void lsq_hip_debug_set_ww_min_rows(int v) { lsq::set_ww_min_rows(v); }
-void lsq_hip_debug_set_ww_split64(int v) { lsq::set_ww_split64(v); }
-void lsq_hip_debug_set_ww_big(int v) { lsq::set_ww_big(v); }
-void lsq_hip_debug_set_ring_nt(int v) { lsq::set_ring_nt(v); }
-void lsq_hip_debug_set_fin_ch(int v) { lsq::set_fin_ch(v); }
-
-void lsq_hip_debug_last_launch(int* out4) {
+void lsq_hip_debug_last_launch(int* out8) {
     const lsq::LaunchNote& n = lsq::last_launch_note();
-    out4[0] = n.grid_x; out4[1] = n.grid_y; out4[2] = n.resident_per_cu; out4[3] = n.vgprs_hint;
+    out8[0] = n.grid_x; out8[1] = n.grid_y; out8[2] = n.resident_per_cu; out8[3] = n.vgprs_hint;
+    out8[4] = n.kind; out8[5] = n.dma_depth; out8[6] = n.block; out8[7] = n.ring_nt;
 }
+#endif
 
 size_t lsq_hip_minmax_workspace(int dtype, int64_t outer, int64_t channels, int64_t inner) {
     if (!dtype_ok(dtype) || outer <= 0 || channels <= 0 || inner <= 0) return 256;

@@ -1,8 +1,10 @@
-/* lsq_internal.h -- NOT part of the drop-in boundary (include/lsq_hip.h is).
+/* lsq_internal.h -- NOT part of the drop-in boundary (include/lsq_hip.h is), and NOT in the production library:
+ * these symbols exist only in the tools build, tools/_tune/liblsq_hip_tools.so (`make tools`, -DLSQ_TOOLS), which the A/B
+ * scripts under tools/ and the branch-pinning tests load through tools/lsq_tools.py.
  * `_ex` twins of the four ops with one extra argument, a launch-variant code
- * (unroll | nt << 8 | blocks_per_cu << 16; 0 = the tuned default), used only by the tuning
- * sweep in tools/tune_stream.py.  A build without -DLSQ_TUNING ignores everything but
- * blocks_per_cu. */
+ * (unroll | nt << 8 | pipelined << 10 | loop form << 12 | blocks_per_cu << 16; 0 = the tuned default); without
+ * -DLSQ_TUNING only the loop form and blocks_per_cu are honoured.
+ * lsq_hip_debug_*: process-wide overrides of the launch policy (lsq_kernels.hpp `knob`). */
 #ifndef LSQ_INTERNAL_H_
 #define LSQ_INTERNAL_H_
 #include "../../include/lsq_hip.h"
@@ -23,9 +25,10 @@ int lsq_hip_backward_per_channel_ex(int dtype, const void* grad, const void* x, 
                                     const void* scale, const void* shift, const lsq_params* p,
                                     const lsq_bwd_extras* extras, void* workspace, size_t workspace_bytes, void* stream,
                                     int variant);
-/* tools only: [grid x, grid y, resident workgroups per CU used for the geometry, numRegs] of this thread's last
- * window-mode backward launch */
-void lsq_hip_debug_last_launch(int* out4);
+/* [grid x, grid y, resident workgroups per CU used for the geometry, numRegs, kind (1 = 256-lane windows, 2 = row-group
+ * windows, 3 = segment mode), LDS-DMA ring depth (0 = register loops), workgroup size, ring copies with the streaming hint]
+ * of this thread's last per-channel backward launch */
+void lsq_hip_debug_last_launch(int* out8);
 /* tests / tools only: loop form of the window-mode per-channel kernels for calls that do not choose one (variant bits 12-13
  * zero): 0 = the built-in policy, 1 = register loops, 2 = LDS-DMA ring whatever the shape */
 void lsq_hip_debug_force_ring(int v);

@@ -7,7 +7,6 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
-#include <mutex>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -51,11 +50,27 @@ constexpr int kDefaultPcBwdNarrowVariant = encode_variant(1, true, true, 4) | (1
 constexpr int kDefaultPcSegVariant = encode_variant(4, true, true, 16);
 constexpr int kDefaultPcSegNarrowVariant = encode_variant(1, true, true, 16);   // bf16 / fp16 storage
 
-// tests / tools only (lsq_hip_debug_force_ring): the loop form of the window-mode kernels when the caller leaves it open
-inline std::atomic<int>& forced_dma() {
-    static std::atomic<int> v{0};
-    return v;
+// ---- launch-policy overrides: tools / tests ONLY -------------------------------------------------------------------
+// The tools build of this library (tools/_tune/liblsq_hip_tools.so: `make tools`, -DLSQ_TOOLS) keeps a handful of
+// process-wide integers that the A/B scripts under tools/ and the branch-pinning tests set through the lsq_hip_debug_*
+// entry points of lsq_internal.h.  The production library (liblsq_hip.so) has none of this: every knob::get() below is the
+// constant 0 ("no override"), the policy code that consults it folds away, no lsq_hip_debug_* symbol is exported, and the
+// library keeps no mutable global state (include/lsq_hip.h).
+namespace knob {
+enum Id { kForceRing, kWwMinRows, kWwSplit64, kWwBig, kRingNt, kFinCh, kObserveWgPerCu, kCount };
+#ifdef LSQ_TOOLS
+inline std::atomic<int>& slot(Id id) {
+    static std::atomic<int> v[kCount];
+    return v[id];
 }
+inline int get(Id id) { return slot(id).load(std::memory_order_relaxed); }
+inline void set(Id id, int v) { slot(id).store(v); }
+#else
+constexpr int get(Id) { return 0; }
+#endif
+// all geometry knobs as one key (the workspace memo of lsq_capi.hip)
+inline int geometry_key() { return get(kWwMinRows) | (get(kWwSplit64) << 16) | (get(kWwBig) << 20) | (get(kRingNt) << 24); }
+}  // namespace knob
 
 inline Variant decode_variant(int code, int dflt) {
     if (code == 0) code = dflt;
@@ -66,7 +81,7 @@ inline Variant decode_variant(int code, int dflt) {
     v.blocks_per_cu = (code >> 16) & 0xff;
     v.chunked = ((code >> 10) & 1) != 0;
     v.dma = (code >> 12) & 3;
-    if (v.dma == 0) v.dma = forced_dma().load(std::memory_order_relaxed);
+    if (v.dma == 0) v.dma = knob::get(knob::kForceRing);
     if (v.unroll != 1 && v.unroll != 2 && v.unroll != 4 && v.unroll != 8) v.unroll = 4;
     if (v.blocks_per_cu < 1) v.blocks_per_cu = 1;
     if (v.blocks_per_cu > kMaxBlocksPerCU) v.blocks_per_cu = kMaxBlocksPerCU;
@@ -128,22 +143,44 @@ inline const DeviceInfo& device_info() {
 // occupancy API is one workgroup per CU too high for kernels with 81-112 SGPRs on this part, MI355X_MICROARCH.md, so the
 // count is derived from the register number instead.)  Immutable per kernel: cached after the first query.
 inline int resident_blocks_per_cu(const void* kernel, size_t lds_bytes = 0);
-inline int resident_blocks_by_registers(const void* kernel) {
-    static std::mutex mu;
-    static std::vector<std::pair<const void*, int>> cache;
-    std::lock_guard<std::mutex> lock(mu);
-    for (const auto& e : cache)
-        if (e.first == kernel) return e.second;
-    hipFuncAttributes attr;
-    int waves = 0;
-    if (hipFuncGetAttributes(&attr, kernel) == hipSuccess && attr.numRegs > 0) {
-        const int regs = (attr.numRegs + 7) & ~7;
-        waves = std::max(1, std::min(8, 512 / regs));
-    } else {
-        (void)hipGetLastError();
+// (a launch consults this once: a lock-free open-addressing table keyed by the kernel's address, filled at a kernel's
+// first launch -- no mutex, no runtime query on the steady-state path)
+inline int registers_of(const void* kernel) {
+    constexpr unsigned kSlots = 1024;      // far more than the kernels this library instantiates
+    static std::atomic<const void*> keys[kSlots];
+    static std::atomic<int> regs[kSlots];
+    unsigned h = static_cast<unsigned>((reinterpret_cast<uintptr_t>(kernel) >> 4) * 2654435761u) % kSlots;
+    for (unsigned probe = 0; probe < kSlots; ++probe, h = (h + 1) % kSlots) {
+        const void* k = keys[h].load(std::memory_order_acquire);
+        if (k == kernel) {
+            const int r = regs[h].load(std::memory_order_acquire);
+            if (r != 0) return r > 0 ? r : 0;
+            break;                          // another thread is filling the slot: ask the runtime ourselves
+        }
+        if (k == nullptr) {
+            hipFuncAttributes attr;
+            int r = -1;
+            if (hipFuncGetAttributes(&attr, kernel) == hipSuccess && attr.numRegs > 0) r = attr.numRegs;
+            else (void)hipGetLastError();
+            const void* expected = nullptr;
+            if (keys[h].compare_exchange_strong(expected, kernel, std::memory_order_acq_rel)) {
+                regs[h].store(r, std::memory_order_release);
+                return r > 0 ? r : 0;
+            }
+            if (expected == kernel) return r > 0 ? r : 0;
+            continue;                       // the slot went to another kernel meanwhile: keep probing
+        }
     }
-    cache.emplace_back(kernel, waves);
-    return waves;
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, kernel) == hipSuccess && attr.numRegs > 0) return attr.numRegs;
+    (void)hipGetLastError();
+    return 0;
+}
+inline int resident_blocks_by_registers(const void* kernel) {
+    const int r = registers_of(kernel);
+    if (r <= 0) return 0;
+    const int regs = (r + 7) & ~7;
+    return std::max(1, std::min(8, 512 / regs));
 }
 
 // ... and the CU's 160 KiB of LDS allow (allocated in 1 KiB units here; the LDS-DMA rings take 32 KiB per workgroup)
@@ -153,14 +190,20 @@ inline int resident_blocks_per_cu(const void* kernel, size_t lds_bytes) {
     return n;
 }
 
-// what the last window-mode backward launch of this thread looked like (tools/ only: lsq_hip_debug_last_launch)
+#ifdef LSQ_TOOLS
+// what the last window-mode backward launch of this thread looked like (lsq_hip_debug_last_launch; tools build only)
 struct LaunchNote {
     int grid_x, grid_y, resident_per_cu, vgprs_hint;
+    int kind;        // 1 = 256-lane windows, 2 = row-group windows, 3 = segment mode
+    int dma_depth;   // 0 = register loops, else the LDS-DMA ring depth
+    int block;       // workgroup size
+    int ring_nt;
 };
 inline LaunchNote& last_launch_note() {
-    thread_local LaunchNote note = {0, 0, 0, 0};
+    thread_local LaunchNote note = {0, 0, 0, 0, 0, 0, 0, 0};
     return note;
 }
+#endif
 
 inline bool is_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -264,7 +307,8 @@ __device__ __forceinline__ double2 load_partial_agent(const double2* p) {
 
 // ---- entry points implemented in lsq_per_tensor.hip / lsq_per_channel.hip ------------------------
 size_t bwd_pt_workspace_bytes();
-size_t bwd_pc_workspace_bytes(int elem_bytes, int64_t outer, int64_t channels, int64_t inner);
+template <typename IO>
+size_t bwd_pc_workspace_bytes(int64_t outer, int64_t channels, int64_t inner);
 
 template <typename IO>
 hipError_t forward_per_tensor(const void* x, void* y, int64_t n, const void* scale, const void* shift,
@@ -281,19 +325,12 @@ template <typename IO>
 hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void* ds, void* db, double* wide,
                                 int64_t outer, int64_t channels, int64_t inner, const void* scale,
                                 const void* shift, const lsq_params& p, void* workspace, size_t workspace_bytes,
-                                uint32_t* ticket, int variant, hipStream_t stream);
+                                uint32_t* ticket, int variant, hipStream_t stream, size_t* plan_need = nullptr);
 
 template <typename IO>
 hipError_t backward_from_mask(const void* grad, const void* mask, void* dx, int64_t n, hipStream_t stream);
 
 // observer statistics (lsq_observe.hip)
-void set_observe_wg_per_cu(int v);
-void set_ww_min_rows(int v);
-int get_ww_min_rows();
-void set_ww_split64(int v);
-void set_ww_big(int v);
-void set_ring_nt(int v);
-void set_fin_ch(int v);
 size_t minmax_workspace_bytes(int io_vec, int elem_arith_bytes, int64_t outer, int64_t channels, int64_t inner);
 template <typename IO>
 hipError_t minmax_per_tensor(const void* x, int64_t n, void* out_min, void* out_max, void* workspace,

@@ -639,12 +639,9 @@ __global__ __launch_bounds__(kBlock) void moments_seg_finalize_kernel(const doub
 // host side
 // ------------------------------------------------------------------------------------------------
 constexpr int kObserveUnroll = 4;
-// workgroups per CU of the statistics kernels; tools/ may override it through the (internal, debug-only)
-// lsq_hip_debug_set_observe_wg_per_cu -- the only mutable global in the library.
-static std::atomic<int> g_observe_wg_per_cu{0};
-void set_observe_wg_per_cu(int v) { g_observe_wg_per_cu.store(v); }
+// workgroups per CU of the statistics kernels (the tools build can override it: knob::kObserveWgPerCu, 0 in production)
 static inline int observe_wg_per_cu(int dflt) {
-    const int v = g_observe_wg_per_cu.load();
+    const int v = knob::get(knob::kObserveWgPerCu);
     return v > 0 ? std::min(v, kMaxBlocksPerCU) : dflt;
 }
 constexpr int kObserveWgPerTensor = 8;

@@ -517,15 +517,21 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
                 // Steady state in blocks of DMA rows: the ring stage of a row is a compile-time constant (its LDS addresses
                 // are instruction offsets), the lane's row addresses advance by one add (every lane walks every row: no
                 // clamping), and -- PRE32 -- the first row of a block assigns the pre-sums, which are flushed un-cleared at
-                // its end.  Row i + u was requested DMA rows ago; the copies counted by the wait are those of the DMA - 1
-                // rows after it.
+                // its end.
+                // The wait is EXACT here.  Vector-memory operations retire in issue order and every row of this loop issues
+                // the same ones -- two copies (the refill of its stage), then its dx store -- so the operations younger than
+                // row i's two copies are: the copies of rows i+1 .. i+DMA-1 and the dx stores of rows i-DMA .. i-1 (row i's
+                // copies were issued as the refill of row i-DMA, before that row's store); in the first block the stores of
+                // rows 0 .. u-1 only.  (The generic loops below cannot know whether a wave stored, count the copies alone and
+                // so wait for one more row and two store acknowledgements than they need.)
                 static_assert(!PRE32 || DMA <= kPreRows, "a pre-sum group is at most kPreRows rows");
                 const int64_t step_e = walk.step * g.L;
                 int64_t e_cur = walk.row(0) * g.L + site.p0;          // i == 0 here
-                for (; i + 2 * DMA <= dma_n; i += DMA) {
+                auto block = [&](auto first_block) {
 #pragma unroll
                     for (int u = 0; u < DMA; ++u) {
-                        wait_vm<2 * (DMA - 1)>();
+                        if (decltype(first_block)::value) wait_vm_upto(2 * (DMA - 1) + u);
+                        else wait_vm<2 * (DMA - 1) + DMA>();
                         const unsigned char* stage = ring + u * kDmaStageBytes + lane * 16;
                         const V4 graw = *reinterpret_cast<const V4*>(stage);
                         const V4 xraw = *reinterpret_cast<const V4*>(stage + 64 * 16);
@@ -541,19 +547,27 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
                         e_cur += step_e;
                     }
                     flush_pre(std::false_type{});
-                }
+                    i += DMA;
+                };
+                static_assert(2 * (DMA - 1) + DMA <= 15, "wait_vm_upto covers counts up to 15");
+                if (i + 2 * DMA <= dma_n) block(std::true_type{});
+                while (i + 2 * DMA <= dma_n) block(std::false_type{});
                 if constexpr (PRE32) {
 #pragma unroll
                     for (int j = 0; j < kAcc / 2; ++j) { pre_s[j] = f2{0.0f, 0.0f}; pre_b[j] = f2{0.0f, 0.0f}; }
                 }
             }
+            // the rows the blocks left over (and every row of a wave with dead lanes or a ragged last tile): one at a time,
+            // ring stage and validity at run time.  `stores`: dx stores younger than row i's copies -- known only when every
+            // row of the wave stores (see above); otherwise they are left out of the count (the wait is then longer).
+            auto stores = [&](int64_t row) { return decltype(all_valid)::value ? static_cast<int>(row < DMA ? row : DMA) : 0; };
             for (; i + DMA < dma_n; ++i) {           // the ring is full, one refill per row
-                wait_vm<2 * (DMA - 1)>();
+                wait_vm_upto(2 * (DMA - 1) + stores(i));
                 consume(i, true, all_valid);
                 if (PRE32 && (i & (kPreRows - 1)) == kPreRows - 1) flush_pre(std::true_type{});
             }
             for (; i < dma_n; ++i) {                 // the last DMA rows: nothing left to request
-                wait_vm_upto(static_cast<int>(2 * (dma_n - 1 - i)));
+                wait_vm_upto(static_cast<int>(2 * (dma_n - 1 - i)) + stores(i));
                 consume(i, false, all_valid);
                 if (PRE32 && (i & (kPreRows - 1)) == kPreRows - 1) flush_pre(std::true_type{});
             }
@@ -710,11 +724,9 @@ constexpr int kFinCh = 32;   // channels per finalize workgroup when there are a
 // workgroups when the channel count allows it: with few channels (RGB inputs; 768 features x 512 row slabs) the
 // lanes of a workgroup share a channel's partials -- there can be thousands -- instead of 24 workgroups walking
 // them one lane per channel.
-static std::atomic<int> g_fin_ch_override{0};      // tools only (lsq_hip_debug_set_fin_ch)
-void set_fin_ch(int v) { g_fin_ch_override.store(v); }
 static inline int fin_channels(int64_t C) {
-    const int o = g_fin_ch_override.load(std::memory_order_relaxed);
-    if (o > 0) return o;
+    const int o = knob::get(knob::kFinCh);        // tools build only: a power of two <= kFinCh
+    if (o > 0) return o > kFinCh ? kFinCh : (o & (o - 1)) ? 1 : o;
     int ch = 1;
     while (ch < kFinCh && static_cast<int64_t>(ch) * 2 * 256 <= C) ch <<= 1;
     // ... but at least 8 channels (128 contiguous bytes of partials per split) where there are that many: better
@@ -1043,12 +1055,10 @@ __global__ __launch_bounds__(kBlock) void finalize_seg_kernel(const double2* __r
 template <typename IO>
 constexpr int kWindowBwdVec = IO::VEC;
 constexpr int kLastAxisBwdBlocksPerCU = 2;
-static std::atomic<int> g_ww_min_rows_override{0};          // tools only (lsq_hip_debug_set_ww_min_rows): 0 = kWwMinRows
-void set_ww_min_rows(int v) { g_ww_min_rows_override.store(v); }
-static std::atomic<int> g_ww_split64{0};                   // tools only: rows of 128 / 192 / 256 lanes as 64-lane windows
-void set_ww_split64(int v) { g_ww_split64.store(v); }
-static std::atomic<int> g_ring_nt{0};                      // tools only: streaming hint on the ring's copies, 0 = policy, 1 = on, 2 = off
-void set_ring_nt(int v) { g_ring_nt.store(v); }
+// (tools-build knobs consulted below, all 0 in the production library -- lsq_kernels.hpp `knob`: kWwMinRows = rows a
+// row-group-window workgroup walks at least, 0 = kWwMinRows<IO>; kWwSplit64 = rows of 128 / 192 / 256 lanes as 64-lane windows;
+// kRingNt = streaming hint on the ring's copies, 0 = policy, 1 = on, 2 = off; kWwBig = 768/1024-lane workgroups, 0 = policy,
+// 1 = always, 2 = never)
 // Policy: on for the BACKWARD of tensors of more than 32 MB -- the x a backward reads was saved by a forward long ago and
 // is not in the 256 MB Infinity Cache any more, whatever the gradient is, and nt copies still hit the lines a producer left
 // there.  256-lane windows, cold (profiles/r02_ring_nt_ab.txt): config 5 fp32 64.9 -> 59.8 us, bf16 (51 MB) 37.1 -> 34.3 us.
@@ -1056,14 +1066,11 @@ void set_ring_nt(int v) { g_ring_nt.store(v); }
 // 78 -> 68 us, [256,197,768] fp32 91 -> 80 us, [65536,1024] bf16 82 -> 76 us; never slower, cold included.  (An earlier A/B that
 // found the hint harmful for row groups and for the forward re-read one set of buffers: the hint kept them out of the cache.)
 static inline int ring_nt_for(int64_t tensor_bytes, bool backward, bool row_groups) {
-    const int k = g_ring_nt.load(std::memory_order_relaxed);
+    const int k = knob::get(knob::kRingNt);
     if (k != 0) return k == 1 ? 1 : 0;
     (void)row_groups;
     return backward && tensor_bytes > (int64_t{32} << 20) ? 1 : 0;
 }
-static std::atomic<int> g_ww_big{0};                       // tools only: 1024-lane workgroups, 0 = policy, 1 = always, 2 = never
-void set_ww_big(int v) { g_ww_big.store(v); }
-int get_ww_min_rows() { return g_ww_min_rows_override.load() | (g_ww_split64.load() << 16) | (g_ww_big.load() << 20) | (g_ring_nt.load() << 24); }   // (the geometry knobs, as one key)
 // (16-bit storage: 768 lanes -- its kernel needs ~140 registers, 1024 lanes would cap it at 128 and spill)
 template <int ELEM_BYTES>
 constexpr int kBigBlockOf = ELEM_BYTES < 4 ? 768 : 1024;
@@ -1081,7 +1088,10 @@ static inline int pick_cpl(int vec, int64_t inner) {
     if (vec == 1 || inner % vec == 0) return 1;
     return inner >= vec ? 2 : vec;
 }
-size_t bwd_pc_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64_t inner) {
+#ifdef LSQ_TOOLS
+// Tools build: a caller may force any launch variant or knob, so the size is the maximum over every geometry the tuning
+// range allows (tens of milliseconds of host time; lsq_capi.hip memoises it).
+static size_t bwd_pc_workspace_bytes_any(int io_vec, int64_t outer, int64_t channels, int64_t inner) {
     const DeviceInfo& dev = device_info();
     size_t need = 0;
     const int vecs[3] = {io_vec, 1, 4};   // full packets, single elements, half packets (16-bit window backward)
@@ -1092,7 +1102,7 @@ size_t bwd_pc_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64
                 need = std::max(need, static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2));
             }
             if (vi == 0 && inner == 1 && io_vec > 1 && channels % io_vec == 0) {
-                const int ovr = g_ww_min_rows_override.load(std::memory_order_relaxed);
+                const int ovr = knob::get(knob::kWwMinRows);
                 const int min_rows = ovr > 0 ? ovr : (io_vec > 4 ? 16 : (107 + (16 / io_vec) - 1) / (16 / io_vec));   // kWwMinRows of the storage type
                 for (int res = 0; res <= 8; ++res) {
                     for (int s64 = 0; s64 < 3; ++s64) {     // whole rows, 64-lane windows, 1024-lane workgroups
@@ -1111,6 +1121,35 @@ size_t bwd_pc_workspace_bytes(int io_vec, int64_t outer, int64_t channels, int64
     return need + 256;
 }
 
+
+#endif
+
+// Scratch bytes of the backward: exactly what backward_per_channel (the library's own launch policy) asks for -- the same
+// code run as a PLAN (BwdPcCall::plan_need: geometry and kernel choice, nothing launched) for the argument properties the
+// size does not take: symmetric or not, init mode or not, 16-byte-aligned buffers or not; eval mode needs none.  A few
+// microseconds of host time (eight plans).
+template <typename IO>
+size_t bwd_pc_workspace_bytes(int64_t outer, int64_t channels, int64_t inner) {
+    size_t need = 0;
+#ifdef LSQ_TOOLS
+    need = bwd_pc_workspace_bytes_any(IO::VEC, outer, channels, inner);
+#else
+    lsq_params p{};
+    p.quant_min = 0; p.quant_max = 127; p.type_min = 0; p.type_max = 255;
+    p.use_grad_scaling = 1; p.grad_scaler = 1.0; p.numel_for_scaler = 0;
+    for (int al = 0; al < 2; ++al) {
+        // only the alignment of the (never dereferenced) buffer addresses matters to the plan
+        void* const fake = reinterpret_cast<void*>(static_cast<uintptr_t>(al ? 4096 + sizeof(typename IO::elem) : 4096));
+        for (int mode = 0; mode < 4; ++mode) {
+            p.sym = mode & 1;
+            p.init_mode = (mode >> 1) & 1;
+            (void)backward_per_channel<IO>(fake, fake, fake, fake, fake, nullptr, outer, channels, inner, fake, fake, p, fake, 0,
+                                           nullptr, 0, nullptr, &need);
+        }
+    }
+#endif
+    return need + 256;
+}
 
 // LDS-DMA ring in the window-mode kernels by default, with the grid it likes: fewer, longer workgroups than the register
 // loops (it needs rows to keep its ring full).  A/B on one box, profiles/r02_dma_ab.txt: 8-16 % faster on every large shape
@@ -1259,6 +1298,7 @@ struct BwdPcCall {
     bool whole_rounds;     // size the grid in whole rounds of what the chip holds at once (make_geom)
     Variant v;
     hipStream_t stream;
+    size_t* plan_need;     // not null: PLAN only -- record the workspace bytes the launch would need, launch nothing
 };
 
 
@@ -1272,7 +1312,7 @@ constexpr int kWwMinRows = sizeof(typename IO::elem) < 4
                                : (107 + static_cast<int>(sizeof(typename IO::elem)) - 1) / static_cast<int>(sizeof(typename IO::elem));
 template <typename IO>
 static inline int ww_min_rows() {
-    const int o = g_ww_min_rows_override.load(std::memory_order_relaxed);
+    const int o = knob::get(knob::kWwMinRows);
     return o > 0 ? o : kWwMinRows<IO>;
 }
 
@@ -1301,7 +1341,7 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
         auto geom = [&](int resident) {
             // rows of 128 / 192 / 256 lanes: 4- and 8-byte storage cuts them into 64-lane windows of four row groups
             // ([65536,1024] fp32 backward 157 -> 140 us, profiles/r02_ww_split64_ab.txt); 16-bit storage gains nothing
-            const bool split64 = sizeof(typename IO::elem) >= 4 ? g_ww_split64.load() != 2 : g_ww_split64.load() == 1;
+            const bool split64 = sizeof(typename IO::elem) >= 4 ? knob::get(knob::kWwSplit64) != 2 : knob::get(knob::kWwSplit64) == 1;
             return WW ? make_geom_ww(c.outer, c.C, V, target_blocks, ww_min_rows<IO>(), resident, split64, block)
                       : make_geom(c.outer, c.C, c.inner, V, target_blocks, 27, resident);
         };
@@ -1332,13 +1372,16 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
         if (tiles_each < min_tiles || tiles_each > max_tiles) return false;
         if (!grid_fits(g)) { result = hipErrorInvalidConfiguration; return true; }
         const size_t need = static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2);
+        if (c.plan_need) {
+            if (!p.eval_mode) *c.plan_need = std::max(*c.plan_need, need);
+            return true;
+        }
         if (!p.eval_mode && c.workspace_bytes < need) { result = hipErrorInvalidValue; return true; }
         const dim3 grid(static_cast<unsigned>(g.n_windows), static_cast<unsigned>(g.splits));
-        {
-            hipFuncAttributes fa;
-            const int regs = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)) == hipSuccess ? fa.numRegs : -1;
-            last_launch_note() = LaunchNote{static_cast<int>(g.n_windows), g.splits, per_cu, regs};
-        }
+#ifdef LSQ_TOOLS
+        last_launch_note() = LaunchNote{static_cast<int>(g.n_windows), g.splits, per_cu, registers_of(reinterpret_cast<const void*>(kern)),
+                                        WW ? 2 : 1, dma_depth, g.block_threads, g.ring_nt};
+#endif
         hipLaunchKernelGGL(kern, grid, dim3(g.block_threads), lds, c.stream, c.grad, c.x, c.dx, g, static_cast<const T*>(c.scale),
                            static_cast<const T*>(c.shift), r, c.gs, c.partials);
         result = hipGetLastError();
@@ -1382,7 +1425,7 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
                 // waves in flight, evenly over the four SIMDs (3-wave workgroups load them 3:2:2:2), a third of the partial
                 // rows, constants and epilogues.  6-12 % faster there, slower below (a [16,197,768] wants many short
                 // workgroups) and no gain above (profiles/r02_ww_big_ab.txt).
-                const int big = g_ww_big.load(std::memory_order_relaxed);
+                const int big = knob::get(knob::kWwBig);
                 const int64_t elems = c.outer * c.C;
                 // (4- and 8-byte storage only up to 64 MB -- tensors that are usually still cache-resident; from HBM the
                 // usual workgroups win there: [256,197,768] fp32 cold 91.5 vs 102.7 us, profiles/r02_cold_buffers_pc.txt)
@@ -1476,7 +1519,7 @@ template <typename IO>
 hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void* ds, void* db, double* wide,
                                 int64_t outer, int64_t channels, int64_t inner, const void* scale,
                                 const void* shift, const lsq_params& p, void* workspace, size_t workspace_bytes,
-                                uint32_t* ticket, int variant, hipStream_t stream) {
+                                uint32_t* ticket, int variant, hipStream_t stream, size_t* plan_need) {
     using T = typename IO::arith;
     (void)ticket;
     const DeviceInfo& dev = device_info();
@@ -1499,8 +1542,15 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
         const SegGeom sg = make_seg_geom(outer, channels, inner, vec, target);
         if (!grid_fits(sg)) return hipErrorInvalidConfiguration;
         const size_t need = static_cast<size_t>(channels) * sg.segs * sg.osplits * sizeof(double2);
+        if (plan_need) {
+            if (!p.eval_mode) *plan_need = std::max(*plan_need, need);
+            return hipSuccess;
+        }
         if (!p.eval_mode && workspace_bytes < need) return hipErrorInvalidValue;
         const bool one_partial = sg.segs == 1 && sg.osplits == 1;
+#ifdef LSQ_TOOLS
+        last_launch_note() = LaunchNote{static_cast<int>(sg.C * sg.segs), sg.osplits, 0, 0, 3, 0, kBlock, 0};
+#endif
         const SegDirect<T> direct{one_partial ? static_cast<T*>(ds) : nullptr, static_cast<T*>(db), wide, sym_term};
         hipError_t e = bwd_seg_modes<IO>(grad, x, dx, sg, scale, shift, p, gs, partials, direct, v, stream);
         if (e != hipSuccess || one_partial) return e;
@@ -1525,13 +1575,13 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
         // the chip holds (variant: workgroups per CU requested, rounded to whole rounds)
         BwdPcCall<T> call{grad, x, dx, static_cast<T*>(ds), static_cast<T*>(db), wide, outer, channels, inner, scale, shift, &p,
                           gs, sym_term, partials, workspace_bytes, variant == 0 ? dev.cu_count * kWwBwdBlocksPerCU : target,
-                          /*default_variant=*/variant == 0, /*whole_rounds=*/true, v, stream};
+                          /*default_variant=*/variant == 0, /*whole_rounds=*/true, v, stream, plan_need};
         return bwd_pc_modes<IO, VB, VB, true>(call);
     }
     const int target_w = (variant == 0 && last_axis) ? dev.cu_count * kLastAxisBwdBlocksPerCU : target;
     BwdPcCall<T> call{grad, x, dx, static_cast<T*>(ds), static_cast<T*>(db), wide, outer, channels, inner, scale, shift, &p,
                       gs, sym_term, partials, workspace_bytes, target_w, /*default_variant=*/variant == 0,
-                      /*whole_rounds=*/!last_axis, v, stream};
+                      /*whole_rounds=*/!last_axis, v, stream, plan_need};
     if (vecw == 1) return bwd_pc_modes<IO, 1, 1>(call);
     if (cpl == 1) return bwd_pc_modes<IO, VB, 1>(call);
     if (cpl == 2) return bwd_pc_modes<IO, VB, 2>(call);
@@ -1544,11 +1594,18 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
                                                 hipStream_t);                                                        \
     template hipError_t backward_per_channel<IO>(const void*, const void*, void*, void*, void*, double*, int64_t,    \
                                                  int64_t, int64_t, const void*, const void*, const lsq_params&,      \
-                                                 void*, size_t, uint32_t*, int, hipStream_t);
+                                                 void*, size_t, uint32_t*, int, hipStream_t, size_t*);              \
+    template size_t bwd_pc_workspace_bytes<IO>(int64_t, int64_t, int64_t);
+// One translation unit per storage type (the Makefile compiles this file four times with -DLSQ_PC_IO=io_f32 ... in
+// parallel: the window kernels' template space takes minutes in one piece); without the macro, all four.
+#ifdef LSQ_PC_IO
+LSQ_INSTANTIATE(LSQ_PC_IO)
+#else
 LSQ_INSTANTIATE(io_f32)
 LSQ_INSTANTIATE(io_f64)
 LSQ_INSTANTIATE(io_bf16)
 LSQ_INSTANTIATE(io_f16)
+#endif
 #undef LSQ_INSTANTIATE
 
 }  // namespace lsq

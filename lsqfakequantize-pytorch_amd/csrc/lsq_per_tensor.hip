@@ -21,7 +21,6 @@
 //    a ticket, by a one-workgroup finalize launch; either way the partials are added in index order, so
 //    the result is bit-deterministic for a given size (the only atomic is the arrival counter).
 #include "lsq_kernels.hpp"
-#include "lsq_pc_geom.hpp"   // glds16 / wait_vm: the LDS-DMA helpers
 
 namespace lsq {
 
@@ -107,90 +106,6 @@ __global__ __launch_bounds__(kBlock) void fwd_pt_kernel(const void* __restrict__
         }
     }
 }
-
-// EXPERIMENT (make EXPERIMENT=pt_ring; not in the production build): K1 / K2 on the LDS-DMA ring of the window-mode
-// per-channel kernels.  Measured on MI355X with cold buffers (profiles/r02_pt_ring_ab.txt): never faster than the register
-// loops below -- fp32 backward 25.7 M elements 53.0 us vs 57.6 us, config 2 410.7 vs 435.4 us, forward config 2 295 vs 301 us --
-// a contiguous 2R:1W / 1R:1W stream with eight or four 16-byte loads in flight per lane is already at the part's practical
-// ceiling; the ring pays where registers are scarce (16-bit per-channel backward) or rows are strided, not here.
-#ifdef LSQ_EXPERIMENT_PT_RING
-// K1 on an LDS-DMA ring (16-byte packets): every wave keeps DMA tiles of 64 packets in flight through its own ring of
-// 1 KiB stages (global_load_lds_dwordx4, no VGPR held by a load in flight), orders itself with counted s_waitcnt vmcnt and
-// reads a stage with one ds_read_b128 -- the loop form of the window-mode per-channel kernels (lsq_per_channel.hip).
-// Tiles are dealt out strided (tile t -> workgroup t % grid), 256 packets per workgroup and tile.
-template <typename IO, bool INIT, bool LEVELS, int DMA, bool NTS, bool NTL>
-__global__ __launch_bounds__(kBlock) void fwd_pt_ring_kernel(const void* __restrict__ x, void* __restrict__ y,
-                                                             int8_t* __restrict__ levels, int level_bias, int aux_kind,
-                                                             int64_t n, const typename IO::arith* __restrict__ scale,
-                                                             const typename IO::arith* __restrict__ shift,
-                                                             Range<typename IO::arith> r) {
-    using T = typename IO::arith;
-    using E = typename IO::elem;
-    constexpr int VEC = IO::VEC;
-    static_assert(VEC * sizeof(E) == 16, "the LDS-DMA ring moves 16-byte packets");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63;
-    unsigned char* ring = smem + (threadIdx.x >> 6) * (DMA * 1024);
-    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(lds_offset_of(ring));
-    const int64_t n_packets = n / VEC;
-    const int64_t n_full = n_packets / kBlock;
-    const int64_t mine = n_full > blockIdx.x ? (n_full - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    auto packet_of = [&](int64_t i) { return (blockIdx.x + i * gridDim.x) * kBlock + threadIdx.x; };
-    auto issue = [&](int64_t i) {
-        glds16<NTL>(static_cast<const E*>(x) + packet_of(i) * VEC, ring_lds + static_cast<uint32_t>(i % DMA) * 1024u);
-    };
-    for (int64_t i = 0; i < DMA && i < mine; ++i) issue(i);            // in flight before the constants are built
-    const QParams<T> q = make_qparams<T>(sanitize_scale_per_tensor<T>(scale[0]), shift[0], r);  // lsq_cpu.cpp:44-47
-    const T bias = static_cast<T>(level_bias);
-    auto emit = [&](const Packet<IO>& in, int64_t p) {
-        Packet<IO> out;
-        LevelPack<VEC> lv;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const T xv = static_cast<T>(in.v[j]);
-            const T c = clamped<T>(xv, q, r);
-            out.v[j] = IO::to_elem(INIT ? xv : dequant<T>(rne(c), q));  // lsq_kernel.h:13
-            if (LEVELS) lv.b[j] = aux_byte<T>(c, r, bias, aux_kind);
-        }
-        if (NTS) store_packet_nt<IO>(y, p * VEC, out); else store_packet<IO>(y, p * VEC, out);
-        if (LEVELS) lv.store(levels + p * VEC);
-    };
-    using V4 = __attribute__((ext_vector_type(4))) unsigned int;
-    auto consume = [&](int64_t i, bool refill) {
-        const V4 raw = *reinterpret_cast<const V4*>(ring + static_cast<uint32_t>(i % DMA) * 1024u + lane * 16);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the stage is in registers: it may be refilled
-        if (refill) issue(i + DMA);
-        Packet<IO> in;
-        __builtin_memcpy(&in, &raw, 16);
-        emit(in, packet_of(i));
-    };
-    // Tile i was requested DMA tiles ago; younger than its copy are the copies of tiles i+1 .. i+DMA-1 and the stores in
-    // between.  Only the copies are counted: the wait is never too short whatever the order stores retire in.
-    int64_t i = 0;
-    for (; i + DMA < mine; ++i) {
-        wait_vm<DMA - 1>();
-        consume(i, true);
-    }
-    for (; i < mine; ++i) {
-        wait_vm_upto(static_cast<int>(mine - 1 - i));
-        consume(i, false);
-    }
-    // the one partial tile, taken by the workgroup whose turn it would be; the ragged tail (n % VEC elements)
-    if (static_cast<int64_t>(blockIdx.x) == n_full % gridDim.x) {
-        for (int64_t p = n_full * kBlock + threadIdx.x; p < n_packets; p += kBlock) emit(load_packet<IO>(x, p * VEC), p);
-    }
-    if (blockIdx.x == 0) {
-        const int64_t e = n_packets * VEC + threadIdx.x;
-        if (e < n) {
-            const T xv = IO::load1(x, e);
-            const T c = clamped<T>(xv, q, r);
-            IO::store1(y, e, INIT ? xv : dequant<T>(rne(c), q));
-            if (LEVELS) levels[e] = aux_byte<T>(c, r, bias, aux_kind);
-        }
-    }
-}
-
-#endif  // LSQ_EXPERIMENT_PT_RING
 
 // scalar fallback for buffers that are not 16-byte aligned (sliced views): 1 element per lane
 template <typename IO, bool INIT, bool LEVELS>
@@ -373,78 +288,6 @@ __global__ __launch_bounds__(kBlock) void bwd_pt_kernel(const void* __restrict__
     else block_reduce_store<T>(acc.s, acc.b, partials, fold);
 }
 
-#ifdef LSQ_EXPERIMENT_PT_RING
-// K2 on the LDS-DMA ring: stages of 2 KiB ([64 grad packets][64 x packets]), otherwise as fwd_pt_ring_kernel.
-template <typename IO, bool SYM, bool INIT, bool EVAL, int DMA, bool NTS, bool NTL>
-__global__ __launch_bounds__(kBlock) void bwd_pt_ring_kernel(const void* __restrict__ grad, const void* __restrict__ x,
-                                                             void* __restrict__ dx, int64_t n,
-                                                             const typename IO::arith* __restrict__ scale,
-                                                             const typename IO::arith* __restrict__ shift,
-                                                             Range<typename IO::arith> r, typename IO::arith grad_scaler,
-                                                             double2* __restrict__ partials, PtFold<typename IO::arith> fold) {
-    using T = typename IO::arith;
-    using E = typename IO::elem;
-    constexpr int VEC = IO::VEC;
-    static_assert(VEC * sizeof(E) == 16, "the LDS-DMA ring moves 16-byte packets");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63;
-    unsigned char* ring = smem + (threadIdx.x >> 6) * (DMA * kDmaStageBytes);
-    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(lds_offset_of(ring));
-    const int64_t n_packets = n / VEC;
-    const int64_t n_full = n_packets / kBlock;
-    const int64_t mine = n_full > blockIdx.x ? (n_full - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    auto packet_of = [&](int64_t i) { return (blockIdx.x + i * gridDim.x) * kBlock + threadIdx.x; };
-    auto issue = [&](int64_t i) {
-        const int64_t e = packet_of(i) * VEC;
-        const uint32_t dst = ring_lds + static_cast<uint32_t>(i % DMA) * kDmaStageBytes;
-        glds16<NTL>(static_cast<const E*>(grad) + e, dst);
-        glds16<NTL>(static_cast<const E*>(x) + e, dst + 64 * 16);
-    };
-    for (int64_t i = 0; i < DMA && i < mine; ++i) issue(i);
-    const QParams<T> q = make_qparams<T>(sanitize_scale_per_tensor<T>(scale[0]), shift[0], r);  // lsq_cpu.cpp:99-102
-    BwdAcc<T, SYM, INIT, EVAL> acc;
-    auto emit = [&](const Packet<IO>& gi, const Packet<IO>& xi, int64_t p) {
-        Packet<IO> out;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j)
-            out.v[j] = IO::to_elem(acc.step(static_cast<T>(gi.v[j]), static_cast<T>(xi.v[j]), q, r, grad_scaler));
-        if (NTS) store_packet_nt<IO>(dx, p * VEC, out); else store_packet<IO>(dx, p * VEC, out);
-    };
-    using V4 = __attribute__((ext_vector_type(4))) unsigned int;
-    auto consume = [&](int64_t i, bool refill) {
-        const unsigned char* stage = ring + static_cast<uint32_t>(i % DMA) * kDmaStageBytes + lane * 16;
-        const V4 graw = *reinterpret_cast<const V4*>(stage);
-        const V4 xraw = *reinterpret_cast<const V4*>(stage + 64 * 16);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (refill) issue(i + DMA);
-        Packet<IO> gi, xi;
-        __builtin_memcpy(&gi, &graw, 16);
-        __builtin_memcpy(&xi, &xraw, 16);
-        emit(gi, xi, packet_of(i));
-    };
-    int64_t i = 0;
-    for (; i + DMA < mine; ++i) {
-        wait_vm<2 * (DMA - 1)>();
-        consume(i, true);
-    }
-    for (; i < mine; ++i) {
-        wait_vm_upto(static_cast<int>(2 * (mine - 1 - i)));
-        consume(i, false);
-    }
-    if (static_cast<int64_t>(blockIdx.x) == n_full % gridDim.x) {
-        for (int64_t p = n_full * kBlock + threadIdx.x; p < n_packets; p += kBlock)
-            emit(load_packet<IO>(grad, p * VEC), load_packet<IO>(x, p * VEC), p);
-    }
-    if (blockIdx.x == 0) {
-        const int64_t e = n_packets * VEC + threadIdx.x;
-        if (e < n) IO::store1(dx, e, acc.step(IO::load1(grad, e), IO::load1(x, e), q, r, grad_scaler));
-    }
-    if (EVAL) eval_store_zero<T>(fold);
-    else block_reduce_store<T>(acc.s, acc.b, partials, fold);
-}
-
-#endif  // LSQ_EXPERIMENT_PT_RING
-
 template <typename IO, bool SYM, bool INIT, bool EVAL>
 __global__ __launch_bounds__(kBlock) void bwd_pt_scalar_kernel(const void* __restrict__ grad, const void* __restrict__ x,
                                                                void* __restrict__ dx, int64_t n,
@@ -495,25 +338,6 @@ static hipError_t launch_fwd_pt(const void* x, void* y, int8_t* levels, int leve
     }
     const Variant v = decode_variant(variant, kDefaultFwdVariant);
     const int64_t n_packets = n / IO::VEC;
-#ifdef LSQ_EXPERIMENT_PT_RING
-    if (v.dma == 2) {       // LDS-DMA ring: tiles of 256 packets; the variant's unroll field picks the ring depth (8: 16 stages, else 8)
-        const int64_t n_tiles = std::max<int64_t>(1, n_packets / kBlock);
-        const int grid = static_cast<int>(std::min<int64_t>(n_tiles, static_cast<int64_t>(dev.cu_count) * v.blocks_per_cu));
-#define LSQ_LAUNCH_FWD_RING(D, NTSF)                                                                                       \
-    do {                                                                                                                       \
-        if (v.nt_load)                                                                                                         \
-            hipLaunchKernelGGL((fwd_pt_ring_kernel<IO, INIT, LEVELS, D, NTSF, true>), dim3(grid), dim3(kBlock),                \
-                               (kBlock / 64) * D * 1024, stream, x, y, levels, level_bias, aux_kind, n, sc, sh, r);            \
-        else                                                                                                                   \
-            hipLaunchKernelGGL((fwd_pt_ring_kernel<IO, INIT, LEVELS, D, NTSF, false>), dim3(grid), dim3(kBlock),               \
-                               (kBlock / 64) * D * 1024, stream, x, y, levels, level_bias, aux_kind, n, sc, sh, r);            \
-    } while (0)
-        if (v.unroll >= 8) LSQ_LAUNCH_FWD_RING(16, true);
-        else LSQ_LAUNCH_FWD_RING(8, true);
-#undef LSQ_LAUNCH_FWD_RING
-        return hipGetLastError();
-    }
-#endif
     const int64_t tile = static_cast<int64_t>(kBlock) * v.unroll;
     const int64_t n_tiles = std::max<int64_t>(1, (n_packets + tile - 1) / tile);
     const int grid = static_cast<int>(std::min<int64_t>(n_tiles, static_cast<int64_t>(dev.cu_count) * v.blocks_per_cu));
@@ -548,11 +372,6 @@ int bwd_pt_grid(int64_t n, int vec, const Variant& v, bool aligned) {
         return static_cast<int>(std::min<int64_t>(want, static_cast<int64_t>(dev.cu_count) * 16));
     }
     const int64_t n_packets = n / vec;
-#ifdef LSQ_EXPERIMENT_PT_RING
-    if (v.dma == 2)     // LDS-DMA ring: tiles of 256 packets
-        return static_cast<int>(std::min<int64_t>(std::max<int64_t>(1, n_packets / kBlock),
-                                                  static_cast<int64_t>(dev.cu_count) * v.blocks_per_cu));
-#endif
     const int64_t tile = static_cast<int64_t>(kBlock) * v.unroll;
     const int64_t n_tiles = std::max<int64_t>(1, (n_packets + tile - 1) / tile);
     return static_cast<int>(std::min<int64_t>(n_tiles, static_cast<int64_t>(dev.cu_count) * v.blocks_per_cu));
@@ -582,21 +401,6 @@ static hipError_t launch_bwd_pt(const void* grad, const void* x, void* dx, void*
     if (!aligned) {
         hipLaunchKernelGGL((bwd_pt_scalar_kernel<IO, SYM, INIT, EVAL>), dim3(grid), dim3(kBlock), 0, stream, grad, x,
                            dx, n, sc, sh, r, gs, partials, fold);
-#ifdef LSQ_EXPERIMENT_PT_RING
-    } else if (v.dma == 2) {     // LDS-DMA ring; the variant's unroll field picks the ring depth (>= 8: 8, else 4)
-#define LSQ_LAUNCH_BWD_RING(D, NTSF)                                                                                     \
-    do {                                                                                                                 \
-        if (v.nt_load)                                                                                                   \
-            hipLaunchKernelGGL((bwd_pt_ring_kernel<IO, SYM, INIT, EVAL, D, NTSF, true>), dim3(grid), dim3(kBlock),       \
-                               (kBlock / 64) * D * kDmaStageBytes, stream, grad, x, dx, n, sc, sh, r, gs, partials, fold); \
-        else                                                                                                             \
-            hipLaunchKernelGGL((bwd_pt_ring_kernel<IO, SYM, INIT, EVAL, D, NTSF, false>), dim3(grid), dim3(kBlock),      \
-                               (kBlock / 64) * D * kDmaStageBytes, stream, grad, x, dx, n, sc, sh, r, gs, partials, fold); \
-    } while (0)
-        if (v.unroll >= 8) LSQ_LAUNCH_BWD_RING(8, true);
-        else LSQ_LAUNCH_BWD_RING(4, true);
-#undef LSQ_LAUNCH_BWD_RING
-#endif
     } else {
 #define LSQ_LAUNCH_BWD(U, NTLF, NTSF)                                                                                    \
     hipLaunchKernelGGL((bwd_pt_kernel<IO, SYM, INIT, EVAL, U, NTLF, NTSF>), dim3(grid), dim3(kBlock), 0, stream, grad, x, dx, \

@@ -157,13 +157,14 @@ Tensor byte_workspace(const Tensor& like, size_t nbytes) {
 // ---- tickets (lsq_bwd_extras): persistent per-stream arrival counters that make the backward ONE launch ----
 // The C ABI wants LSQ_TICKET_BYTES of zero-initialised device memory that outlives the call and is never shared by
 // launches that can run concurrently.  One slab of kTicketSlots tickets per device is allocated (and zeroed) at the
-// first eager backward on that device; streams get a slot each on first use (host bookkeeping only, so a stream first
-// seen during graph capture still gets one as long as the slab exists; otherwise that call takes the two-launch route).
+// first eager backward on that device -- with hipMalloc and never freed: a static holding an at::Tensor would be destroyed
+// after the HIP runtime at process exit -- and streams get a slot each on first use.  A launch that is being captured
+// into a HIP graph gets no ticket (two-launch route): the graph may be replayed on any stream, next to eager work on the
+// capture stream, and two concurrent launches must never share an arrival counter.
 // Off by default: measured on MI355X the single-launch route is not faster than kernel + finalize launch.
 std::atomic<bool> g_use_ticket{[] { const char* e = std::getenv("TORCHLSQ_SINGLE_LAUNCH_BACKWARD"); return e && e[0] == '1'; }()};
 constexpr int kTicketSlots = 64;
 struct TicketSlab {
-    Tensor storage;
     char* base = nullptr;
     int next = 0;
 };
@@ -173,6 +174,9 @@ std::map<std::pair<int, void*>, void*> g_tickets;            // (device index, s
 
 void* ticket_for(const Tensor& x, void* stream) {
     if (!g_use_ticket.load(std::memory_order_relaxed)) return nullptr;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &st) != hipSuccess || st != hipStreamCaptureStatusNone)
+        return nullptr;                                       // captured launches: two-launch route
     const int dev = x.device().index();
     std::lock_guard<std::mutex> lock(g_ticket_mutex);
     const auto key = std::make_pair(dev, stream);
@@ -180,12 +184,15 @@ void* ticket_for(const Tensor& x, void* stream) {
     if (hit != g_tickets.end()) return hit->second;
     TicketSlab& slab = g_ticket_slabs[dev];
     if (!slab.base) {
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &st) != hipSuccess || st != hipStreamCaptureStatusNone)
-            return nullptr;                                   // no allocation inside a capture: two-launch route
-        slab.storage = at::zeros({kTicketSlots * LSQ_TICKET_BYTES / 4}, x.options().dtype(at::kInt));
-        c10::hip::getCurrentHIPStream(dev).synchronize();     // zeroed before any other stream may use a slot (one-off)
-        slab.base = static_cast<char*>(slab.storage.data_ptr());
+        void* p = nullptr;
+        const size_t bytes = static_cast<size_t>(kTicketSlots) * LSQ_TICKET_BYTES;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {   // zeroed before any stream uses a slot (one-off)
+            (void)hipGetLastError();
+            (void)hipFree(p);
+            return nullptr;
+        }
+        slab.base = static_cast<char*>(p);
     }
     if (slab.next >= kTicketSlots) return nullptr;            // more streams than slots: two-launch route for the rest
     void* t = slab.base + static_cast<size_t>(slab.next++) * LSQ_TICKET_BYTES;
@@ -351,9 +358,11 @@ class LsqNode : public torch::autograd::Function<LsqNode> {
    public:
     static Tensor forward(torch::autograd::AutogradContext* ctx, const Tensor& x, const Tensor& scale,
                           const Tensor& shift, int64_t qmin, int64_t qmax, int64_t tmin, int64_t tmax, int64_t axis,
-                          bool use_gs, double gs, bool sym, bool per_channel, bool eval_mode, bool init_mode) {
+                          bool use_gs, double gs, bool sym, bool per_channel, bool eval_mode, bool init_mode, bool mask_backward) {
         at::AutoDispatchBelowADInplaceOrView below;
-        const bool masked = eval_mode && !init_mode && x.requires_grad();
+        // mask_backward == false: the reference's eval backward, from x and the parameters as they are at backward time
+        // (lsq_autograd.cpp:46-73) -- what LSQFakeQuantizer asks for while its observer rewrites them on every call
+        const bool masked = eval_mode && !init_mode && x.requires_grad() && mask_backward;
         const Scalars s{qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode};
         auto [y, mask] = forward_impl(x, scale, shift, per_channel, axis, s, masked);
         ctx->save_for_backward({masked ? mask : x, scale, shift});
@@ -381,7 +390,7 @@ class LsqNode : public torch::autograd::Function<LsqNode> {
             BackwardOut o = backward_impl(grads[0], saved[0], saved[1], saved[2], (flags & 4) != 0, cfg[4], s);
             dx = o.dx; ds = o.ds; db = o.db;
         }
-        torch::autograd::variable_list out(14);
+        torch::autograd::variable_list out(15);
         out[0] = dx; out[1] = ds; out[2] = db;
         return out;
     }
@@ -390,7 +399,7 @@ class LsqNode : public torch::autograd::Function<LsqNode> {
 // quantops::ops::lsq (lsq.cpp:104-134): checks, per-channel broadcast of single-element parameters, routing.
 Tensor lsq(const Tensor& x, const Tensor& scale, const Tensor& shift, int64_t qmin, int64_t qmax, int64_t tmin,
            int64_t tmax, int64_t axis, bool use_gs, double gs, bool is_affine, bool is_perchannel, bool eval_mode,
-           bool init_mode) {
+           bool init_mode, bool mask_backward) {
     TORCH_CHECK(scale.dim() == 1, "scale should be a 1-D tensor, even in per tensor case(please, avoid torch.Scalar too)");
     TORCH_CHECK(shift.dim() == 1, "shift should be a 1-D tensor, even in per tensor case(please, avoid torch.Scalar too)");
     Tensor sc = scale, sh = shift;
@@ -399,7 +408,8 @@ Tensor lsq(const Tensor& x, const Tensor& scale, const Tensor& shift, int64_t qm
         if (sc.size(0) != size) sc = sc.repeat({size});  // differentiable: a size-1 leaf receives the summed gradient
         if (sh.size(0) != size) sh = sh.repeat({size});
     }
-    return LsqNode::apply(x, sc, sh, qmin, qmax, tmin, tmax, axis, use_gs, gs, !is_affine, is_perchannel, eval_mode, init_mode);
+    return LsqNode::apply(x, sc, sh, qmin, qmax, tmin, tmax, axis, use_gs, gs, !is_affine, is_perchannel, eval_mode, init_mode,
+                          mask_backward);
 }
 
 }  // namespace
@@ -421,7 +431,8 @@ TORCH_LIBRARY(torchlsq_native, m) {
     m.def("lsq_backward_from_mask(Tensor grad, Tensor mask) -> Tensor");
     // composite (autograd handled by the node inside), like the reference's front op
     m.def("lsq(Tensor x, Tensor scale, Tensor shift, int quant_min, int quant_max, int type_min, int type_max, int axis, "
-          "bool use_grad_scaling, float grad_scale, bool is_affine, bool is_perchannel, bool eval_mode, bool init_mode) -> Tensor",
+          "bool use_grad_scaling, float grad_scale, bool is_affine, bool is_perchannel, bool eval_mode, bool init_mode, "
+          "bool mask_backward=True) -> Tensor",
           &lsq);
     m.def("_abi_version() -> int", []() -> int64_t { return lsq_hip_abi_version(); });
     m.def("_set_single_launch_backward(bool on) -> ()", [](bool on) { g_use_ticket.store(on); });

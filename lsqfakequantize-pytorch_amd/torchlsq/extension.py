@@ -18,6 +18,7 @@ the package refuses to work at all (`_assert_has_ops`), CPU tensors included.
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -87,16 +88,9 @@ C_ABI = {
     "lsq_hip_meanstd_per_channel": (_int, [_int, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "lsq_hip_observer_update": (_int, [_i64, _vp, _vp, _vp, _vp, ctypes.POINTER(LsqObserverUpdate), _vp, _vp, _vp]),
 }
-# tuning twins (csrc/lsq_internal.h): same signatures + a trailing launch-variant code
-C_ABI_INTERNAL = {
-    "lsq_hip_debug_force_ring": (None, [_int]),
-    "lsq_hip_debug_set_ww_big": (None, [_int]),
-    "lsq_hip_debug_set_ring_nt": (None, [_int]),
-    "lsq_hip_forward_per_tensor_ex": (_int, C_ABI["lsq_hip_forward_per_tensor"][1] + [_int]),
-    "lsq_hip_backward_per_tensor_ex": (_int, C_ABI["lsq_hip_backward_per_tensor"][1] + [_int]),
-    "lsq_hip_forward_per_channel_ex": (_int, C_ABI["lsq_hip_forward_per_channel"][1] + [_int]),
-    "lsq_hip_backward_per_channel_ex": (_int, C_ABI["lsq_hip_backward_per_channel"][1] + [_int]),
-}
+# NOT bound here: the `_ex` twins (a trailing launch-variant code) and the lsq_hip_debug_* knobs of csrc/lsq_internal.h.
+# They exist only in the tools build of the library (tools/_tune/liblsq_hip_tools.so), which tools/lsq_tools.py loads and
+# swaps in for this module's handle; the `variant` arguments below are for that build and raise on the production library.
 
 
 def _load_library():
@@ -106,11 +100,10 @@ def _load_library():
         raise ImportError("%s not found -- build it with `python __graft_entry__.py` or "
                           "`make -C lsqfakequantize-pytorch_amd/csrc`" % _LIB_PATH)
     lib = ctypes.CDLL(_LIB_PATH)
-    for table in (C_ABI, C_ABI_INTERNAL):
-        for name, (res, args) in table.items():
-            fn = getattr(lib, name)  # AttributeError -> OSError-like failure below
-            fn.restype = res
-            fn.argtypes = args
+    for name, (res, args) in C_ABI.items():
+        fn = getattr(lib, name)  # AttributeError -> OSError-like failure below
+        fn.restype = res
+        fn.argtypes = args
     abi = lib.lsq_hip_abi_version()
     if abi != ABI_VERSION:
         raise ImportError("liblsq_hip.so has ABI version %d, this package needs %d" % (abi, ABI_VERSION))
@@ -131,6 +124,7 @@ cpu_error_str = ""
 C_ABI_CPU = {
     "lsq_cpu_abi_version": (_int, []),
     "lsq_cpu_last_error": (ctypes.c_char_p, []),
+    "lsq_cpu_set_num_threads": (None, [_int]),
     "lsq_cpu_forward_per_tensor": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _PP]),
     "lsq_cpu_backward_per_tensor": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _PP]),
     "lsq_cpu_forward_per_channel": (_int, [_int, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP]),
@@ -414,6 +408,18 @@ def _status(rc, what):
         raise RuntimeError("%s failed (%d): %s" % (what, rc, _LIB.lsq_hip_last_error().decode("utf-8", "replace")))
 
 
+def _entry(name, variant):
+    """(C entry point, trailing arguments): the include/lsq_hip.h symbol, or -- `variant` != 0, tools build only -- its
+    `_ex` twin with the launch-variant code appended."""
+    if not variant:
+        return getattr(_LIB, name), ()
+    fn = getattr(_LIB, name + "_ex", None)
+    if fn is None:
+        raise RuntimeError("launch variants need the tools build of the library (make -C lsqfakequantize-pytorch_amd/csrc "
+                           "tools; tools/lsq_tools.py): liblsq_hip.so exports only include/lsq_hip.h")
+    return fn, (int(variant),)
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
@@ -443,9 +449,8 @@ def _workspace(device, nbytes):
 # ---- tickets (lsq_bwd_extras): persistent per-stream arrival counters that make the backward ONE launch -------------
 # The C ABI wants LSQ_TICKET_BYTES of zero-initialised device memory that outlives the call and is never shared by
 # launches that can run concurrently.  One slab of _TICKET_SLOTS tickets per device is allocated (and zeroed) at the
-# first eager backward on that device; streams get a slot each on first use (pure host bookkeeping, so a stream first
-# seen DURING graph capture still gets one -- as long as the slab exists; otherwise that call takes the two-launch
-# route).  Kernels of one stream are serialised by the stream, kernels captured from one stream by the graph.
+# first eager backward on that device; streams get a slot each on first use.  Kernels of one stream are serialised by the
+# stream; launches captured into a HIP graph take no ticket (see _ticket).
 # Measured on MI355X (profiles/r02_ticket_single_launch.txt): the single-launch route is NOT faster -- the last workgroup's
 # serial chain (drain its dx stores, agent-scope counter round trip, agent-scope loads of the partials) costs as much
 # as the finalize kernel's launch (config 1 backward 8.0 us against 6.9 us; config 2 / 4 unchanged) -- so it is off unless
@@ -464,17 +469,29 @@ _TICKET_SLOTS = 64
 _TICKET_SLABS = {}     # device index -> (slab tensor, base pointer, [next free slot])
 _TICKETS = {}          # (device index, raw stream) -> byref(LsqBwdExtras)
 _TICKET_KEEP = []      # the structs behind the byrefs
+_TICKET_LOCK = threading.Lock()   # backward runs on autograd engine threads (one per device), forward-side callers on others
 
 
 def _ticket(idx, stream):
+    # A launch that is being CAPTURED into a HIP graph gets no ticket (two-launch route): the graph may later be replayed on
+    # any stream, next to eager work or another replay on the capture stream, and two concurrent launches must never share
+    # an arrival counter.
+    if torch.cuda.is_current_stream_capturing():
+        return None
     key = (idx, stream)
+    hit = _TICKETS.get(key)          # (a dict read is atomic under the GIL; entries are never removed or changed)
+    if hit is not None:
+        return hit
+    with _TICKET_LOCK:
+        return _ticket_locked(idx, stream, key)
+
+
+def _ticket_locked(idx, stream, key):
     hit = _TICKETS.get(key)
     if hit is not None:
         return hit
     slab = _TICKET_SLABS.get(idx)
     if slab is None:
-        if torch.cuda.is_current_stream_capturing():
-            return None                                   # no allocation inside a capture: two-launch route
         t = torch.zeros(_TICKET_SLOTS * LSQ_TICKET_BYTES // 4, dtype=torch.int32, device=torch.device("cuda", idx))
         torch.cuda.current_stream(idx).synchronize()      # zeroed before any other stream may use a slot (one-off)
         slab = _TICKET_SLABS[idx] = (t, t.data_ptr(), [0])
@@ -528,8 +545,9 @@ def hip_forward_per_tensor(x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, 
     _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
     scale_c, shift_c = scale.contiguous(), shift.contiguous()
     idx = x.device.index
-    rc = _on_device(idx, _LIB.lsq_hip_forward_per_tensor_ex, _DTYPE_CODE[x.dtype], xd.data_ptr(), y.data_ptr(), n,
-                    scale_c.data_ptr(), shift_c.data_ptr(), pref, ex, _stream_of(idx), variant)
+    fn, tail = _entry("lsq_hip_forward_per_tensor", variant)
+    rc = _on_device(idx, fn, _DTYPE_CODE[x.dtype], xd.data_ptr(), y.data_ptr(), n,
+                    scale_c.data_ptr(), shift_c.data_ptr(), pref, ex, _stream_of(idx), *tail)
     if rc:
         _status(rc, "lsq_hip_forward_per_tensor")
     return (y, lv) if has_aux else y
@@ -563,10 +581,11 @@ def hip_backward_per_tensor(grad, x, scale, shift, qmin, qmax, tmin, tmax, use_g
     stream = _stream_of(idx)
     if use_ticket is None:
         use_ticket = _SINGLE_LAUNCH_BWD[0]
-    rc = _on_device(idx, _LIB.lsq_hip_backward_per_tensor_ex, code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(),
+    fn, tail = _entry("lsq_hip_backward_per_tensor", variant)
+    rc = _on_device(idx, fn, code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(),
                     ds.data_ptr(), db.data_ptr(), wide.data_ptr() if want_wide else None, xd.numel(),
                     scale_c.data_ptr(), shift_c.data_ptr(), pref, _ticket(idx, stream) if use_ticket else None,
-                    ws.data_ptr(), ws.numel(), stream, variant)
+                    ws.data_ptr(), ws.numel(), stream, *tail)
     if rc:
         _status(rc, "lsq_hip_backward_per_tensor")
     if want_wide:
@@ -590,8 +609,9 @@ def hip_forward_per_channel(x, scale, shift, axis, qmin, qmax, tmin, tmax, use_g
     _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
     scale_c, shift_c = scale.contiguous(), shift.contiguous()
     idx = x.device.index
-    rc = _on_device(idx, _LIB.lsq_hip_forward_per_channel_ex, _DTYPE_CODE[x.dtype], xd.data_ptr(), y.data_ptr(), outer,
-                    C, inner, scale_c.data_ptr(), shift_c.data_ptr(), pref, ex, _stream_of(idx), variant)
+    fn, tail = _entry("lsq_hip_forward_per_channel", variant)
+    rc = _on_device(idx, fn, _DTYPE_CODE[x.dtype], xd.data_ptr(), y.data_ptr(), outer,
+                    C, inner, scale_c.data_ptr(), shift_c.data_ptr(), pref, ex, _stream_of(idx), *tail)
     if rc:
         _status(rc, "lsq_hip_forward_per_channel")
     return (y, lv) if has_aux else y
@@ -660,10 +680,11 @@ def hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax
     stream = _stream_of(idx)
     if use_ticket is None:
         use_ticket = _SINGLE_LAUNCH_BWD[0]
-    rc = _on_device(idx, _LIB.lsq_hip_backward_per_channel_ex, code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(),
+    fn, tail = _entry("lsq_hip_backward_per_channel", variant)
+    rc = _on_device(idx, fn, code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(),
                     ds.data_ptr(), db.data_ptr(), wide.data_ptr() if want_wide else None, outer, C, inner,
                     scale_c.data_ptr(), shift_c.data_ptr(), pref, _ticket(idx, stream) if use_ticket else None,
-                    ws.data_ptr(), ws.numel(), stream, variant)
+                    ws.data_ptr(), ws.numel(), stream, *tail)
     if rc:
         _status(rc, "lsq_hip_backward_per_channel")
     if want_wide:
@@ -838,6 +859,7 @@ def _cpu_lib(what):
     _assert_has_ops()      # the package as a whole needs its HIP library: CPU tensors do not make it usable on their own
     if _CPU_LIB is None:
         raise NotImplementedError("%s: the CPU kernels (liblsq_cpu.so) are not available: %s" % (what, cpu_error_str))
+    _CPU_LIB.lsq_cpu_set_num_threads(torch.get_num_threads())     # the loops follow torch's intra-op thread setting
     return _CPU_LIB
 
 

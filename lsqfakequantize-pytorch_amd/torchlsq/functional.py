@@ -25,18 +25,18 @@ class _LSQOnDevice(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, scale, shift, cfg):
-        (qmin, qmax, tmin, tmax, axis, use_gs, gs, sym, per_channel, eval_mode, init_mode) = cfg
-        # eval mode (plain fake-quantizer behaviour; also the whole observer-driven init phase): the backward
-        # only needs "was the element strictly inside the range", so the forward emits that as one byte per
-        # element and autograd keeps the mask instead of x (1 instead of 4 bytes per fp32 element, and the
-        # backward reads 9 instead of 12 bytes per element).
-        # One observable difference from the reference, which recomputes the mask in its backward from the saved
-        # (x, scale, shift) (lsq_autograd.cpp:52-67): the mask is that of the FORWARD's parameter values.  They only
-        # differ if scale / shift are overwritten in place (param.data.copy_, which autograd's version check does not
-        # see) between this forward and its backward -- e.g. the same quantizer instance called twice before one
-        # backward during its observer-driven phase; the reference then differentiates with the newer parameters, this
-        # build with the ones the output was actually computed with.  (The C++ host binding's LsqNode does the same.)
-        masked = eval_mode and not init_mode and x.requires_grad
+        (qmin, qmax, tmin, tmax, axis, use_gs, gs, sym, per_channel, eval_mode, init_mode, mask_backward) = cfg
+        # eval mode (plain fake-quantizer behaviour): the backward only needs "was the element strictly inside the
+        # range", so the forward emits that as one byte per element and autograd keeps the mask instead of x (1 instead
+        # of 4 bytes per fp32 element, and the backward reads 9 instead of 12 bytes per element).
+        # The mask is that of the FORWARD's parameter values, whereas the reference recomputes it in its backward from
+        # the saved (x, scale, shift) (lsq_autograd.cpp:46-73), i.e. from the parameter values AT BACKWARD TIME.  The two
+        # differ only if scale / shift are overwritten in place (param.data.copy_, which autograd's version check does
+        # not see) between this forward and its backward -- which is exactly what the observer-driven phase of
+        # LSQFakeQuantizer does on every call (observers.py:417-420).  `mask_backward=False` (what the module passes
+        # while its observer is enabled) keeps the reference's behaviour: x is saved and the eval backward runs on the
+        # current parameters.  (The C++ host binding's LsqNode has the same switch.)
+        masked = eval_mode and not init_mode and x.requires_grad and mask_backward
         if per_channel:
             y = _E.hip_forward_per_channel(x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode,
                                            init_mode, want_mask=masked)
@@ -56,7 +56,7 @@ class _LSQOnDevice(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, grad_out):
         x, scale, shift = ctx.saved_tensors
-        (qmin, qmax, tmin, tmax, axis, use_gs, gs, sym, per_channel, eval_mode, init_mode) = ctx.cfg
+        (qmin, qmax, tmin, tmax, axis, use_gs, gs, sym, per_channel, eval_mode, init_mode, _) = ctx.cfg
         if ctx.masked:      # x is the inside mask here; d_scale = d_shift = 0 (lsq_kernel.h:142-144)
             return _E.hip_backward_from_mask(grad_out, x), torch.zeros_like(scale), torch.zeros_like(shift), None
         if per_channel:
@@ -79,7 +79,8 @@ def lsq(x: Tensor, scale: Tensor, shift: Tensor,
         is_affine: bool = True,
         is_perchannel: bool = False,
         eval_mode: bool = False,
-        init_mode: bool = False) -> Tensor:
+        init_mode: bool = False, *,
+        mask_backward: bool = True) -> Tensor:
     """Learned Step Size Quantization (LSQ+, arXiv:2004.09576) fake quantizer: quantize -> dequantize
     with `scale` and `shift` as learnable parameters.
 
@@ -114,6 +115,10 @@ def lsq(x: Tensor, scale: Tensor, shift: Tensor,
         eval_mode: behave like a plain fake-quantizer (no parameter gradients).
         init_mode: parameter-initialisation phase: the forward is the identity and the parameter
             gradients are those of ||x_r - x||^2 (the upstream gradient is ignored for them).
+        mask_backward (keyword only; this build, GPU tensors): in eval mode keep the forward's one-byte "inside the
+            range" mask for the backward (default) instead of x.  False = the reference's behaviour to the letter: x is
+            saved and the backward recomputes the mask from the parameters as they are THEN (lsq_autograd.cpp:46-73) --
+            it only matters when scale / shift are overwritten in place between a forward and its backward.
     """
     _assert_has_ops()
     if not is_affine:
@@ -128,7 +133,8 @@ def lsq(x: Tensor, scale: Tensor, shift: Tensor,
         native = _E._NATIVE_LSQ
         if native is not None:      # C++ front op + autograd node (csrc/torch_binding): same kernels, less host time
             return native(x, scale, shift, quant_min, quant_max, type_min, type_max, axis, bool(use_grad_scaling),
-                          float(grad_scaler), bool(is_affine), bool(is_perchannel), bool(eval_mode), bool(init_mode))
+                          float(grad_scaler), bool(is_affine), bool(is_perchannel), bool(eval_mode), bool(init_mode),
+                          bool(mask_backward))
         if scale.dim() != 1:
             raise RuntimeError("scale should be a 1-D tensor, even in per tensor case(please, avoid torch.Scalar too)")
         if shift.dim() != 1:
@@ -140,7 +146,7 @@ def lsq(x: Tensor, scale: Tensor, shift: Tensor,
             if shift.size(0) != size:
                 shift = shift.repeat(size)
         cfg = (quant_min, quant_max, type_min, type_max, axis, bool(use_grad_scaling), float(grad_scaler),
-               not is_affine, bool(is_perchannel), bool(eval_mode), bool(init_mode))
+               not is_affine, bool(is_perchannel), bool(eval_mode), bool(init_mode), bool(mask_backward))
         return _LSQOnDevice.apply(x, scale, shift, cfg)
     return torch.ops.torchlsq.lsq(x, scale, shift, quant_min, quant_max, type_min, type_max,
                                   axis, use_grad_scaling, grad_scaler, is_affine, is_perchannel,

@@ -424,10 +424,14 @@ class LSQFakeQuantizer(ObserverBase):
             tmin, tmax = TYPES_RANGE_MAPPING[self.dtype]['range']
             self.scale.requires_grad = full_lsq
             self.shift.requires_grad = full_lsq and self.is_affine
+            # While the observer is enabled it overwrites scale / shift in place on EVERY call (above), so a second call
+            # before the first one's backward changes what the reference's eval backward sees (it recomputes the mask
+            # from the saved x and the then-current parameters, lsq_autograd.cpp:46-73): keep that behaviour there
+            # (save x); once the parameters are only changed by the optimizer, the one-byte saved mask is equivalent.
             return lsq(x, self.scale, self.shift, quant_min=self.quant_min, quant_max=self.quant_max,
                        type_min=tmin, type_max=tmax, axis=self.ch_axis, use_grad_scaling=self.use_grad_scaling,
                        grad_scaler=self.grad_scaler, is_affine=self.is_affine, is_perchannel=self.is_perchannel,
-                       eval_mode=(not full_lsq), init_mode=backprop_init)
+                       eval_mode=(not full_lsq), init_mode=backprop_init, mask_backward=(h['observer'] != 1))
         return x
 
     @torch.jit.export

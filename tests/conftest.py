@@ -14,7 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG_DIR = os.path.join(ROOT, "lsqfakequantize-pytorch_amd")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-for p in (PKG_DIR, ROOT):
+for p in (PKG_DIR, ROOT, os.path.join(ROOT, "tools")):     # tools/: lsq_tools.py (the tools build of the library)
     if p not in sys.path:
         sys.path.insert(0, p)
 

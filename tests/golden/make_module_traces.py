@@ -160,6 +160,31 @@ def drive(module_cls, sc, dump_state_after=None, resume=None):
     return out, final
 
 
+def two_calls_one_backward(module_cls, device="cpu"):
+    """The same quantizer called TWICE during its observer-driven phase before the FIRST call's backward runs: the observer
+    rewrites scale / shift in place at the second call, and the reference's eval-mode backward recomputes its mask from the
+    saved x and the parameters as they are by then (lsq_autograd.cpp:46-73).  Returns what the first call's input gradient
+    looks like, plus the masks either parameter set would give (they differ for this data)."""
+    from torch.ao.quantization.observer import MinMaxObserver
+    m = module_cls(MinMaxObserver, otype="activation", init_batches=6)
+    m.train()
+    n = 4 * 8 * 6 * 6
+    mk = lambda seed, mean, std: S.normal_like(n, seed, mean, std).view(4, 8, 6, 6).to(device)
+    m(mk(300, 0.5, 0.2))                                   # creating call
+    if device != "cpu":
+        m.to(device)
+    x1 = mk(301, 0.5, 0.2).requires_grad_(True)            # narrow range ...
+    y1 = m(x1)
+    p1 = (m.scale.detach().clone(), m.shift.detach().clone())
+    x2 = mk(302, 0.5, 3.0).requires_grad_(True)            # ... then a much wider one: the running min / max jump
+    y2 = m(x2)
+    p2 = (m.scale.detach().clone(), m.shift.detach().clone())
+    w = mk(303, 0.0, 1.0)
+    (y1 * w).sum().backward()
+    return dict(dx1_sha=sha(x1.grad.cpu()), dx1_nonzero=int((x1.grad != 0).sum()), scale_after_call1=tolist(p1[0]), shift_after_call1=tolist(p1[1]),
+                scale_after_call2=tolist(p2[0]), shift_after_call2=tolist(p2[1]), y1_sha=sha(y1.cpu()), y2_sha=sha(y2.cpu()))
+
+
 def import_reference_module():
     from oracle import build_ref
     build_ref.build_all(verbose=False)
@@ -209,6 +234,7 @@ if __name__ == "__main__":
                          init_mode="learnable", avoid_torch_overflow=lb).__dict__[k] for k in ("quant_min", "quant_max"))]
                         for ot, dt in (("weight", "qint8"), ("activation", "quint8")) for lb in (True, False)],
     )
+    extras["two_calls_one_backward"] = two_calls_one_backward(ref.LSQFakeQuantizer)
     with open(os.path.join(HERE, "module_traces.json"), "w") as f:
         json.dump(dict(generator="tests/golden/make_module_traces.py", torch=torch.__version__,
                        reference="DeadAt0m/LSQFakeQuantize-PyTorch torchlsq/quantized/modules/observers.py (imported in place)",

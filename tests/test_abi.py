@@ -25,11 +25,24 @@ def test_header_symbols_are_exported():
     names = _declared()
     assert len(names) == 18, names
     nm = subprocess.run(["nm", "-D", "--defined-only", LIB], capture_output=True, text=True, check=True).stdout
-    exported = set(l.split()[-1] for l in nm.splitlines() if " T " in l)
-    missing = [n for n in names if n not in exported]
-    assert not missing, "declared in include/lsq_hip.h but not exported: %s" % missing
+    exported = sorted(set(l.split()[-1] for l in nm.splitlines() if " T " in l and l.split()[-1].startswith("lsq_")))
+    # exported == declared, not a superset: no `_ex` twin, no lsq_hip_debug_* knob, nothing else with C linkage
+    assert exported == names, "C symbols exported %s != declared in include/lsq_hip.h %s" % (exported, names)
+    assert "debug" not in nm
     lib = ctypes.CDLL(LIB)
     for n in names:
+        getattr(lib, n)
+
+
+def test_tools_build_carries_the_internal_entry_points():
+    """tools/_tune/liblsq_hip_tools.so (-DLSQ_TOOLS): include/lsq_hip.h plus csrc/lsq_internal.h, typed by tools/lsq_tools.py"""
+    import lsq_tools
+    lib = lsq_tools.load()
+    assert lib.lsq_hip_abi_version() == 2
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "lsqfakequantize-pytorch_amd", "csrc", "lsq_internal.h")).read(), flags=re.S)
+    internal = sorted(set(re.findall(r"\b(lsq_hip_\w+)\s*\(", text)))
+    assert internal == sorted(lsq_tools.internal_abi()), (internal, sorted(lsq_tools.internal_abi()))
+    for n in internal:
         getattr(lib, n)
 
 
@@ -92,7 +105,7 @@ def test_cpu_library_exports_its_header_and_devices_never_substitute():
     from torchlsq import extension as E
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "lsq_cpu.h")).read(), flags=re.S)
     declared = sorted(set(re.findall(r"\b(lsq_cpu_\w+)\s*\(", text)))
-    assert declared == sorted(E.C_ABI_CPU) and len(declared) == 6
+    assert declared == sorted(E.C_ABI_CPU) and len(declared) == 7
     cpu_lib = os.path.join(os.path.dirname(LIB), "liblsq_cpu.so")
     nm = subprocess.run(["nm", "-D", "--defined-only", cpu_lib], capture_output=True, text=True, check=True).stdout
     exported = set(l.split()[-1] for l in nm.splitlines() if " T " in l)

@@ -36,6 +36,43 @@ def test_self_spawned_ranks_on_one_device():
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2"
     assert out["config"]["global_elements"] == 2 * out["config"]["elements_per_gpu"]
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
+    assert 0 < out["per_gpu_efficiency"] and out["rank0_shard_alone_ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_default_multi_rank_line_carries_the_strong_scaled_config_too():
+    """the N > 1 default line (weak-scaled config 2 per rank) also reports BASELINE config 4, [1024,1024,14,14] split over the
+    ranks, with its own per-GPU efficiency; here 2 ranks share the one GPU over gloo (the control flow, not the numbers)"""
+    r = _run(["--gpus", "2", "--backend", "gloo", "--single-device", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and "cfg2" in out["config"]["workload"]
+    s4 = out["strong_scaled"]
+    assert s4["scaling"] == "strong" and s4["global_elements"] == 1024 * 1024 * 14 * 14 and s4["elements_per_gpu"] * 2 == s4["global_elements"]
+    assert s4["value"] > 0 and 0 < s4["per_gpu_efficiency"] and 0 < out["per_gpu_efficiency"]
+
+
+def test_default_line_has_secondary_records_declared():
+    """(CPU: the flag surface only) the default run appends `secondary` records for the other single-GPU BASELINE configs"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_bench", BENCH)
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.SECONDARY == ("cfg1", "cfg3", "cfg5", "cfg5_bf16")
+    a = b.parse_args([])
+    assert a.workload == "cfg2" and a.gpus == 1 and not a.no_secondary
+
+
+@pytest.mark.gpu
+def test_default_line_carries_the_per_channel_half():
+    r = _run(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-measure-traffic", "--secondary-steps", "20"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    sec = {s["workload"]: s for s in out["secondary"]}
+    assert sorted(sec) == ["cfg1", "cfg3", "cfg5", "cfg5_bf16"]
+    for s in sec.values():
+        assert "error" not in s and s["value"] > 0 and s["launch"] == "eager" and 0 < s["step_frac"] < 1
+    assert "ms_per_step_ctypes_binding" in sec["cfg1"] and sec["cfg5_bf16"]["storage"] == "bfloat16"
 
 
 @pytest.mark.gpu

@@ -17,10 +17,15 @@ REG, RING = 1 << 12, 2 << 12
 
 @pytest.fixture(scope="module")
 def E():
+    """torchlsq.extension on the TOOLS build of the library (tools/_tune/liblsq_hip_tools.so: the same kernels plus the
+    launch-variant `_ex` entry points and the lsq_hip_debug_* policy knobs, which liblsq_hip.so does not export)."""
     import torchlsq  # noqa: F401
     from torchlsq import extension
     extension._assert_has_ops()
-    return extension
+    import lsq_tools
+    lsq_tools.activate()
+    yield extension
+    lsq_tools.deactivate()
 
 
 def _bits(t):
@@ -198,21 +203,19 @@ def test_row_group_workgroup_sizes_on_random_last_axis_shapes(E, dtype):
 def test_default_policy_takes_the_ring_on_large_shapes(E):
     """the launch note of the window-mode backward reports the grid; with the ring a [256,2048,7,7] bf16 backward is
     sized for 4 resident workgroups per CU (LDS-bound) and fills one round"""
-    import ctypes
+    import lsq_tools
     from torchlsq import synth
     dev = torch.device("cuda:0")
-    lib = E.library()
-    lib.lsq_hip_debug_last_launch.argtypes = [ctypes.POINTER(ctypes.c_int * 4)]
     n = 256 * 2048 * 49
     x = synth.normal_like(n, 1, 0.0, 1.0, dtype=torch.bfloat16, device=dev).view(256, 2048, 7, 7)
     g = synth.normal_like(n, 2, 0.0, 1e-3, dtype=torch.bfloat16, device=dev).view(256, 2048, 7, 7)
     s, b = synth.uniform_like(2048, 3, 0.05, 0.35, device=dev), synth.normal_like(2048, 4, 0.0, 0.1, device=dev)
     E.hip_backward_per_channel(g, x, s, b, 1, -8, 7, -128, 127, True, 1.0, False, False, False)
     torch.cuda.synchronize()
-    out = (ctypes.c_int * 4)()
-    lib.lsq_hip_debug_last_launch(ctypes.byref(out))
+    note = lsq_tools.last_launch()
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    assert out[0] == 49 and out[2] >= 3                      # 49 windows of 2048 positions; residency known
-    total = out[0] * out[1]
-    rounds = -(-total // (out[2] * cus))
-    assert total / (rounds * out[2] * cus) >= 0.9, (list(out), "the last round of workgroups is not full")
+    assert note["kind"] == "windows" and note["ring_depth"] == 4 and note["ring_nt"] == 1, note
+    assert note["grid_x"] == 49 and note["resident_per_cu"] >= 3           # 49 windows of 2048 positions; residency known
+    total = note["grid_x"] * note["grid_y"]
+    rounds = -(-total // (note["resident_per_cu"] * cus))
+    assert total / (rounds * note["resident_per_cu"] * cus) >= 0.9, (note, "the last round of workgroups is not full")

@@ -55,6 +55,7 @@ N_SEEDS = int(os.environ.get("LSQ_FUZZ_SEEDS", "12"))      # a longer soak: LSQ_
 def test_random_cases_against_the_oracle(seed):
     assert torch.cuda.is_available()
     import torchlsq  # noqa: F401
+    import lsq_tools
     from torchlsq import extension
     from torchlsq.functional import lsq
     extension._assert_has_ops()
@@ -111,16 +112,24 @@ def test_random_cases_against_the_oracle(seed):
         # the window-mode per-channel kernels have two loop forms (register loops, LDS-DMA ring) and the launch policy
         # picks by shape: force either one on a share of the cases so that both meet every kind of input
         loop_form = int(rng.choice([0, 0, 1, 2, 2]))
-        extension.library().lsq_hip_debug_force_ring(loop_form)
         # ... and the row-group windows (quantized axis last) two workgroup sizes: 768/1024 lanes on a share of the cases
         ww_big = int(rng.choice([0, 0, 1]))
-        extension.library().lsq_hip_debug_set_ww_big(ww_big)
         # ... and the ring's copies with or without the streaming hint (the policy uses it above 32 MB only)
         ring_nt = int(rng.choice([0, 1, 2]))
-        extension.library().lsq_hip_debug_set_ring_nt(ring_nt)
+        # The knobs exist only in the TOOLS build of the library (tools/lsq_tools.py), which the ctypes host layer can be
+        # pointed at; the C++ binding is linked against the production library, so its cases run the built-in policy.
+        if binding == "native":
+            loop_form = ww_big = ring_nt = 0
+        forced = bool(loop_form or ww_big or ring_nt)
         tag += " loop=%d big=%d nt=%d" % (loop_form, ww_big, ring_nt)
-        extension.set_host_binding(binding)
         try:
+            if forced:
+                tl = lsq_tools.activate()
+                tl.lsq_hip_debug_force_ring(loop_form)
+                tl.lsq_hip_debug_set_ww_big(ww_big)
+                tl.lsq_hip_debug_set_ring_nt(ring_nt)
+            else:
+                extension.set_host_binding(binding)
             xt = _layout(rng, torch.from_numpy(xs).to(dev).to(dtype), kind).requires_grad_(True)
             gt = torch.from_numpy(g.reshape(shape)).to(dev).to(dtype)
             st = torch.from_numpy(scale).to(dev).requires_grad_(True)
@@ -130,10 +139,9 @@ def test_random_cases_against_the_oracle(seed):
             y.backward(gt)
             torch.cuda.synchronize()
         finally:
+            if forced:
+                lsq_tools.deactivate()
             extension.set_host_binding("native")
-            extension.library().lsq_hip_debug_force_ring(0)
-            extension.library().lsq_hip_debug_set_ww_big(0)
-            extension.library().lsq_hip_debug_set_ring_nt(0)
         if narrow:      # parity for 16-bit storage is defined by the build: the fp32 result rounded to the storage type
             want_y = torch.from_numpy(np.ascontiguousarray(oy)).to(dtype)
             want_dx = torch.from_numpy(np.ascontiguousarray(r.dx)).to(dtype)

@@ -167,6 +167,16 @@ def test_state_dict_interchanges_with_the_reference_module(oracle_cpu_backend, t
         assert own[key].tobytes() == ref_state[key].tobytes(), "%s: state_dict()[%r] differs from the reference's" % (name, key)
 
 
+def test_two_calls_before_one_backward_match_the_reference(oracle_cpu_backend, traces):
+    """the observer rewrites scale / shift in place at the second call; the first call's eval-mode backward then runs on the
+    parameters as they are by then -- the reference's behaviour (lsq_autograd.cpp:46-73), pinned by its own module's trace"""
+    from torchlsq.quantized import LSQFakeQuantizer
+    drv = _load_driver()
+    want = traces["extras"]["two_calls_one_backward"]
+    got = drv.two_calls_one_backward(LSQFakeQuantizer)
+    assert got == want
+
+
 def test_apply_helpers():
     import torchlsq.quantized as TQ
     from torch.ao.quantization import FakeQuantize

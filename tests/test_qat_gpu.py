@@ -122,3 +122,50 @@ def test_quantized_block_runs_as_a_hip_graph():
                 assert pa.grad is not None and torch.equal(pa.grad, pb.grad), (step, na)
         eager.zero_grad(set_to_none=True)        # (graphed callables hand out their static gradient buffers: an in-place
         graphed_src.zero_grad(set_to_none=True)  # zero would alias them -- the usual make_graphed_callables rule)
+
+
+@pytest.mark.parametrize("binding", ["native", "ctypes"])
+def test_eval_backward_while_the_observer_rewrites_the_parameters(binding):
+    """Two calls of one quantizer before the first call's backward, during the observer-driven phase.  The module asks for
+    the reference's eval backward there (x saved, mask recomputed from the parameters as they are at backward time,
+    lsq_autograd.cpp:46-73): same input gradient as the reference module's own trace.  The functional's default, the saved
+    one-byte mask, differentiates with the parameters the output was computed with -- both behaviours shown."""
+    import importlib.util
+    import json
+    import os
+    from torchlsq import extension as E
+    from torchlsq.functional import lsq
+    from torchlsq.quantized import LSQFakeQuantizer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_trace_driver", os.path.join(root, "tests", "golden", "make_module_traces.py"))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    want = json.load(open(os.path.join(root, "tests", "golden", "module_traces.json")))["extras"]["two_calls_one_backward"]
+    if binding == "native" and E.native_lsq() is None:
+        pytest.skip("C++ binding not built")
+    saved = E.host_binding()
+    E.set_host_binding(binding)
+    try:
+        got = drv.two_calls_one_backward(LSQFakeQuantizer, device="cuda:0")
+        for k in ("dx1_sha", "dx1_nonzero", "y1_sha", "y2_sha", "scale_after_call1", "scale_after_call2", "shift_after_call2"):
+            assert got[k] == want[k], (binding, k, got[k], want[k])
+        # the functional op on the same data: in-place parameter overwrite between forward and backward
+        dev = torch.device("cuda:0")
+        n = 4 * 8 * 6 * 6
+        x = drv.S.normal_like(n, 301, 0.5, 0.2).view(4, 8, 6, 6).to(dev)
+        w = drv.S.normal_like(n, 303, 0.0, 1.0).view(4, 8, 6, 6).to(dev)
+        grads = {}
+        for mask_backward in (True, False):
+            scale = torch.tensor(want["scale_after_call1"], device=dev, requires_grad=True)
+            shift = torch.tensor(want["shift_after_call1"], device=dev, requires_grad=True)
+            xi = x.clone().requires_grad_(True)
+            y = lsq(xi, scale, shift, 0, 127, 0, 255, eval_mode=True, mask_backward=mask_backward)
+            scale.data.copy_(torch.tensor(want["scale_after_call2"], device=dev))
+            shift.data.copy_(torch.tensor(want["shift_after_call2"], device=dev))
+            (y * w).sum().backward()
+            grads[mask_backward] = xi.grad.clone()
+        assert drv.sha(grads[False].cpu()) == want["dx1_sha"]                 # the reference's answer
+        assert int((grads[True] != 0).sum()) < want["dx1_nonzero"]           # forward-time mask: the extreme elements sat on the borders
+        assert not torch.equal(grads[True], grads[False])
+    finally:
+        E.set_host_binding(saved)

@@ -25,7 +25,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, per_channel, out_q):
+def _worker(rank, world, port, per_channel, out_q, bounds=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -46,7 +46,7 @@ def _worker(rank, world, port, per_channel, out_q):
             return real_all_reduce(*a, **k)
         dist.all_reduce = counting_all_reduce
 
-        shape = (6, 8, 5, 5)
+        shape = (6, 8, 5, 5) if bounds is None else (bounds[-1], 8, 5, 5)
         n = int(np.prod(shape))
         x = synth.normal_like(n, 71, 0.3, 1.0).view(shape)
         g = synth.normal_like(n, 72, 0.0, 1e-2).view(shape)
@@ -64,12 +64,17 @@ def _worker(rank, world, port, per_channel, out_q):
         yf = lsq(xf, sf, bf, **kw)
         yf.backward(g)
         # this rank's shard
-        h = shape[0] // world
-        sl = slice(rank * h, (rank + 1) * h)
+        if bounds is None:       # equal shards: the global element count is local numel x world size (the default)
+            h = shape[0] // world
+            sl = slice(rank * h, (rank + 1) * h)
+            extra = {}
+        else:                    # UNEVEN shards (one of them may be empty): the caller states the global element count
+            sl = slice(bounds[rank], bounds[rank + 1])
+            extra = dict(global_numel=n)
         xs = x[sl].clone().requires_grad_(True)
         ss = scale.clone().requires_grad_(True)
         bs = shift.clone().requires_grad_(True)
-        ys = lsq_sharded(xs, ss, bs, **kw)
+        ys = lsq_sharded(xs, ss, bs, **kw, **extra)
         ys.backward(g[sl])
         ok = (torch.equal(ys, yf[sl]) and torch.equal(xs.grad, xf.grad[sl])
               and torch.allclose(ss.grad, sf.grad, rtol=1e-6, atol=0) and torch.allclose(bs.grad, bf.grad, rtol=1e-6, atol=1e-12)
@@ -92,5 +97,25 @@ def test_sharded_equals_unsharded_gloo_world2(per_channel):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    for rank, ok, ncalls, err in res:
+        assert ok, "rank %d: sharded != unsharded (all_reduce calls %d, max |ds err| %g)" % (rank, ncalls, err)
+
+
+@pytest.mark.parametrize("per_channel", [False, True])
+def test_uneven_shards_explicit_global_numel_gloo_world4(per_channel):
+    """world 4, shards of 5 / 1 / 3 / 2 rows of an 11-row batch: with `global_numel` given, the sharded op still equals the
+    unsharded one on the concatenated tensor (one all-reduce per backward on every rank)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    bounds = (0, 5, 6, 9, 11)
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, per_channel, q, bounds)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1, 2, 3]
     for rank, ok, ncalls, err in res:
         assert ok, "rank %d: sharded != unsharded (all_reduce calls %d, max |ds err| %g)" % (rank, ncalls, err)

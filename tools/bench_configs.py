@@ -13,6 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def main():
@@ -27,6 +28,8 @@ def main():
     from torchlsq import synth
     ops = torch.ops.torchlsq
     from torchlsq import extension as E
+    import lsq_tools  # noqa: E402  (tools build of the library: `_ex` entry points, lsq_hip_debug_* knobs)
+    lsq_tools.activate()
     pcv = (4 | (1 << 8) | (1 << 9) | (a.pc_bpc << 16)) if a.pc_bpc else 0
     dev = torch.device("cuda:0")
     out = {}

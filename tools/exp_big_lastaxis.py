@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import torchlsq  # noqa: F401
 from torchlsq import extension as E, synth
+import lsq_tools  # noqa: E402  (tools build of the library: `_ex` entry points, lsq_hip_debug_* knobs)
+lsq_tools.activate()
 from exp_dma_ab import timeit, code
 dev = torch.device("cuda:0")
 for shape, axis in (((32, 2048, 4096), 2), ((128, 512, 28, 28), 1), ((64, 64, 112, 112), 1), ((65536, 1024), 1)):

@@ -3,8 +3,11 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch, torchlsq
 from torchlsq import synth, extension as E
+import lsq_tools  # noqa: E402  (tools build of the library: `_ex` entry points, lsq_hip_debug_* knobs)
+lsq_tools.activate()
 dev = torch.device("cuda:0")
 def timeit(fn, reps=10):
     st = torch.cuda.Stream()

@@ -4,9 +4,12 @@ GPU-side us per backward incl. finalize, one MI355X."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import torchlsq  # noqa: F401
 from torchlsq import extension as E, synth
+import lsq_tools  # noqa: E402  (tools build of the library: `_ex` entry points, lsq_hip_debug_* knobs)
+lsq_tools.activate()
 lib = E.library()
 lib.lsq_hip_debug_set_fin_ch.argtypes = [ctypes.c_int]
 dev = torch.device("cuda:0")

@@ -3,11 +3,14 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import torchlsq
 from torchlsq import synth
 dev = torch.device("cuda:0")
 from torchlsq import extension as E
+import lsq_tools  # noqa: E402  (tools build of the library: `_ex` entry points, lsq_hip_debug_* knobs)
+lsq_tools.activate()
 import ctypes
 E._LIB.lsq_hip_debug_set_observe_wg_per_cu.argtypes = [ctypes.c_int]
 WG = int(sys.argv[1]) if len(sys.argv) > 1 else 0

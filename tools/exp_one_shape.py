@@ -4,6 +4,7 @@ usage: python3 tools/exp_one_shape.py 64,197,768 2 float32 [ww_big knob: 0 polic
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import torchlsq  # noqa: F401
 from torchlsq import synth
@@ -14,6 +15,8 @@ dev = torch.device("cuda:0")
 if len(sys.argv) > 4:
     import ctypes
     from torchlsq import extension as E
+    import lsq_tools  # noqa: E402  (tools build of the library: `_ex` entry points, lsq_hip_debug_* knobs)
+    lsq_tools.activate()
     E.library().lsq_hip_debug_set_ww_big.argtypes = [ctypes.c_int]
     E.library().lsq_hip_debug_set_ww_big(int(sys.argv[4]))
 n = 1

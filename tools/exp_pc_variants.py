@@ -3,9 +3,12 @@
 import ctypes, os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 from torchlsq import synth
-from torchlsq.extension import C_ABI, C_ABI_INTERNAL, LsqParams
+from torchlsq.extension import C_ABI, LsqParams
+import lsq_tools
+C_ABI_INTERNAL = lsq_tools.internal_abi()
 lib = ctypes.CDLL(os.path.join(ROOT, "tools", "_tune", "liblsq_hip_tune.so"))
 for tbl in (C_ABI, C_ABI_INTERNAL):
     for name, (res, args) in tbl.items():

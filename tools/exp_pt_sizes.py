@@ -3,9 +3,12 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import torchlsq  # noqa: F401
 from torchlsq import synth, extension as E
+import lsq_tools  # noqa: E402  (tools build of the library: `_ex` entry points, lsq_hip_debug_* knobs)
+lsq_tools.activate()
 dev = torch.device("cuda:0")
 
 

@@ -5,10 +5,13 @@ CU (the 16-bit backward is short of waves, not of bytes in flight).  Ring forced
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import torchlsq  # noqa: F401
 from torchlsq import extension as E, synth
-from torchlsq.extension import C_ABI, C_ABI_INTERNAL, LsqParams
+from torchlsq.extension import C_ABI, LsqParams
+import lsq_tools
+C_ABI_INTERNAL = lsq_tools.internal_abi()
 
 dev = torch.device("cuda:0")
 libs = {"4": E.library()}

@@ -5,12 +5,15 @@ brackets, results checked against each other (dx bits, d_scale/d_shift to 1e-6 o
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import torchlsq  # noqa: F401
 from torchlsq import extension as E, synth
+import lsq_tools  # noqa: E402  (tools build of the library: `_ex` entry points, lsq_hip_debug_* knobs)
+lsq_tools.activate()
 lib = E.library()
 lib.lsq_hip_debug_set_ww_big.argtypes = [ctypes.c_int]
-lib.lsq_hip_debug_last_launch.argtypes = [ctypes.POINTER(ctypes.c_int * 4)]
+lib.lsq_hip_debug_last_launch.argtypes = [ctypes.POINTER(ctypes.c_int * 8)]
 dev = torch.device("cuda:0")
 
 
@@ -48,7 +51,7 @@ for shape, axis in SHAPES:
             E._WS_BYTES_PC.clear()
             outs[knob] = E.hip_backward_per_channel(g, x, s, b, axis, *q)
             t = timeit(lambda: E.hip_backward_per_channel(g, x, s, b, axis, *q))
-            o = (ctypes.c_int * 4)(); lib.lsq_hip_debug_last_launch(ctypes.byref(o))
+            o = (ctypes.c_int * 8)(); lib.lsq_hip_debug_last_launch(ctypes.byref(o))
             res.append("%s %.1f us (%dx%d)" % ({2: "usual", 1: "big", 0: "policy"}[knob], t, o[0], o[1]))
         lib.lsq_hip_debug_set_ww_big(0)
         E._WS_BYTES_PC.clear()

@@ -4,13 +4,16 @@ workgroup (its partial row costs 16 bytes per slot) x workgroups per CU; GPU-sid
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 sys.argv = sys.argv[:1]
 import torch
 import torchlsq  # noqa: F401
 from torchlsq import extension as E, synth
+import lsq_tools  # noqa: E402  (tools build of the library: `_ex` entry points, lsq_hip_debug_* knobs)
+lsq_tools.activate()
 lib = E.library()
 lib.lsq_hip_debug_set_ww_min_rows.argtypes = [ctypes.c_int]
-lib.lsq_hip_debug_last_launch.argtypes = [ctypes.POINTER(ctypes.c_int * 4)]
+lib.lsq_hip_debug_last_launch.argtypes = [ctypes.POINTER(ctypes.c_int * 8)]
 dev = torch.device("cuda:0")
 
 
@@ -49,7 +52,7 @@ for shape, axis in (((64, 197, 768), 2), ((8192, 4096), 1), ((64, 56, 56, 256), 
                 for dma in (1, 2):
                     base = ((4 | (3 << 8)) if dt == torch.float32 else (1 | (3 << 8) | (1 << 10))) | (bpc << 16) | (dma << 12)
                     t = timeit(lambda: E.hip_backward_per_channel(g, x, s, b, axis, *q, variant=base))
-                    o = (ctypes.c_int * 4)(); lib.lsq_hip_debug_last_launch(ctypes.byref(o))
+                    o = (ctypes.c_int * 8)(); lib.lsq_hip_debug_last_launch(ctypes.byref(o))
                     row.append("%d/CU %s %.1f(%dx%d)" % (bpc, "reg" if dma == 1 else "dma", t, o[0], o[1]))
             out.append("min_rows %s: %s" % (mr or "rule", "  ".join(row)))
         lib.lsq_hip_debug_set_ww_min_rows(0)

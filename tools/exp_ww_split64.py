@@ -4,12 +4,15 @@ row groups (knob), default launch policy otherwise; GPU-side us per backward inc
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import torchlsq  # noqa: F401
 from torchlsq import extension as E, synth
+import lsq_tools  # noqa: E402  (tools build of the library: `_ex` entry points, lsq_hip_debug_* knobs)
+lsq_tools.activate()
 lib = E.library()
 lib.lsq_hip_debug_set_ww_split64.argtypes = [ctypes.c_int]
-lib.lsq_hip_debug_last_launch.argtypes = [ctypes.POINTER(ctypes.c_int * 4)]
+lib.lsq_hip_debug_last_launch.argtypes = [ctypes.POINTER(ctypes.c_int * 8)]
 dev = torch.device("cuda:0")
 
 
@@ -44,7 +47,7 @@ for shape, axis in (((64, 197, 768), 2), ((65536, 1024), 1), ((16384, 512), 1), 
             lib.lsq_hip_debug_set_ww_split64(knob)
             E._WS_BYTES_PC.clear()
             t = timeit(lambda: E.hip_backward_per_channel(g, x, s, b, axis, *q))
-            o = (ctypes.c_int * 4)(); lib.lsq_hip_debug_last_launch(ctypes.byref(o))
+            o = (ctypes.c_int * 8)(); lib.lsq_hip_debug_last_launch(ctypes.byref(o))
             res.append("%s %.1f us (%dx%d)" % ("64-lane x4" if knob else "whole rows", t, o[0], o[1]))
         lib.lsq_hip_debug_set_ww_split64(0)
         E._WS_BYTES_PC.clear()

@@ -5,13 +5,16 @@ per-row cost.  GPU-side us per backward incl. finalize (HIP graph of 20), (windo
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import torchlsq  # noqa: F401
 from torchlsq import extension as E, synth
+import lsq_tools  # noqa: E402  (tools build of the library: `_ex` entry points, lsq_hip_debug_* knobs)
+lsq_tools.activate()
 lib = E.library()
 lib.lsq_hip_debug_set_ww_big.argtypes = [ctypes.c_int]
 lib.lsq_hip_debug_set_ww_min_rows.argtypes = [ctypes.c_int]
-lib.lsq_hip_debug_last_launch.argtypes = [ctypes.POINTER(ctypes.c_int * 4)]
+lib.lsq_hip_debug_last_launch.argtypes = [ctypes.POINTER(ctypes.c_int * 8)]
 dev = torch.device("cuda:0")
 
 
@@ -45,7 +48,7 @@ for shape in ((3152, 768), (12608, 768), (4096, 1024)):
                 lib.lsq_hip_debug_set_ww_big(big); lib.lsq_hip_debug_set_ww_min_rows(mr)
                 E._WS_BYTES_PC.clear()
                 t = timeit(lambda: E.hip_backward_per_channel(g, x, s, b, 1, *q))
-                o = (ctypes.c_int * 4)(); lib.lsq_hip_debug_last_launch(ctypes.byref(o))
+                o = (ctypes.c_int * 8)(); lib.lsq_hip_debug_last_launch(ctypes.byref(o))
                 res.append("%d: %.1f (%dx%d)" % (mr, t, o[0], o[1]))
             print("%-9s %-14s %-5s %s" % (str(dt).replace("torch.", ""), shape, "big" if big == 1 else "usual", "  ".join(res)), flush=True)
 lib.lsq_hip_debug_set_ww_big(0); lib.lsq_hip_debug_set_ww_min_rows(0)

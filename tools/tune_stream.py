@@ -25,7 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
 def build():
     os.makedirs(OUT, exist_ok=True)
     flags = ["-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
-             "-DLSQ_TUNING", "-shared"]
+             "-DLSQ_TOOLS", "-DLSQ_TUNING", "-shared"]
     srcs = [os.path.join(CSRC, f) for f in ("lsq_capi.hip", "lsq_per_tensor.hip", "lsq_per_channel.hip", "lsq_observe.hip")]
     srcs.append(os.path.join(ROOT, "tools", "stream_probe.hip"))
     cmd = ["/opt/rocm/bin/hipcc"] + flags + srcs + ["-o", SO]
@@ -53,7 +53,10 @@ def main():
         return
     import torch
     from torchlsq import synth
-    from torchlsq.extension import C_ABI_INTERNAL, LsqParams
+    from torchlsq.extension import LsqParams
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lsq_tools
+    C_ABI_INTERNAL = lsq_tools.internal_abi()
     lib = ctypes.CDLL(SO)
     for name, (res, args) in C_ABI_INTERNAL.items():
         getattr(lib, name).restype = res
