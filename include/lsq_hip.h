@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LSQ_HIP_ABI_VERSION 2
+#define LSQ_HIP_ABI_VERSION 3
 
 /* Storage type of x / grad / y / dx.  Arithmetic is fp32 for F32, BF16 and F16 storage and fp64
  * for F64 (reference CPU path: AT_DISPATCH_FLOATING_TYPES, lsq_cpu.cpp:37,92,182,243).
@@ -162,6 +162,38 @@ int lsq_hip_backward_per_channel(int dtype, const void* grad, const void* x, voi
                                  int64_t inner, const void* scale, const void* shift,
                                  const lsq_params* p, const lsq_bwd_extras* extras, void* workspace,
                                  size_t workspace_bytes, void* stream);
+
+/* ---- many per-channel quantizers in one launch --------------------------------------------------- */
+
+/* The weight quantizers of a QAT model: one lsq_forward_per_channel / lsq_backward_per_channel pair per conv / linear layer
+ * and step in the reference (quantized/modules/observers.py:458-461 through lsq.cpp:104-134), each launch-latency-bound on a
+ * tensor of a few MB.  These entry points take the tensors of many such calls at once and put their channels into ONE grid
+ * (one launch per 32 tensors; no workspace, no finalize launch, HIP-graph capturable).
+ * `items` is a HOST array (read before the call returns); every pointer in it is a device pointer with the meaning of the
+ * same-named argument of the single-tensor entry points: the forward reads x, scale, shift and writes y; the backward reads
+ * grad, x, scale, shift and writes dx, ds[channels], db[channels].  All tensors share `dtype` and `p` (numel_for_scaler must
+ * be <= 0: every tensor's gradient scaler uses its own element count).  Every tensor must satisfy
+ * lsq_hip_per_channel_multi_ok -- the tensors the single-tensor launch policy walks with one workgroup per channel (long,
+ * packet-aligned channel rows, few outer indices: conv / linear weights quantized along axis 0); results are then bit-identical
+ * to the single-tensor calls (the same walk and summation order).  Other tensors go through the single-tensor entry points. */
+typedef struct lsq_pc_item {
+    const void* x;
+    const void* grad; /* backward only */
+    void* y;          /* forward only */
+    void* dx;         /* backward only */
+    const void* scale;
+    const void* shift;
+    void* ds; /* backward only */
+    void* db; /* backward only */
+    int64_t outer, channels, inner;
+} lsq_pc_item;
+
+/* 1 if a dense [outer, channels, inner] tensor of `dtype` may take part in a multi-tensor launch (aligned16: all its
+ * buffers are 16-byte aligned), 0 otherwise.  Host-only; depends on the current device's CU count. */
+int lsq_hip_per_channel_multi_ok(int dtype, int64_t outer, int64_t channels, int64_t inner, int aligned16);
+
+int lsq_hip_forward_per_channel_multi(int dtype, const lsq_pc_item* items, int32_t count, const lsq_params* p, void* stream);
+int lsq_hip_backward_per_channel_multi(int dtype, const lsq_pc_item* items, int32_t count, const lsq_params* p, void* stream);
 
 /* ---- eval-mode backward from the saved mask ---------------------------------------------------- */
 

@@ -235,6 +235,44 @@ int lsq_hip_backward_per_channel(int dtype, const void* grad, const void* x, voi
                                            p, extras, workspace, workspace_bytes, stream, 0);
 }
 
+int lsq_hip_per_channel_multi_ok(int dtype, int64_t outer, int64_t channels, int64_t inner, int aligned16) {
+    if (!dtype_ok(dtype)) return 0;
+    bool ok = false;
+    LSQ_DISPATCH_IO(dtype, ok = lsq::multi_eligible<IO>(outer, channels, inner, aligned16 != 0));
+    return ok ? 1 : 0;
+}
+
+static int multi_call(bool backward, int dtype, const lsq_pc_item* items, int32_t count, const lsq_params* p, void* stream) {
+    const char* what = backward ? "lsq_hip_backward_per_channel_multi" : "lsq_hip_forward_per_channel_multi";
+    if (int rc = check_common(dtype, p)) return rc;
+    if (count < 0) return fail(LSQ_EINVAL, "%s: negative item count", what);
+    if (count == 0) return LSQ_OK;
+    if (!items) return fail(LSQ_EINVAL, "%s: NULL item table", what);
+    if (p->numel_for_scaler > 0) return fail(LSQ_EINVAL, "%s: numel_for_scaler must be <= 0 (every tensor uses its own element count)", what);
+    for (int32_t i = 0; i < count; ++i) {
+        const lsq_pc_item& it = items[i];
+        if (!it.x || !it.scale || !it.shift || (backward ? (!it.grad || !it.dx || !it.ds || !it.db) : !it.y))
+            return fail(LSQ_EINVAL, "%s: item %d has a NULL buffer", what, i);
+        const bool aligned = lsq::is_aligned16(it.x) && (backward ? lsq::is_aligned16(it.grad) && lsq::is_aligned16(it.dx) : lsq::is_aligned16(it.y));
+        if (!lsq_hip_per_channel_multi_ok(dtype, it.outer, it.channels, it.inner, aligned ? 1 : 0))
+            return fail(LSQ_EINVAL, "%s: item %d ([%lld, %lld, %lld]) cannot take part in a multi-tensor launch "
+                                    "(lsq_hip_per_channel_multi_ok); use the single-tensor entry point", what, i,
+                        static_cast<long long>(it.outer), static_cast<long long>(it.channels), static_cast<long long>(it.inner));
+    }
+    hipError_t e = hipSuccess;
+    if (backward) { LSQ_DISPATCH_IO(dtype, e = lsq::backward_per_channel_multi<IO>(items, count, *p, static_cast<hipStream_t>(stream))); }
+    else { LSQ_DISPATCH_IO(dtype, e = lsq::forward_per_channel_multi<IO>(items, count, *p, static_cast<hipStream_t>(stream))); }
+    return hip_status(e, what);
+}
+
+int lsq_hip_forward_per_channel_multi(int dtype, const lsq_pc_item* items, int32_t count, const lsq_params* p, void* stream) {
+    return multi_call(false, dtype, items, count, p, stream);
+}
+
+int lsq_hip_backward_per_channel_multi(int dtype, const lsq_pc_item* items, int32_t count, const lsq_params* p, void* stream) {
+    return multi_call(true, dtype, items, count, p, stream);
+}
+
 int lsq_hip_backward_from_mask(int dtype, const void* grad, const void* mask, void* dx, int64_t n, void* stream) {
     if (!dtype_ok(dtype)) return fail(LSQ_EINVAL, "unknown dtype code %d", dtype);
     if (n < 0) return fail(LSQ_EINVAL, "negative element count");
@@ -253,6 +291,10 @@ void lsq_hip_debug_set_ww_split64(int v) { lsq::knob::set(lsq::knob::kWwSplit64,
 void lsq_hip_debug_set_ww_big(int v) { lsq::knob::set(lsq::knob::kWwBig, v); }
 void lsq_hip_debug_set_ring_nt(int v) { lsq::knob::set(lsq::knob::kRingNt, v); }
 void lsq_hip_debug_set_fin_ch(int v) { lsq::knob::set(lsq::knob::kFinCh, v); }
+
+#ifdef LSQ_TIMELINE
+void lsq_hip_debug_set_timeline(void* device_buffer) { lsq::knob::timeline_buffer().store(static_cast<unsigned long long*>(device_buffer)); }
+#endif
 
 void lsq_hip_debug_last_launch(int* out8) {
     const lsq::LaunchNote& n = lsq::last_launch_note();

@@ -68,6 +68,12 @@ inline void set(Id id, int v) { slot(id).store(v); }
 #else
 constexpr int get(Id) { return 0; }
 #endif
+#if defined(LSQ_TOOLS) && defined(LSQ_TIMELINE)
+inline std::atomic<unsigned long long*>& timeline_buffer() {     // lsq_hip_debug_set_timeline (experiment build)
+    static std::atomic<unsigned long long*> p{nullptr};
+    return p;
+}
+#endif
 // all geometry knobs as one key (the workspace memo of lsq_capi.hip)
 inline int geometry_key() { return get(kWwMinRows) | (get(kWwSplit64) << 16) | (get(kWwBig) << 20) | (get(kRingNt) << 24); }
 }  // namespace knob
@@ -326,6 +332,14 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
                                 int64_t outer, int64_t channels, int64_t inner, const void* scale,
                                 const void* shift, const lsq_params& p, void* workspace, size_t workspace_bytes,
                                 uint32_t* ticket, int variant, hipStream_t stream, size_t* plan_need = nullptr);
+
+// many per-channel quantizers in one launch (lsq_multi.hip)
+template <typename IO>
+bool multi_eligible(int64_t outer, int64_t channels, int64_t inner, bool aligned16);
+template <typename IO>
+hipError_t forward_per_channel_multi(const lsq_pc_item* items, int32_t count, const lsq_params& p, hipStream_t stream);
+template <typename IO>
+hipError_t backward_per_channel_multi(const lsq_pc_item* items, int32_t count, const lsq_params& p, hipStream_t stream);
 
 template <typename IO>
 hipError_t backward_from_mask(const void* grad, const void* mask, void* dx, int64_t n, hipStream_t stream);

@@ -126,6 +126,9 @@ struct PcGeom {
     int32_t ww_lanes;        // row-group windows (make_geom_ww): lanes per row group; 0 otherwise
     int32_t block_threads;   // workgroup size to launch (kBlock except for row-group windows)
     int32_t ring_nt;         // LDS-DMA ring: issue its copies with the streaming hint (global_load_lds ... nt)
+#ifdef LSQ_TIMELINE
+    unsigned long long* timeline;   // experiment build (tools/exp_timeline.py): 8 x u64 per wave of the window backward
+#endif
 };
 
 // How many workgroups along the row axis?  `want` is what the caller asked for (workgroups per CU x CUs / windows).
@@ -181,6 +184,9 @@ static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec,
     g.ww_lanes = 0;
     g.block_threads = kBlock;
     g.ring_nt = 0;
+#ifdef LSQ_TIMELINE
+    g.timeline = nullptr;
+#endif
     // keep the partial-sum traffic (16 B per slot per workgroup) below ~5 % of the streamed bytes -- except for small
     // tensors (< 2 M elements), which are latency- not traffic-bound: there a workgroup takes as few rows as the grid
     // target allows ([128, 768]: 128 workgroups of one row instead of 7 walking 21 rows one group after the other)
@@ -212,6 +218,9 @@ static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_
                                   bool split64 = false, int block = kBlock) {
     PcGeom g;
     g.ring_nt = 0;
+#ifdef LSQ_TIMELINE
+    g.timeline = nullptr;
+#endif
     g.outer = outer; g.C = C; g.inner = 1; g.L = C; g.vec = vec;
     g.fits32 = (g.L + static_cast<int64_t>(kBlock) * vec) < 0x7fffffffLL ? 1 : 0;
     const int64_t lanes_per_row = g.L / vec;
@@ -337,6 +346,8 @@ static inline SegGeom make_seg_geom(int64_t outer, int64_t C, int64_t inner, int
 // The (o, sub-row) pairs a workgroup walks, flattened: it -> (o_begin + it / n_r, r_begin + it % n_r)
 struct SegWalk {
     int64_t c, o_begin, r_begin, n_r, n_it;
+    // a whole channel by one workgroup (segs == osplits == 1): the multi-tensor kernels, channel `ch` of their item
+    __device__ __forceinline__ SegWalk(const SegGeom& g, int64_t ch) : c(ch), o_begin(0), r_begin(0), n_r(g.n_sub), n_it(g.n_sub * g.outer) {}
     __device__ __forceinline__ SegWalk(const SegGeom& g) {
         c = blockIdx.x / g.segs;
         const int64_t seg = blockIdx.x - c * g.segs;

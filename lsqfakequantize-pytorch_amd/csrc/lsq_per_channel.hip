@@ -30,6 +30,7 @@
 // by L2) and masks its effects.  No global atomics, no zero-initialised buffers.
 #include "lsq_kernels.hpp"
 #include "lsq_pc_geom.hpp"
+#include "lsq_seg_body.hpp"
 
 namespace lsq {
 
@@ -309,6 +310,13 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
     using E = typename IO::elem;
     using LC = LaneChannels<T, V, CPL>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef LSQ_TIMELINE     // experiment build: shader-clock stamps per wave (tools/exp_timeline.py)
+    const unsigned long long tl0 = __builtin_readcyclecounter();
+    unsigned long long tl1 = 0, tl2 = 0, tl_wait = 0;
+#define LSQ_TL_WAIT(stmt) do { const unsigned long long a_ = __builtin_readcyclecounter(); stmt; tl_wait += __builtin_readcyclecounter() - a_; } while (0)
+#else
+#define LSQ_TL_WAIT(stmt) stmt
+#endif
     static_assert(!WW || (CPL == V && V > 1), "row-group windows: one channel per packet component");
     static_assert(BLOCK == kBlock || (WW && DMA > 0), "768/1024-lane workgroups: row-group windows on the ring only");
     QSlot<T>* table = reinterpret_cast<QSlot<T>*>(smem);
@@ -491,6 +499,9 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
         for (int u = 0; u < UNROLL; ++u) emit_row(walk.row(i0 + u < last ? i0 + u : last), gb[u], xb[u], i0 + u <= last);
     };
     int64_t i = 0;
+#ifdef LSQ_TIMELINE
+    tl1 = __builtin_readcyclecounter();
+#endif
     if constexpr (DMA > 0) {
         // Row i was requested DMA rows ago.  Younger than its two copies are the copies of rows i+1 .. i+DMA-1 (two each)
         // and the dx stores in between; only the copies are counted (a wave without a valid lane skips its stores), so
@@ -530,8 +541,8 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
                 auto block = [&](auto first_block) {
 #pragma unroll
                     for (int u = 0; u < DMA; ++u) {
-                        if (decltype(first_block)::value) wait_vm_upto(2 * (DMA - 1) + u);
-                        else wait_vm<2 * (DMA - 1) + DMA>();
+                        if (decltype(first_block)::value) LSQ_TL_WAIT(wait_vm_upto(2 * (DMA - 1) + u));
+                        else LSQ_TL_WAIT((wait_vm<2 * (DMA - 1) + DMA>()));
                         const unsigned char* stage = ring + u * kDmaStageBytes + lane * 16;
                         const V4 graw = *reinterpret_cast<const V4*>(stage);
                         const V4 xraw = *reinterpret_cast<const V4*>(stage + 64 * 16);
@@ -562,12 +573,12 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
             // row of the wave stores (see above); otherwise they are left out of the count (the wait is then longer).
             auto stores = [&](int64_t row) { return decltype(all_valid)::value ? static_cast<int>(row < DMA ? row : DMA) : 0; };
             for (; i + DMA < dma_n; ++i) {           // the ring is full, one refill per row
-                wait_vm_upto(2 * (DMA - 1) + stores(i));
+                LSQ_TL_WAIT(wait_vm_upto(2 * (DMA - 1) + stores(i)));
                 consume(i, true, all_valid);
                 if (PRE32 && (i & (kPreRows - 1)) == kPreRows - 1) flush_pre(std::true_type{});
             }
             for (; i < dma_n; ++i) {                 // the last DMA rows: nothing left to request
-                wait_vm_upto(static_cast<int>(2 * (dma_n - 1 - i)) + stores(i));
+                LSQ_TL_WAIT(wait_vm_upto(static_cast<int>(2 * (dma_n - 1 - i)) + stores(i)));
                 consume(i, false, all_valid);
                 if (PRE32 && (i & (kPreRows - 1)) == kPreRows - 1) flush_pre(std::true_type{});
             }
@@ -639,6 +650,22 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
         if constexpr (UNROLL >= 4) if (i + 2 <= walk.n_rows) { group(i, std::integral_constant<int, 2>{}); i += 2; }
         if constexpr (UNROLL >= 2) if (i < walk.n_rows) group(i, std::integral_constant<int, 1>{});
     }
+#ifdef LSQ_TIMELINE
+    tl2 = __builtin_readcyclecounter();
+    auto tl_record = [&]() {
+        if (g.timeline && (threadIdx.x & 63) == 0) {
+            const int64_t wave = ((static_cast<int64_t>(blockIdx.y) * g.n_windows + blockIdx.x) * (BLOCK / 64)) + (threadIdx.x >> 6);
+            unsigned long long* rec = g.timeline + wave * 8;
+            unsigned int hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            unsigned int xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            rec[0] = tl0; rec[1] = tl1; rec[2] = tl2; rec[3] = __builtin_readcyclecounter(); rec[4] = tl_wait;
+            rec[5] = static_cast<unsigned long long>(walk.n_tiles_split); rec[6] = hw; rec[7] = xcc;
+        }
+    };
+    if (EVAL) { tl_record(); return; }
+#endif
     if (EVAL) return;
     if constexpr (PAIRS && LC::N == 1) {     // one channel per lane: even + odd components
         acc_s[0] += acc_s[1];
@@ -670,6 +697,9 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
                 out[j * w + lane_in_group] = make_double2(ts, tb);
             }
         }
+#ifdef LSQ_TIMELINE
+        tl_record();
+#endif
         return;
     }
 
@@ -711,6 +741,10 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
     const int64_t block_linear = static_cast<int64_t>(blockIdx.y) * g.n_windows + blockIdx.x;
     double2* out = partials + block_linear * g.k_slots;
     for (int k = threadIdx.x; k < g.k_slots; k += kBlock) out[k] = make_double2(lds_s[k], lds_b[k]);
+#ifdef LSQ_TIMELINE
+    tl_record();
+#endif
+#undef LSQ_TL_WAIT
 }
 
 // Finalize (window mode): folds, in a fixed order, every (split, window) partial that can hold a piece
@@ -851,81 +885,10 @@ __global__ __launch_bounds__(kBlock) void fwd_seg_kernel(const void* __restrict_
                                                          const typename IO::arith* __restrict__ scale,
                                                          const typename IO::arith* __restrict__ shift,
                                                          Range<typename IO::arith> r) {
-    using T = typename IO::arith;
-    using E = typename IO::elem;
-    const SegWalk w(g);
-    const QParams<T> q = make_qparams<T>(sanitize_scale_per_channel<T>(scale[w.c]), shift[w.c], r);
-    const T bias = static_cast<T>(level_bias);
-    const int64_t W = static_cast<int64_t>(kBlock) * V;
-    const int64_t q0 = static_cast<int64_t>(threadIdx.x) * V;
-    const int64_t q_last = (g.inner - V);   // last packet of a channel row (inner % V == 0)
-
-    // iteration it -> element index of the lane's packet (clamped into the row) and its validity
-    auto site = [&](int64_t it, bool& valid) {
-        const int64_t oi = static_cast<int64_t>(static_cast<uint32_t>(it) / static_cast<uint32_t>(w.n_r));
-        const int64_t ri = it - oi * w.n_r;
-        const int64_t pos = (w.r_begin + ri) * W + q0;
-        valid = pos < g.inner;
-        return ((w.o_begin + oi) * g.C + w.c) * g.inner + (valid ? pos : q_last);
-    };
-    auto emit = [&](int64_t e, const E (&in)[V], bool valid) {
-        E out[V];
-        LevelPack<V> lv;
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-            const T xv = static_cast<T>(in[j]);
-            const T c = clamped<T>(xv, q, r);
-            out[j] = IO::to_elem(INIT ? xv : dequant<T>(rne(c), q));
-            if (LEVELS) lv.b[j] = aux_byte<T>(c, r, bias, aux_kind);
-        }
-        if (valid) {
-            store_elems<IO, V, NTS>(y, e, out);
-            if (LEVELS) lv.store(levels + e);
-        }
-    };
-    // n_it = full groups of UNROLL + (if left) one group of UNROLL/2 + ... + one single iteration: every slot of
-    // every group is a real iteration (a padded last group would load and compute for nothing; a weight channel has
-    // only a handful of iterations, so that was up to half of the kernel's work)
-    auto group = [&](int64_t it, auto width) {
-        constexpr int H = decltype(width)::value;
-        E in[H][V];
-        int64_t e[H];
-        bool ok[H];
-#pragma unroll
-        for (int u = 0; u < H; ++u) {
-            e[u] = site(it + u, ok[u]);
-            load_elems<IO, V, NTL>(x, e[u], in[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < H; ++u) emit(e[u], in[u], ok[u]);
-    };
-    int64_t it = 0;
-    for (; it + UNROLL <= w.n_it; it += UNROLL) group(it, std::integral_constant<int, UNROLL>{});
-    if constexpr (UNROLL >= 8) if (it + 4 <= w.n_it) { group(it, std::integral_constant<int, 4>{}); it += 4; }
-    if constexpr (UNROLL >= 4) if (it + 2 <= w.n_it) { group(it, std::integral_constant<int, 2>{}); it += 2; }
-    if constexpr (UNROLL >= 2) if (it < w.n_it) group(it, std::integral_constant<int, 1>{});
+    seg_forward<IO, V, INIT, LEVELS, UNROLL, NTL, NTS>(x, y, levels, level_bias, aux_kind, g, SegWalk(g), scale, shift, r);
 }
 
-// Segment mode with ONE workgroup per channel (segs == osplits == 1: every conv / linear weight whose channel row is
-// not worth splitting -- the usual weight quantizer): the workgroup's sums ARE the channel's sums, so the kernel
-// rounds and stores d_scale / d_shift itself and the finalize launch (3-4 us, a third of the backward of a
-// BASELINE-config-3-sized weight) disappears.  ds == nullptr selects the partials + finalize route.
-template <typename T>
-struct SegDirect {
-    T* ds;
-    T* db;
-    double* wide;
-    T sym_term;
-    __device__ __forceinline__ void write(int64_t c, int64_t C, double ts, double tb) const {
-        ds[c] = static_cast<T>(ts);
-        db[c] = static_cast<T>(tb);
-        if (wide) {
-            wide[c] = ts;
-            wide[C + c] = tb;
-        }
-    }
-};
-
+// (SegDirect, seg_forward, seg_backward: lsq_seg_body.hpp)
 template <typename IO, int V, bool SYM, bool INIT, bool EVAL, int UNROLL, bool NTL, bool NTS>
 __global__ __launch_bounds__(kBlock) void bwd_seg_kernel(const void* __restrict__ grad, const void* __restrict__ x,
                                                          void* __restrict__ dx, SegGeom g,
@@ -934,78 +897,8 @@ __global__ __launch_bounds__(kBlock) void bwd_seg_kernel(const void* __restrict_
                                                          Range<typename IO::arith> r, typename IO::arith grad_scaler,
                                                          double2* __restrict__ partials,
                                                          SegDirect<typename IO::arith> direct) {
-    using T = typename IO::arith;
-    using E = typename IO::elem;
-    __shared__ double2 wave_tot[kBlock / 64];
-    const SegWalk w(g);
-    const QParams<T> q = make_qparams<T>(sanitize_scale_per_channel<T>(scale[w.c]), shift[w.c], r);
-    const int64_t W = static_cast<int64_t>(kBlock) * V;
-    const int64_t q0 = static_cast<int64_t>(threadIdx.x) * V;
-    const int64_t q_last = (g.inner - V);
-    double acc_s = 0.0, acc_b = 0.0;
-
-    auto site = [&](int64_t it, bool& valid) {
-        const int64_t oi = static_cast<int64_t>(static_cast<uint32_t>(it) / static_cast<uint32_t>(w.n_r));
-        const int64_t ri = it - oi * w.n_r;
-        const int64_t pos = (w.r_begin + ri) * W + q0;
-        valid = pos < g.inner;
-        return ((w.o_begin + oi) * g.C + w.c) * g.inner + (valid ? pos : q_last);
-    };
-    auto emit = [&](int64_t e, const E (&gi)[V], const E (&xi)[V], bool valid) {
-        E out[V];
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-            const T gv = static_cast<T>(gi[j]), xv = static_cast<T>(xi[j]);
-            if (EVAL) {
-                out[j] = IO::to_elem(backward_elem_eval<T, INIT>(gv, xv, q, r));
-            } else {
-                T ds_t, db_t;
-                out[j] = IO::to_elem(backward_elem<T, SYM, INIT>(gv, xv, q, r, grad_scaler, ds_t, db_t));
-                if (!valid) { ds_t = static_cast<T>(0); db_t = static_cast<T>(0); }
-                acc_s += static_cast<double>(ds_t);
-                if (!SYM) acc_b += static_cast<double>(db_t);
-            }
-        }
-        if (valid) store_elems<IO, V, NTS>(dx, e, out);
-    };
-    auto group = [&](int64_t it, auto width) {     // see fwd_seg_kernel: groups of UNROLL, then UNROLL/2, ..., 1
-        constexpr int H = decltype(width)::value;
-        E gi[H][V], xi[H][V];
-        int64_t e[H];
-        bool ok[H];
-#pragma unroll
-        for (int u = 0; u < H; ++u) {
-            e[u] = site(it + u, ok[u]);
-            load_elems<IO, V, NTL>(grad, e[u], gi[u]);
-            load_elems<IO, V, NTL>(x, e[u], xi[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < H; ++u) emit(e[u], gi[u], xi[u], ok[u]);
-    };
-    int64_t it = 0;
-    for (; it + UNROLL <= w.n_it; it += UNROLL) group(it, std::integral_constant<int, UNROLL>{});
-    if constexpr (UNROLL >= 8) if (it + 4 <= w.n_it) { group(it, std::integral_constant<int, 4>{}); it += 4; }
-    if constexpr (UNROLL >= 4) if (it + 2 <= w.n_it) { group(it, std::integral_constant<int, 2>{}); it += 2; }
-    if constexpr (UNROLL >= 2) if (it < w.n_it) group(it, std::integral_constant<int, 1>{});
-    if (EVAL) {
-        if (direct.ds && threadIdx.x == 0) direct.write(w.c, g.C, 0.0, 0.0);   // d_scale = d_shift = 0 (lsq_kernel.h:142-144)
-        return;
-    }
-    acc_s = wave_sum(acc_s);
-    acc_b = wave_sum(acc_b);
-    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = make_double2(acc_s, acc_b);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double ts = 0.0, tb = 0.0;
-#pragma unroll
-        for (int k = 0; k < kBlock / 64; ++k) { ts += wave_tot[k].x; tb += wave_tot[k].y; }
-        if (direct.ds) {   // this workgroup holds the channel's only partial: finish here, no finalize launch
-            if (SYM) tb = 0.0 + static_cast<double>(direct.sym_term);
-            direct.write(w.c, g.C, ts, tb);
-        } else {
-            partials[static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = make_double2(ts, tb);
-        }
-    }
+    seg_backward<IO, V, SYM, INIT, EVAL, UNROLL, NTL, NTS>(grad, x, dx, g, SegWalk(g), scale, shift, r, grad_scaler, partials,
+                                                           static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x, direct);
 }
 
 // Finalize (segment mode): fin_ch channels x (256 / fin_ch) interleaved slices of the (osplit, seg) partials.
@@ -1235,6 +1128,9 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
     if (seg) {
         const SegGeom sg = make_seg_geom(outer, channels, inner, vec, target);
         if (!grid_fits(sg)) return hipErrorInvalidConfiguration;
+#ifdef LSQ_TOOLS
+        last_launch_note() = LaunchNote{static_cast<int>(sg.C * sg.segs), sg.osplits, 0, 0, 3, 0, kBlock, 0};
+#endif
         if (p.init_mode) {
             return levels ? launch_fwd_seg<IO, true, true>(x, y, levels, bias, aux_kind, sg, scale, shift, p, v, stream)
                           : launch_fwd_seg<IO, true, false>(x, y, levels, bias, aux_kind, sg, scale, shift, p, v, stream);
@@ -1270,6 +1166,9 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
         }
     }
     if (!grid_fits(g)) return hipErrorInvalidConfiguration;
+#ifdef LSQ_TOOLS
+    last_launch_note() = LaunchNote{static_cast<int>(g.n_windows), g.splits, 0, 0, 1, vv.dma == 2 ? kFwdDmaDepth : 0, kBlock, g.ring_nt};
+#endif
     if (vec == 1) return fwd_pc_modes<IO, 1, 1>(x, y, levels, bias, aux_kind, g, scale, shift, p, vv, stream);
     if (cpl == 1) return fwd_pc_modes<IO, IO::VEC, 1>(x, y, levels, bias, aux_kind, g, scale, shift, p, vv, stream);
     if (cpl == 2) return fwd_pc_modes<IO, IO::VEC, 2>(x, y, levels, bias, aux_kind, g, scale, shift, p, vv, stream);
@@ -1368,6 +1267,9 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
         }
         PcGeom g = geom(per_cu * dev.cu_count);
         g.ring_nt = ring_nt_for(c.outer * c.C * c.inner * static_cast<int64_t>(sizeof(typename IO::elem)), true, WW);
+#if defined(LSQ_TOOLS) && defined(LSQ_TIMELINE)
+        g.timeline = knob::timeline_buffer().load();
+#endif
         const int64_t tiles_each = g.n_tiles / std::max<int64_t>(1, g.splits);
         if (tiles_each < min_tiles || tiles_each > max_tiles) return false;
         if (!grid_fits(g)) { result = hipErrorInvalidConfiguration; return true; }

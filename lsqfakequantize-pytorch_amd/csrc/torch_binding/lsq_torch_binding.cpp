@@ -397,9 +397,10 @@ class LsqNode : public torch::autograd::Function<LsqNode> {
 };
 
 // quantops::ops::lsq (lsq.cpp:104-134): checks, per-channel broadcast of single-element parameters, routing.
-Tensor lsq(const Tensor& x, const Tensor& scale, const Tensor& shift, int64_t qmin, int64_t qmax, int64_t tmin,
+Tensor lsq_impl(const Tensor& x, const Tensor& scale, const Tensor& shift, int64_t qmin, int64_t qmax, int64_t tmin,
            int64_t tmax, int64_t axis, bool use_gs, double gs, bool is_affine, bool is_perchannel, bool eval_mode,
            bool init_mode, bool mask_backward) {
+    // (registered twice below with the reference's argument list: `lsq` = mask_backward true, `lsq_keep_input` = false)
     TORCH_CHECK(scale.dim() == 1, "scale should be a 1-D tensor, even in per tensor case(please, avoid torch.Scalar too)");
     TORCH_CHECK(shift.dim() == 1, "shift should be a 1-D tensor, even in per tensor case(please, avoid torch.Scalar too)");
     Tensor sc = scale, sh = shift;
@@ -410,6 +411,184 @@ Tensor lsq(const Tensor& x, const Tensor& scale, const Tensor& shift, int64_t qm
     }
     return LsqNode::apply(x, sc, sh, qmin, qmax, tmin, tmax, axis, use_gs, gs, !is_affine, is_perchannel, eval_mode, init_mode,
                           mask_backward);
+}
+
+// ---- many per-channel quantizers in one launch: lsq_hip_*_per_channel_multi behind one autograd node --------------------
+// (torchlsq.functional.lsq_foreach picks the tensors that qualify -- lsq_hip_per_channel_multi_ok -- and hands them over here;
+// the host cost per tensor is an output allocation and a table row)
+struct MultiCfg {
+    Scalars s;
+    std::vector<int64_t> axes;
+};
+
+void multi_rows(const std::vector<Tensor>& xs, const std::vector<Tensor>& scales, const std::vector<Tensor>& shifts,
+                const std::vector<int64_t>& axes, std::vector<lsq_pc_item>& rows, std::vector<Tensor>& keep, bool backward,
+                const char* what) {
+    const size_t n = xs.size();
+    rows.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        const Tensor& x = xs[i];
+        TORCH_CHECK(x.scalar_type() == xs[0].scalar_type(), what, ": all tensors must have the same floating-point type");
+        if (backward) dtype_code(x.scalar_type(), "lsq_backward"); else check_forward_types(x, scales[i], shifts[i]);
+        check_channel_args(x, scales[i], shifts[i], axes[i]);
+        require_gpu(what, {&xs[0], &x, &scales[i], &shifts[i]});
+        TORCH_CHECK(x.is_contiguous(), what, ": tensor ", i, " must be contiguous");
+        const Geometry g = geometry(x, axes[i]);
+        keep.push_back(scales[i].contiguous());
+        keep.push_back(shifts[i].contiguous());
+        lsq_pc_item& r = rows[i];
+        r = lsq_pc_item{};
+        r.x = x.data_ptr();
+        r.scale = keep[keep.size() - 2].data_ptr();
+        r.shift = keep[keep.size() - 1].data_ptr();
+        r.outer = g.outer; r.channels = g.channels; r.inner = g.inner;
+    }
+}
+
+class LsqForeachNode : public torch::autograd::Function<LsqForeachNode> {
+   public:
+    // (the tensors arrive as at::TensorList: that is the list type custom Functions recognise as differentiable inputs)
+    static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, at::TensorList tensors,
+                                                  std::vector<int64_t> axes, int64_t qmin, int64_t qmax, int64_t tmin,
+                                                  int64_t tmax, bool use_gs, double gs, bool sym, bool eval_mode, bool init_mode) {
+        at::AutoDispatchBelowADInplaceOrView below;
+        const size_t n = tensors.size() / 3;
+        std::vector<Tensor> xs(tensors.begin(), tensors.begin() + n), scales(tensors.begin() + n, tensors.begin() + 2 * n),
+            shifts(tensors.begin() + 2 * n, tensors.end());
+        const Scalars s{qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode};
+        std::vector<lsq_pc_item> rows;
+        std::vector<Tensor> keep;
+        multi_rows(xs, scales, shifts, axes, rows, keep, false, "lsq_forward_per_channel_multi");
+        torch::autograd::variable_list ys(n);
+        for (size_t i = 0; i < n; ++i) {
+            ys[i] = at::empty_like(xs[i]);
+            rows[i].y = ys[i].data_ptr();
+        }
+        const lsq_params p = pack(s);
+        c10::DeviceGuard guard(xs[0].device());
+        status(lsq_hip_forward_per_channel_multi(dtype_code(xs[0].scalar_type(), "lsq_forward"), rows.data(),
+                                                 static_cast<int32_t>(n), &p, stream_of(xs[0])),
+               "lsq_hip_forward_per_channel_multi");
+        ctx->save_for_backward(tensors.vec());
+        const int64_t flags = (use_gs ? 1 : 0) | (sym ? 2 : 0) | (eval_mode ? 8 : 0) | (init_mode ? 16 : 0);
+        ctx->saved_data["cfg"] = c10::IValue(std::vector<int64_t>{qmin, qmax, tmin, tmax, flags});
+        ctx->saved_data["axes"] = c10::IValue(axes);
+        ctx->saved_data["gs"] = gs;
+        return ys;
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
+        const auto saved = ctx->get_saved_variables();
+        const size_t n = saved.size() / 3;
+        const std::vector<int64_t> cfg = ctx->saved_data["cfg"].toIntVector();
+        const std::vector<int64_t> axes = ctx->saved_data["axes"].toIntVector();
+        const int64_t flags = cfg[4];
+        const Scalars s{cfg[0], cfg[1], cfg[2], cfg[3], (flags & 1) != 0, ctx->saved_data["gs"].toDouble(), (flags & 2) != 0,
+                        (flags & 8) != 0, (flags & 16) != 0};
+        std::vector<Tensor> xs(saved.begin(), saved.begin() + n), scales(saved.begin() + n, saved.begin() + 2 * n),
+            shifts(saved.begin() + 2 * n, saved.end());
+        std::vector<lsq_pc_item> rows;
+        std::vector<Tensor> keep;
+        multi_rows(xs, scales, shifts, axes, rows, keep, true, "lsq_backward_per_channel_multi");
+        torch::autograd::variable_list out(3 * n + 10);
+        for (size_t i = 0; i < n; ++i) {
+            Tensor g = grads[i].defined() ? like_layout(grads[i], xs[i]) : at::zeros_like(xs[i]);
+            check_backward_types(g, xs[i], scales[i], shifts[i]);
+            if (reinterpret_cast<uintptr_t>(g.data_ptr()) & 15u) g = g.clone();
+            keep.push_back(g);
+            const auto popt = xs[i].options().dtype(param_type(xs[i].scalar_type()));
+            out[i] = at::empty_like(xs[i]);
+            out[n + i] = at::empty({rows[i].channels}, popt);
+            out[2 * n + i] = at::empty({rows[i].channels}, popt);
+            rows[i].grad = g.data_ptr();
+            rows[i].dx = out[i].data_ptr();
+            rows[i].ds = out[n + i].data_ptr();
+            rows[i].db = out[2 * n + i].data_ptr();
+        }
+        const lsq_params p = pack(s);
+        c10::DeviceGuard guard(xs[0].device());
+        status(lsq_hip_backward_per_channel_multi(dtype_code(xs[0].scalar_type(), "lsq_backward"), rows.data(),
+                                                  static_cast<int32_t>(n), &p, stream_of(xs[0])),
+               "lsq_hip_backward_per_channel_multi");
+        return out;
+    }
+};
+
+Tensor lsq_impl(const Tensor& x, const Tensor& scale, const Tensor& shift, int64_t qmin, int64_t qmax, int64_t tmin,
+                int64_t tmax, int64_t axis, bool use_gs, double gs, bool is_affine, bool is_perchannel, bool eval_mode,
+                bool init_mode, bool mask_backward);
+
+// `lsq(x_i, scale_i, shift_i, ..., is_perchannel = true)` for every i, horizontally fused: the tensors that qualify
+// (lsq_hip_per_channel_multi_ok: one GPU, one storage type, contiguous, 16-byte aligned, channel rows the single-tensor policy
+// gives one workgroup each) share ONE autograd node and one launch per 32 of them each way; the others go through `lsq`.
+std::vector<Tensor> lsq_foreach(at::TensorList xs, at::TensorList scales, at::TensorList shifts, at::IntArrayRef axes, int64_t qmin,
+                                int64_t qmax, int64_t tmin, int64_t tmax, bool use_gs, double gs, bool is_affine, bool eval_mode,
+                                bool init_mode) {
+    const size_t n = xs.size();
+    TORCH_CHECK(scales.size() == n && shifts.size() == n && axes.size() == n, "lsq_foreach: xs, scales, shifts and axes must have the same length");
+    std::vector<Tensor> out(n);
+    std::vector<size_t> fused;
+    fused.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        const Tensor& x = xs[i];
+        bool ok = x.is_cuda() && scales[i].is_cuda() && shifts[i].is_cuda() && x.numel() > 0 && x.is_contiguous() &&
+                  axes[i] >= 0 && axes[i] < x.dim() && scales[i].dim() == 1 && shifts[i].dim() == 1 &&
+                  (reinterpret_cast<uintptr_t>(x.data_ptr()) & 15u) == 0;
+        if (ok && !fused.empty()) ok = x.device() == xs[fused[0]].device() && x.scalar_type() == xs[fused[0]].scalar_type();
+        if (ok) {
+            int code = -1;
+            switch (x.scalar_type()) {
+                case at::kFloat: code = LSQ_F32; break;
+                case at::kDouble: code = LSQ_F64; break;
+                case at::kBFloat16: code = LSQ_BF16; break;
+                case at::kHalf: code = LSQ_F16; break;
+                default: ok = false;
+            }
+            if (ok) {
+                const Geometry g = geometry(x, axes[i]);
+                c10::DeviceGuard guard(x.device());        // the answer depends on the device's CU count
+                ok = lsq_hip_per_channel_multi_ok(code, g.outer, g.channels, g.inner, 1) != 0;
+            }
+        }
+        if (ok) fused.push_back(i);
+        else out[i] = lsq_impl(x, scales[i], shifts[i], qmin, qmax, tmin, tmax, axes[i], use_gs, gs, is_affine, true, eval_mode, init_mode, true);
+    }
+    if (fused.size() == 1) {
+        const size_t i = fused[0];
+        out[i] = lsq_impl(xs[i], scales[i], shifts[i], qmin, qmax, tmin, tmax, axes[i], use_gs, gs, is_affine, true, eval_mode, init_mode, true);
+        fused.clear();
+    }
+    if (fused.empty()) return out;
+    const size_t m = fused.size();
+    torch::autograd::variable_list tensors;
+    std::vector<int64_t> ax;
+    tensors.reserve(3 * m);
+    ax.reserve(m);
+    for (size_t i : fused) { tensors.push_back(xs[i]); ax.push_back(axes[i]); }
+    for (size_t i : fused) {      // front-op rule (lsq.cpp:124-126): a size-1 parameter is repeated up to the other's size
+        const int64_t size = std::max(scales[i].size(0), shifts[i].size(0));
+        tensors.push_back(scales[i].size(0) == size ? scales[i] : scales[i].repeat({size}));
+    }
+    for (size_t i : fused) {
+        const int64_t size = std::max(scales[i].size(0), shifts[i].size(0));
+        tensors.push_back(shifts[i].size(0) == size ? shifts[i] : shifts[i].repeat({size}));
+    }
+    const auto ys = LsqForeachNode::apply(at::TensorList(tensors), ax, qmin, qmax, tmin, tmax, use_gs, gs, !is_affine, eval_mode, init_mode);
+    for (size_t k = 0; k < m; ++k) out[fused[k]] = ys[k];
+    return out;
+}
+
+Tensor lsq(const Tensor& x, const Tensor& scale, const Tensor& shift, int64_t qmin, int64_t qmax, int64_t tmin, int64_t tmax,
+           int64_t axis, bool use_gs, double gs, bool is_affine, bool is_perchannel, bool eval_mode, bool init_mode) {
+    return lsq_impl(x, scale, shift, qmin, qmax, tmin, tmax, axis, use_gs, gs, is_affine, is_perchannel, eval_mode, init_mode, true);
+}
+
+// the reference's eval-mode backward to the letter: x is saved, the mask is recomputed from the parameters as they are at
+// backward time (lsq_autograd.cpp:46-73) -- what LSQFakeQuantizer asks for while its observer rewrites them on every call
+Tensor lsq_keep_input(const Tensor& x, const Tensor& scale, const Tensor& shift, int64_t qmin, int64_t qmax, int64_t tmin,
+                      int64_t tmax, int64_t axis, bool use_gs, double gs, bool is_affine, bool is_perchannel, bool eval_mode,
+                      bool init_mode) {
+    return lsq_impl(x, scale, shift, qmin, qmax, tmin, tmax, axis, use_gs, gs, is_affine, is_perchannel, eval_mode, init_mode, false);
 }
 
 }  // namespace
@@ -431,9 +610,14 @@ TORCH_LIBRARY(torchlsq_native, m) {
     m.def("lsq_backward_from_mask(Tensor grad, Tensor mask) -> Tensor");
     // composite (autograd handled by the node inside), like the reference's front op
     m.def("lsq(Tensor x, Tensor scale, Tensor shift, int quant_min, int quant_max, int type_min, int type_max, int axis, "
-          "bool use_grad_scaling, float grad_scale, bool is_affine, bool is_perchannel, bool eval_mode, bool init_mode, "
-          "bool mask_backward=True) -> Tensor",
+          "bool use_grad_scaling, float grad_scale, bool is_affine, bool is_perchannel, bool eval_mode, bool init_mode) -> Tensor",
           &lsq);
+    m.def("lsq_keep_input(Tensor x, Tensor scale, Tensor shift, int quant_min, int quant_max, int type_min, int type_max, int axis, "
+          "bool use_grad_scaling, float grad_scale, bool is_affine, bool is_perchannel, bool eval_mode, bool init_mode) -> Tensor",
+          &lsq_keep_input);
+    m.def("lsq_foreach(Tensor[] xs, Tensor[] scales, Tensor[] shifts, int[] axes, int quant_min, int quant_max, int type_min, "
+          "int type_max, bool use_grad_scaling, float grad_scale, bool is_affine, bool eval_mode, bool init_mode) -> Tensor[]",
+          &lsq_foreach);
     m.def("_abi_version() -> int", []() -> int64_t { return lsq_hip_abi_version(); });
     m.def("_set_single_launch_backward(bool on) -> ()", [](bool on) { g_use_ticket.store(on); });
 }

@@ -58,8 +58,15 @@ class LsqObserverUpdate(ctypes.Structure):
                 ("zero_point_symmetric", ctypes.c_int32), ("eps", ctypes.c_float)]
 
 
+class LsqPcItem(ctypes.Structure):
+    """struct lsq_pc_item (include/lsq_hip.h): one tensor of a multi-tensor launch."""
+    _fields_ = [("x", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("y", ctypes.c_void_p), ("dx", ctypes.c_void_p),
+                ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("ds", ctypes.c_void_p), ("db", ctypes.c_void_p),
+                ("outer", ctypes.c_int64), ("channels", ctypes.c_int64), ("inner", ctypes.c_int64)]
+
+
 LSQ_TICKET_BYTES = 4096
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
 _PP = ctypes.POINTER(LsqParams)
@@ -79,6 +86,9 @@ C_ABI = {
     "lsq_hip_forward_per_channel": (_int, [_int, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP, _EP, _vp]),
     "lsq_hip_backward_per_channel": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP, _BP,
                                             _vp, _sz, _vp]),
+    "lsq_hip_per_channel_multi_ok": (_int, [_int, _i64, _i64, _i64, _int]),
+    "lsq_hip_forward_per_channel_multi": (_int, [_int, ctypes.POINTER(LsqPcItem), ctypes.c_int32, _PP, _vp]),
+    "lsq_hip_backward_per_channel_multi": (_int, [_int, ctypes.POINTER(LsqPcItem), ctypes.c_int32, _PP, _vp]),
     "lsq_hip_backward_from_mask": (_int, [_int, _vp, _vp, _vp, _i64, _vp]),
     "lsq_hip_minmax_workspace": (_sz, [_int, _i64, _i64, _i64]),
     "lsq_hip_minmax_per_tensor": (_int, [_int, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
@@ -690,6 +700,100 @@ def hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax
     if want_wide:
         return dx, wide
     return dx, ds, db
+
+
+# ---- many per-channel quantizers in one launch (lsq_hip_*_per_channel_multi) ----------------------------------------------
+_MULTI_OK = {}
+
+
+def hip_multi_eligible(x, axis):
+    """Can the per-channel quantizer of GPU tensor `x` along `axis` take part in a multi-tensor launch?  (Tensors the
+    single-tensor policy walks with one workgroup per channel: conv / linear weights on axis 0 and the like.)"""
+    if not _HAS_OPS or not x.is_cuda or x.dtype not in _DTYPE_CODE or x.numel() == 0 or not (0 <= axis < x.dim()):
+        return False
+    if not x.is_contiguous() or (x.data_ptr() & 15):
+        return False
+    shape = tuple(x.shape)
+    key = (x.device.index, x.dtype, shape, axis)
+    hit = _MULTI_OK.get(key)
+    if hit is None:
+        outer, C, inner = _ocl(x, _ROW_MAJOR, axis)
+        hit = bool(_on_device(x.device.index, _LIB.lsq_hip_per_channel_multi_ok, _DTYPE_CODE[x.dtype], outer, C, inner, 1))
+        if len(_MULTI_OK) < 65536:
+            _MULTI_OK[key] = hit
+    return hit
+
+
+def _multi_table(n):
+    return (LsqPcItem * n)()
+
+
+def hip_forward_per_channel_multi(xs, scales, shifts, axes, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode):
+    """y_i = fake_quant(x_i) for every tensor of the lists in ONE launch per 32 tensors.  Every x_i must satisfy
+    hip_multi_eligible(x_i, axes[i]); all tensors on one GPU, one storage type."""
+    _assert_has_ops()
+    n = len(xs)
+    dev, dt = xs[0].device, xs[0].dtype
+    table = _multi_table(n)
+    ys = []
+    for i in range(n):
+        x, scale, shift = xs[i], scales[i], shifts[i]
+        check_forward_dtypes(x, scale, shift)
+        check_channel_args(x, scale, shift, axes[i], backward=False)
+        _require_gpu("lsq_forward_per_channel_multi", xs[0], x, scale, shift)
+        _check(x.dtype == dt, "lsq_forward_per_channel_multi: all tensors must have the same floating-point type")
+        _check(hip_multi_eligible(x, axes[i]), "lsq_forward_per_channel_multi: tensor %d cannot take part in a multi-tensor launch" % i)
+        y = torch.empty_like(x)
+        outer, C, inner = _ocl(x, _ROW_MAJOR, axes[i])
+        sc, sh = scale.contiguous(), shift.contiguous()
+        it = table[i]
+        it.x, it.y, it.scale, it.shift = x.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr()
+        it.outer, it.channels, it.inner = outer, C, inner
+        ys.append((y, sc, sh))
+    _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
+    idx = dev.index
+    rc = _on_device(idx, _LIB.lsq_hip_forward_per_channel_multi, _DTYPE_CODE[dt], table, n, pref, _stream_of(idx))
+    if rc:
+        _status(rc, "lsq_hip_forward_per_channel_multi")
+    return [y for y, _, _ in ys]
+
+
+def hip_backward_per_channel_multi(grads, xs, scales, shifts, axes, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode,
+                                   init_mode):
+    """(dx_i, ds_i, db_i) for every tensor of the lists in ONE launch per 32 tensors (no workspace, no finalize launch)."""
+    _assert_has_ops()
+    n = len(xs)
+    dev, dt = xs[0].device, xs[0].dtype
+    table = _multi_table(n)
+    outs, keep = [], []
+    for i in range(n):
+        x, g, scale, shift = xs[i], grads[i], scales[i], shifts[i]
+        check_backward_dtypes(g, x, scale, shift)
+        check_channel_args(x, scale, shift, axes[i], backward=True)
+        _require_gpu("lsq_backward_per_channel_multi", xs[0], x, g, scale, shift)
+        _check(x.dtype == dt, "lsq_backward_per_channel_multi: all tensors must have the same floating-point type")
+        _check(hip_multi_eligible(x, axes[i]), "lsq_backward_per_channel_multi: tensor %d cannot take part in a multi-tensor launch" % i)
+        gd = _like_layout(g, x)
+        if gd.data_ptr() & 15:
+            gd = gd.clone()
+        dx = torch.empty_like(x)
+        outer, C, inner = _ocl(x, _ROW_MAJOR, axes[i])
+        pd = _param_dtype(x)
+        ds = torch.empty(C, dtype=pd, device=dev)
+        db = torch.empty(C, dtype=pd, device=dev)
+        sc, sh = scale.contiguous(), shift.contiguous()
+        it = table[i]
+        it.x, it.grad, it.dx, it.scale, it.shift = x.data_ptr(), gd.data_ptr(), dx.data_ptr(), sc.data_ptr(), sh.data_ptr()
+        it.ds, it.db = ds.data_ptr(), db.data_ptr()
+        it.outer, it.channels, it.inner = outer, C, inner
+        outs.append((dx, ds, db))
+        keep.append((gd, sc, sh))
+    _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
+    idx = dev.index
+    rc = _on_device(idx, _LIB.lsq_hip_backward_per_channel_multi, _DTYPE_CODE[dt], table, n, pref, _stream_of(idx))
+    if rc:
+        _status(rc, "lsq_hip_backward_per_channel_multi")
+    return outs
 
 
 _WS_BYTES_MM = {}

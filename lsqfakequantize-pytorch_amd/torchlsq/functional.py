@@ -132,9 +132,10 @@ def lsq(x: Tensor, scale: Tensor, shift: Tensor,
         # front-op checks and routing of quantops::ops::lsq (lsq.cpp:104-134), then straight to the kernels
         native = _E._NATIVE_LSQ
         if native is not None:      # C++ front op + autograd node (csrc/torch_binding): same kernels, less host time
+            if not mask_backward:
+                native = torch.ops.torchlsq_native.lsq_keep_input.default
             return native(x, scale, shift, quant_min, quant_max, type_min, type_max, axis, bool(use_grad_scaling),
-                          float(grad_scaler), bool(is_affine), bool(is_perchannel), bool(eval_mode), bool(init_mode),
-                          bool(mask_backward))
+                          float(grad_scaler), bool(is_affine), bool(is_perchannel), bool(eval_mode), bool(init_mode))
         if scale.dim() != 1:
             raise RuntimeError("scale should be a 1-D tensor, even in per tensor case(please, avoid torch.Scalar too)")
         if shift.dim() != 1:
@@ -151,3 +152,97 @@ def lsq(x: Tensor, scale: Tensor, shift: Tensor,
     return torch.ops.torchlsq.lsq(x, scale, shift, quant_min, quant_max, type_min, type_max,
                                   axis, use_grad_scaling, grad_scaler, is_affine, is_perchannel,
                                   eval_mode, init_mode)
+
+
+class _LSQForeach(torch.autograd.Function):
+    """N per-channel quantizers as ONE autograd node over the multi-tensor kernels (lsq_hip_*_per_channel_multi): one launch
+    per 32 tensors each way instead of N.  Same arithmetic and summation order as N `lsq` calls (bit-identical outputs and
+    gradients); saves {x_i, scale_i, shift_i} like the reference's nodes (lsq_autograd.cpp:111-173)."""
+
+    @staticmethod
+    def forward(ctx, cfg, n, *tensors):
+        xs, scales, shifts = tensors[:n], tensors[n:2 * n], tensors[2 * n:]
+        (qmin, qmax, tmin, tmax, axes, use_gs, gs, sym, eval_mode, init_mode) = cfg
+        ys = _E.hip_forward_per_channel_multi(xs, scales, shifts, axes, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode,
+                                              init_mode)
+        ctx.save_for_backward(*tensors)
+        ctx.cfg, ctx.n = cfg, n
+        return tuple(ys)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grad_outs):
+        n = ctx.n
+        tensors = ctx.saved_tensors
+        xs, scales, shifts = tensors[:n], tensors[n:2 * n], tensors[2 * n:]
+        (qmin, qmax, tmin, tmax, axes, use_gs, gs, sym, eval_mode, init_mode) = ctx.cfg
+        grads = [g if g is not None else torch.zeros_like(x) for g, x in zip(grad_outs, xs)]
+        outs = _E.hip_backward_per_channel_multi(grads, xs, scales, shifts, axes, qmin, qmax, tmin, tmax, use_gs, gs, sym,
+                                                 eval_mode, init_mode)
+        return (None, None) + tuple(o[0] for o in outs) + tuple(o[1] for o in outs) + tuple(o[2] for o in outs)
+
+
+def lsq_foreach(xs, scales, shifts,
+                quant_min: int = 0,
+                quant_max: int = 255,
+                type_min: int = None,
+                type_max: int = None,
+                axis=0,
+                use_grad_scaling: bool = True,
+                grad_scaler: float = 1.,
+                is_affine: bool = True,
+                eval_mode: bool = False,
+                init_mode: bool = False):
+    """`lsq(x_i, scale_i, shift_i, ..., is_perchannel=True)` for every i, horizontally fused (an addition of this build).
+
+    The per-channel quantizers of many tensors -- typically all conv / linear weights of a QAT model, each a few MB and
+    launch-latency-bound on its own -- run in ONE launch per 32 tensors each way.  `axis` is one int or one per tensor; all
+    other arguments are shared and mean what they mean in `lsq`.  Returns the list of outputs; gradients reach every x_i,
+    scale_i, shift_i exactly as through N separate `lsq` calls (bit-identical).  Tensors the multi-tensor kernels do not take
+    (CPU tensors, channel rows too short or unaligned, tensors so small or so large that the single-tensor policy splits their
+    channels differently: `torchlsq.extension.hip_multi_eligible`) silently go through `lsq` one by one.
+    """
+    _assert_has_ops()
+    n = len(xs)
+    assert len(scales) == n and len(shifts) == n, "xs, scales and shifts must have the same length"
+    if not is_affine:
+        assert quant_min <= 0 <= quant_max, 'quantization range must be covered 0 in symmetric quantization'
+    type_min = quant_min if type_min is None else type_min
+    type_max = quant_max if type_max is None else type_max
+    axes = [int(axis)] * n if isinstance(axis, int) else [int(a) for a in axis]
+    assert len(axes) == n
+    fusable = not torch.jit.is_tracing() and not torch.compiler.is_compiling()
+    if fusable and n > 1 and _E._NATIVE_LSQ is not None and xs[0].is_cuda:
+        # C++ host layer: the partition into fused / single tensors, the checks and the one autograd node all happen there
+        # (a table row and an output allocation of host time per tensor instead of a Python call chain)
+        return list(torch.ops.torchlsq_native.lsq_foreach(list(xs), list(scales), list(shifts), axes, quant_min, quant_max,
+                                                          type_min, type_max, bool(use_grad_scaling), float(grad_scaler),
+                                                          bool(is_affine), bool(eval_mode), bool(init_mode)))
+    out = [None] * n
+    groups = {}
+    for i in range(n):
+        x, sc, sh = xs[i], scales[i], shifts[i]
+        if (fusable and x.is_cuda and sc.is_cuda and sh.is_cuda and sc.dim() == 1 and sh.dim() == 1
+                and _E.hip_multi_eligible(x, axes[i])):
+            groups.setdefault((x.device, x.dtype), []).append(i)
+        else:
+            out[i] = lsq(x, sc, sh, quant_min, quant_max, type_min, type_max, axes[i], use_grad_scaling, grad_scaler, is_affine,
+                         True, eval_mode, init_mode)
+    for idx in groups.values():
+        if len(idx) == 1:       # nothing to fuse
+            i = idx[0]
+            out[i] = lsq(xs[i], scales[i], shifts[i], quant_min, quant_max, type_min, type_max, axes[i], use_grad_scaling,
+                         grad_scaler, is_affine, True, eval_mode, init_mode)
+            continue
+        sc_l, sh_l = [], []
+        for i in idx:       # front-op rule (lsq.cpp:124-126): a size-1 parameter is repeated up to the other's size
+            sc, sh = scales[i], shifts[i]
+            size = max(sc.size(0), sh.size(0))
+            sc_l.append(sc if sc.size(0) == size else sc.repeat(size))
+            sh_l.append(sh if sh.size(0) == size else sh.repeat(size))
+        cfg = (quant_min, quant_max, type_min, type_max, tuple(axes[i] for i in idx), bool(use_grad_scaling), float(grad_scaler),
+               not is_affine, bool(eval_mode), bool(init_mode))
+        ys = _LSQForeach.apply(cfg, len(idx), *[xs[i] for i in idx], *sc_l, *sh_l)
+        for i, y in zip(idx, ys):
+            out[i] = y
+    return out

@@ -9,6 +9,7 @@ import torch
 from torch.ao.quantization import FakeQuantize as _FakeQuantize
 
 from .modules.observers import LSQFakeQuantizer
+from .modules.weight_group import LSQWeightGroup  # noqa: F401
 
 
 def _switch(name, method, only_dtype=None):
@@ -40,4 +41,4 @@ for _name, _method, _dtype in _TABLE:
     globals()[_name] = _switch(_name, _method, _dtype)
 del _name, _method, _dtype
 
-__all__ = ["LSQFakeQuantizer"] + [row[0] for row in _TABLE]
+__all__ = ["LSQFakeQuantizer", "LSQWeightGroup"] + [row[0] for row in _TABLE]

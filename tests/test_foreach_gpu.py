@@ -1,0 +1,149 @@
+"""GPU: many per-channel quantizers in one launch (lsq_hip_*_per_channel_multi -> functional.lsq_foreach -> LSQWeightGroup)
+against the same tensors through single calls: outputs and every gradient bit-identical."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(t):
+    t = t.detach().contiguous()
+    return t.view({1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[t.element_size()]).cpu().numpy().tobytes()
+
+
+def _weights(shapes, dtype, dev, seed):
+    from torchlsq import synth
+    xs, gs, ss, bs = [], [], [], []
+    for k, shape in enumerate(shapes):
+        n = int(np.prod(shape))
+        xs.append(synth.normal_like(n, seed + 4 * k, 0.0, 0.05, dtype=dtype, device=dev).view(shape))
+        gs.append(synth.normal_like(n, seed + 4 * k + 1, 0.0, 1e-3, dtype=dtype, device=dev).view(shape))
+        pdt = torch.float64 if dtype == torch.float64 else torch.float32
+        ss.append(synth.uniform_like(shape[0], seed + 4 * k + 2, 5e-4, 2.5e-3, device=dev, dtype=pdt))
+        bs.append(synth.normal_like(shape[0], seed + 4 * k + 3, 0.0, 1e-3, device=dev, dtype=pdt))
+    return xs, gs, ss, bs
+
+
+def _run(fn_each, xs, gs, ss, bs, kw, fused):
+    from torchlsq.functional import lsq, lsq_foreach
+    xl = [x.clone().requires_grad_(True) for x in xs]
+    sl = [s.clone().requires_grad_(True) for s in ss]
+    bl = [b.clone().requires_grad_(True) for b in bs]
+    if fused:
+        ys = lsq_foreach(xl, sl, bl, axis=0, **kw)
+    else:
+        ys = [lsq(x, s, b, axis=0, is_perchannel=True, **kw) for x, s, b in zip(xl, sl, bl)]
+    torch.autograd.backward(ys, gs)
+    torch.cuda.synchronize()
+    return ys, [x.grad for x in xl], [s.grad for s in sl], [b.grad for b in bl]
+
+
+@pytest.mark.parametrize("mode", ["sym", "affine", "eval", "init"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float64, torch.float16])
+def test_foreach_equals_single_calls_bit_for_bit(dtype, mode):
+    """conv / linear weight shapes of a CNN and a transformer block, a few that the multi-tensor kernels do not take
+    ([64,3,7,7]: 147 elements per channel, not packet-aligned; [10,64]: one short row per channel) and more than one launch's
+    worth (32) of them"""
+    from torchlsq import extension as E
+    dev = torch.device("cuda:0")
+    shapes = [(512, 512, 3, 3), (256, 128, 3, 3), (64, 3, 7, 7), (1024, 4096), (4096, 1024), (128, 64, 1, 1), (10, 64),
+              (64, 64, 3, 3)] + [(256, 256, 3, 3)] * 30 + [(2048, 2048)]
+    xs, gs, ss, bs = _weights(shapes, dtype, dev, 4000)
+    taken = [E.hip_multi_eligible(x, 0) for x in xs]
+    assert sum(taken) >= 33 and not all(taken), taken       # both routes, and more than one launch of 32
+    kw = dict(quant_min=-128, quant_max=127, type_min=-128, type_max=127, is_affine=(mode != "sym"),
+              eval_mode=(mode == "eval"), init_mode=(mode == "init"), use_grad_scaling=True, grad_scaler=0.5)
+    single = _run(None, xs, gs, ss, bs, kw, fused=False)
+    fused = _run(None, xs, gs, ss, bs, kw, fused=True)
+    for what, a, b in zip(("y", "dx", "d_scale", "d_shift"), single, fused):
+        for i, (u, v) in enumerate(zip(a, b)):
+            if u is None or v is None:
+                assert u is None and v is None, (what, i)
+                continue
+            assert u.shape == v.shape and _bits(u) == _bits(v), "%s of tensor %d %s differs (%s, %s)" % (what, i, shapes[i], dtype, mode)
+
+
+def test_fifty_conv_weights():
+    """the review's case: 50 x [512,512,3,3] fp32 qint8 per-channel weights (BASELINE config 3), forward + backward"""
+    dev = torch.device("cuda:0")
+    shapes = [(512, 512, 3, 3)] * 50
+    xs, gs, ss, bs = _weights(shapes, torch.float32, dev, 9000)
+    kw = dict(quant_min=-128, quant_max=127, type_min=-128, type_max=127, is_affine=False)
+    single = _run(None, xs, gs, ss, bs, kw, fused=False)
+    fused = _run(None, xs, gs, ss, bs, kw, fused=True)
+    for a, b in zip(single[:3], fused[:3]):
+        for u, v in zip(a, b):
+            assert _bits(u) == _bits(v)
+    # ... and against the reference digest of config 3 for a tensor generated like the golden one
+    from torchlsq import synth
+    import json, os
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_digests.json")))["configs"]["cfg3"]
+    x, g, scale, shift = synth.make_inputs("cfg3", device=dev, dtype=torch.float32)
+    from helpers import sha
+
+    def sha_t(t):
+        return sha(t.detach().contiguous().cpu().numpy())
+    ys, dxs, dss, _ = _run(None, [x, x.clone()], [g, g.clone()], [scale, scale.clone()], [shift, shift.clone()],
+                            dict(quant_min=-128, quant_max=127, type_min=-128, type_max=127, is_affine=False), fused=True)
+    for y, dx in zip(ys, dxs):
+        assert sha_t(y) == d["y_sha256"] and sha_t(dx) == d["dx_sha256"]
+
+
+def test_weight_group_on_a_qat_model():
+    """prepare_qat model with LSQFakeQuantizer weight quantizers: with the LSQWeightGroup hook the layers get their weights from
+    one fused call; loss, input gradient and every parameter gradient equal the ungrouped model's bit for bit"""
+    import copy
+    import torchlsq  # noqa: F401
+    from torch.ao.quantization import QConfig, prepare_qat
+    from torch.ao.quantization.observer import MovingAverageMinMaxObserver, MovingAveragePerChannelMinMaxObserver
+    from torchlsq.quantized import LSQFakeQuantizer, LSQWeightGroup
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(
+        torch.nn.Conv2d(8, 256, 3, padding=1), torch.nn.ReLU(),
+        torch.nn.Conv2d(256, 256, 3, padding=1), torch.nn.ReLU(),
+        torch.nn.Conv2d(256, 512, 3, padding=1, stride=2), torch.nn.ReLU(),
+        torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(), torch.nn.Linear(512, 1024), torch.nn.ReLU(), torch.nn.Linear(1024, 16))
+    net.qconfig = QConfig(
+        activation=LSQFakeQuantizer.with_args(observer=MovingAverageMinMaxObserver, otype="activation", init_batches=1),
+        weight=LSQFakeQuantizer.with_args(observer=MovingAveragePerChannelMinMaxObserver, otype="weight", dtype=torch.qint8,
+                                          qscheme=torch.per_channel_symmetric))
+    net = prepare_qat(net.train()).to(dev)
+    x0 = torch.randn(4, 8, 16, 16, device=dev)
+    for _ in range(4):                       # creating call + initialisation batches: every quantizer reaches its steady state
+        net(x0).sum().backward()
+    net.zero_grad(set_to_none=True)
+    grouped = copy.deepcopy(net)
+    group = LSQWeightGroup(grouped)
+    assert len(group.pairs) == 5
+    x = torch.randn(4, 8, 16, 16, device=dev)
+    outs = []
+    for model in (net, grouped):
+        seen = {}
+        hooks = [m.weight_fake_quant.register_forward_hook(lambda mod, a, out, k=k: seen.__setitem__(k, out.detach().clone()))
+                 for k, m in enumerate(mm for mm in model.modules() if hasattr(mm, "weight_fake_quant"))]
+        xi = x.clone().requires_grad_(True)
+        loss = (model(xi) ** 2).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        for h in hooks:
+            h.remove()
+        outs.append((loss, xi.grad, {n: p.grad for n, p in model.named_parameters()}, seen))
+    assert group.last_fused >= 3, group.last_fused        # the weights of the big layers went through the fused call
+    # forward: every layer got the same fake-quantized weight, the loss is the same number
+    assert sorted(outs[0][3]) == sorted(outs[1][3]) and len(outs[0][3]) == 5
+    for k in outs[0][3]:
+        assert _bits(outs[0][3][k]) == _bits(outs[1][3][k]), k
+    assert _bits(outs[0][0]) == _bits(outs[1][0])
+    # backward: the gradients that reach the quantizers come out of the framework's convolution / GEMM backward kernels, which
+    # are not bit-reproducible run to run; the fused node itself is (test_foreach_equals_single_calls_bit_for_bit), so here:
+    # same gradients to rounding noise, for every parameter (scale / shift of all quantizers included) and the input
+    def close(a, b, what):
+        assert (a is None) == (b is None), what
+        if a is not None:
+            tol = 1e-4 * float(a.abs().max()) + 1e-12
+            assert float((a - b).abs().max()) <= tol, (what, float((a - b).abs().max()), tol)
+    close(outs[0][1], outs[1][1], "input gradient")
+    for n, g0 in outs[0][2].items():
+        close(g0, outs[1][2][n], n)

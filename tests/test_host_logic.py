@@ -330,3 +330,17 @@ def test_ops_trace_under_torch_compile(oracle_cpu_backend):
         mn, mx = torch.ops.torchlsq.lsq_minmax_per_channel(fx, 1)
         yq, q = torch.ops.torchlsq.lsq_quantize_per_tensor(fx, torch.empty(1), torch.empty(1), 0, 127, 0, 255, 0)
         assert mn.shape == (8,) and q.dtype == torch.int8 and q.shape == fx.shape
+
+
+def test_lsq_foreach_on_cpu_tensors_is_the_loop(oracle_cpu_backend):
+    """CPU tensors are not fused: lsq_foreach is then exactly one lsq call per tensor"""
+    from torchlsq.functional import lsq, lsq_foreach
+    torch.manual_seed(0)
+    xs = [torch.randn(6, 4, 3, 3) * 0.05, torch.randn(5, 8) * 0.05]
+    ss = [torch.full((6,), 1e-3), torch.full((5,), 2e-3)]
+    bs = [torch.zeros(6), torch.zeros(5)]
+    kw = dict(quant_min=-128, quant_max=127, type_min=-128, type_max=127, is_affine=False)
+    got = lsq_foreach([x.clone().requires_grad_(True) for x in xs], ss, bs, axis=0, **kw)
+    want = [lsq(x, s, b, axis=0, is_perchannel=True, **kw) for x, s, b in zip(xs, ss, bs)]
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)

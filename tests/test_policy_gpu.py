@@ -1,0 +1,150 @@
+"""GPU: every size threshold of the per-channel launch policy (lsq_per_channel.hip: forward_per_channel, launch_bwd_pc,
+backward_per_channel; lsq_pc_geom.hpp) pinned from both sides: one shape just below and one just above it, fp32 and bf16
+storage, each held to the CPU oracle (y / dx bit-exact, d_scale / d_shift within 1e-6 of sum|terms|) -- and the launch note of
+the tools build (tools/lsq_tools.py) says which kernel family / loop form / workgroup size actually ran, so a threshold that
+moves, or a branch that stops being taken, fails here.  tools/exp_policy_cliffs.py sweeps the same thresholds for time."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_bits_equal, assert_reduction_close
+from oracle import lsq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MB = 1 << 20
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torchlsq  # noqa: F401
+    import lsq_tools
+    from torchlsq import extension
+    extension._assert_has_ops()
+    lsq_tools.activate()
+    yield lsq_tools
+    lsq_tools.deactivate()
+
+
+def _case(T, shape, axis, dtype, qrange=(0, 127, 0, 255)):
+    """run forward + backward on the default policy; return (forward note, backward note); parity against the oracle"""
+    from torchlsq import extension as E, synth
+    dev = torch.device("cuda:0")
+    n = int(np.prod(shape))
+    C = shape[axis]
+    x = synth.normal_like(n, 61, 0.5, 1.0, dtype=dtype, device=dev).view(shape)
+    g = synth.normal_like(n, 62, 0.0, 1e-3, dtype=dtype, device=dev).view(shape)
+    s = synth.uniform_like(C, 63, 0.01, 0.05, device=dev)
+    b = synth.normal_like(C, 64, 0.0, 0.1, device=dev)
+    q = qrange + (True, 1.0, False, False, False)
+    y = E.hip_forward_per_channel(x, s, b, axis, *q)
+    fnote = T.last_launch()
+    dx, ds, db = E.hip_backward_per_channel(g, x, s, b, axis, *q)
+    bnote = T.last_launch()
+    torch.cuda.synchronize()
+    xs, gs_ = x.float().cpu().numpy(), g.float().cpu().numpy()
+    outer, C_, inner = O.axis_to_ocl(shape, axis)
+    oy = O.fwd_pc(xs, s.cpu().numpy(), b.cpu().numpy(), outer, C_, inner, *qrange)
+    r = O.bwd_pc(gs_, xs, s.cpu().numpy(), b.cpu().numpy(), outer, C_, inner, *qrange, True, 1.0, False)
+    tag = "%s %s" % (shape, dtype)
+    if dtype == torch.float32:
+        assert_bits_equal(y.cpu().numpy(), oy, tag + " y")
+        assert_bits_equal(dx.cpu().numpy(), r.dx, tag + " dx")
+    else:
+        assert torch.equal(y.cpu().view(torch.int16), torch.from_numpy(np.ascontiguousarray(oy)).to(dtype).view(torch.int16)), tag + " y"
+        assert torch.equal(dx.cpu().view(torch.int16), torch.from_numpy(np.ascontiguousarray(r.dx)).to(dtype).view(torch.int16)), tag + " dx"
+    assert_reduction_close(ds.cpu().numpy(), r.ds_wide, r.abs_ds, tag + " ds")
+    assert_reduction_close(db.cpu().numpy(), r.db_wide, r.abs_db, tag + " db")
+    del x, g, y, dx
+    torch.cuda.empty_cache()
+    return fnote, bnote
+
+
+def _rows(elements, C):
+    """(rows just below, rows just above) an element-count threshold for [rows, C]"""
+    lo = (elements - 1) // C
+    return lo, lo + 1 if (lo + 1) * C >= elements else lo + 2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_small_tensor_floor_2p21_elements(T, dtype):
+    """below 2^21 elements a workgroup takes as few rows as the grid target allows (latency regime), above it at least the
+    rows that keep the partial-sum traffic under ~5 %"""
+    lo, hi = _rows(1 << 21, 768)
+    (_, b_lo), (_, b_hi) = _case(T, (lo, 768), 1, dtype), _case(T, (hi, 768), 1, dtype)
+    assert b_lo["kind"] == b_hi["kind"] == "row-groups"
+    rows_per_wg = lambda note, rows: rows / note["grid_y"]
+    assert rows_per_wg(b_lo, lo) < rows_per_wg(b_hi, hi), (b_lo, b_hi)      # the floor binds only above the threshold
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_streaming_hint_above_32_mb(T, dtype):
+    esz = 4 if dtype == torch.float32 else 2
+    lo, hi = _rows(32 * MB // esz + 1, 2048 * 7)        # NCHW-style windows: [rows, 2048, 7] quantized on axis 1
+    (_, b_lo), (_, b_hi) = _case(T, (lo, 2048, 7), 1, dtype, (-8, 7, -128, 127)), _case(T, (hi, 2048, 7), 1, dtype, (-8, 7, -128, 127))
+    assert b_lo["kind"] == b_hi["kind"] == "windows" and b_lo["ring_depth"] == b_hi["ring_depth"] == 4
+    assert (b_lo["ring_nt"], b_hi["ring_nt"]) == (0, 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_big_row_group_workgroups_band(T, dtype):
+    """one 768/1024-lane workgroup per CU for last-axis tensors of 2^23 .. 3 * 2^24 elements whose rows fit one window
+    (4-byte storage: only up to 64 MB)"""
+    big = 1024 if dtype == torch.float32 else 768
+    lo, hi = _rows(1 << 23, 768)
+    (_, a), (_, b) = _case(T, (lo, 768), 1, dtype), _case(T, (hi, 768), 1, dtype)
+    assert (a["block"], b["block"]) == (192 if dtype == torch.float32 else 192, big), (a, b)
+    if dtype == torch.float32:
+        lo, hi = _rows(64 * MB // 4 + 1, 768)          # the 64 MB cap of 4-byte storage
+        (_, a), (_, b) = _case(T, (lo, 768), 1, dtype), _case(T, (hi, 768), 1, dtype)
+        assert a["block"] == big and b["block"] < big, (a, b)
+    else:
+        lo, hi = _rows(3 << 24, 768)                   # the upper end of the band
+        (_, a), (_, b) = _case(T, (lo, 768), 1, dtype), _case(T, (hi, 768), 1, dtype)
+        assert a["block"] == big and b["block"] < big, (a, b)
+
+
+def test_fp32_row_groups_leave_the_ring_above_160_mb(T):
+    lo, hi = _rows(160 * MB // 4 + 1, 768)
+    (_, a), (_, b) = _case(T, (lo, 768), 1, torch.float32), _case(T, (hi, 768), 1, torch.float32)
+    assert a["kind"] == b["kind"] == "row-groups"
+    assert a["ring_depth"] == 4 and b["ring_depth"] == 0, (a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_row_groups_give_way_to_windows_at_2p27_elements(T, dtype):
+    lo, hi = _rows(1 << 27, 2048)
+    (_, a), (_, b) = _case(T, (lo, 2048), 1, dtype), _case(T, (hi, 2048), 1, dtype)
+    assert (a["kind"], b["kind"]) == ("row-groups", "windows"), (a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ring_needs_as_many_row_tiles_as_stages(T, dtype):
+    """a workgroup that would walk fewer row tiles than the ring is deep runs the register loops"""
+    (_, a), (_, b) = _case(T, (32, 2048, 7, 7), 1, dtype, (-8, 7, -128, 127)), _case(T, (256, 2048, 7, 7), 1, dtype, (-8, 7, -128, 127))
+    assert a["kind"] == b["kind"] == "windows"
+    assert a["ring_depth"] == 0 and b["ring_depth"] == 4, (a, b)
+    assert 32 / a["grid_y"] < 4 <= 256 / b["grid_y"]
+
+
+def test_segment_mode_few_rows_long_channels(T):
+    """few outer indices + long packet-aligned channel rows -> one channel per workgroup (conv / linear weights on axis 0);
+    8 outer indices or a short row -> windows"""
+    (f1, b1) = _case(T, (512, 512, 3, 3), 0, torch.float32, (-128, 127, -128, 127))
+    (f2, b2) = _case(T, (7, 64, 4096), 1, torch.float32)
+    (f3, b3) = _case(T, (8, 64, 4096), 1, torch.float32)
+    (f4, b4) = _case(T, (512, 512), 0, torch.float32, (-128, 127, -128, 127))          # 512 elements per channel: under one window
+    assert f1["kind"] == b1["kind"] == f2["kind"] == b2["kind"] == "segment"
+    assert f3["kind"] == b3["kind"] == f4["kind"] == b4["kind"] == "windows"
+    assert b1["grid_x"] == 512 and b1["grid_y"] == 1          # one workgroup per channel: d_scale finished in the kernel
+
+
+def test_forward_of_16_bit_last_axis_takes_the_coarser_grid_above_2p24_elements(T):
+    """16-bit last-axis forwards with a 32 KiB channel table (2048 channels per window) run 4 workgroups per CU (half the table
+    builds) once the tensor has 2^24 elements; smaller ones keep 16 per CU"""
+    lo, hi = _rows(1 << 24, 4096)
+    (a, _), (b, _) = _case(T, (lo, 4096), 1, torch.bfloat16), _case(T, (hi, 4096), 1, torch.bfloat16)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    wg = lambda n: n["grid_x"] * n["grid_y"]
+    assert wg(a) > 8 * cus and wg(b) <= 6 * cus, (a, b)
+    assert a["ring_depth"] == b["ring_depth"] == 0          # register loops either way
