@@ -199,7 +199,7 @@ def measure_traffic(a, kernel_substr):
             d = os.path.join(tmp, ctr)
             cmd = [rocprof, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "bench", "--", sys.executable,
                    os.path.abspath(__file__), "--workload", a.workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                   "--no-measure-traffic", "--no-yardstick", "--host-binding", a.host_binding]
+                   "--no-measure-traffic", "--no-yardstick", "--no-secondary", "--host-binding", a.host_binding]
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=180, cwd="/tmp", env=env)
             got = _pmc_mean(d, ctr, kernel_substr)
             if got is None:

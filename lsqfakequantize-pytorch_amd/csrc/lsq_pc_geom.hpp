@@ -76,6 +76,14 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
                      : "memory");
     }
 }
+// the 4-byte form: lane l's dword lands at LDS byte offset `lds_dst` + 4 l (staging of per-channel parameters)
+__device__ __forceinline__ void glds4(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
 __device__ __forceinline__ void glds16_rt(const void* gsrc, uint32_t lds_dst, int nt) {     // nt wave-uniform
     if (nt) glds16<true>(gsrc, lds_dst);
     else glds16<false>(gsrc, lds_dst);
@@ -187,11 +195,15 @@ static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec,
 #ifdef LSQ_TIMELINE
     g.timeline = nullptr;
 #endif
-    // keep the partial-sum traffic (16 B per slot per workgroup) below ~5 % of the streamed bytes -- except for small
-    // tensors (< 2 M elements), which are latency- not traffic-bound: there a workgroup takes as few rows as the grid
-    // target allows ([128, 768]: 128 workgroups of one row instead of 7 walking 21 rows one group after the other)
-    const bool small = outer * g.L < (int64_t{1} << 21);
-    const int64_t min_tiles = small ? 1 : std::max<int64_t>(1, (per_slot_rows * static_cast<int64_t>(g.k_slots) + W - 1) / W);
+    // keep the partial-sum traffic (16 B per slot per workgroup) below ~5 % of the streamed bytes -- but never at the price
+    // of idle CUs: a tensor too small to give every CU a workgroup of that many tiles is latency- not traffic-bound, and its
+    // workgroups take the tiles that one workgroup per CU would ([128, 768]: 64 workgroups of one tile instead of 7 walking
+    // 21 rows one group after the other).  A smooth rule: the former switch at 2^21 elements was a cliff (just below it
+    // a [2730, 768] bf16 backward ran 1024 two-row workgroups in 21.9 us, just above 170 sixteen-row ones in 13.6 us;
+    // profiles/r03_policy_cliffs.txt).
+    const int64_t floor_tiles = std::max<int64_t>(1, (per_slot_rows * static_cast<int64_t>(g.k_slots) + W - 1) / W);
+    const int64_t spread_tiles = g.n_tiles * g.n_windows / std::max(1, device_info().cu_count);
+    const int64_t min_tiles = std::max<int64_t>(1, std::min(floor_tiles, spread_tiles));
     const int64_t max_splits = std::max<int64_t>(1, g.n_tiles / min_tiles);       // every split gets >= min_tiles tiles
     const int64_t want_splits = std::max<int64_t>(1, (target_blocks + g.n_windows - 1) / g.n_windows);
     // whole tiles per workgroup first (ceil), then as many workgroups as that needs: [64,197,768] forward = 3152
@@ -238,8 +250,10 @@ static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_
     g.wpos = static_cast<int64_t>(g.ww_lanes) * vec;
     g.k_slots = static_cast<int32_t>(g.wpos);
     g.n_tiles = (outer + g.R - 1) / g.R;
-    const bool small = outer * g.L < (int64_t{1} << 21);
-    const int64_t min_tiles = small ? 1 : std::max<int64_t>(1, (min_rows + g.R - 1) / g.R);
+    // (the rows-per-workgroup floor gives way to "one workgroup per CU first" for small tensors: see make_geom)
+    const int64_t floor_tiles = std::max<int64_t>(1, (min_rows + g.R - 1) / g.R);
+    const int64_t spread_tiles = g.n_tiles * g.n_windows / std::max(1, device_info().cu_count);
+    const int64_t min_tiles = std::max<int64_t>(1, std::min(floor_tiles, spread_tiles));
     const int64_t max_splits = std::max<int64_t>(1, g.n_tiles / min_tiles);
     int64_t splits = std::max<int64_t>(1, (target_blocks + g.n_windows - 1) / g.n_windows);
     splits = std::min(splits, max_splits);
@@ -253,9 +267,10 @@ static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_
 // Dynamic LDS of the window-mode backward in front of the LDS-DMA ring: the channel table + fp64 slots of the 256-lane
 // windows (the ring starts at the next 1 KiB boundary).  Row-group windows have nothing in front: their combine buffer
 // is only used after the last row has been consumed and takes the ring's place (one barrier in between).
+// (+ 8 bytes per slot: the raw scale / shift of the window's channels, staged by LDS-DMA before the row copies are issued)
 static inline __host__ __device__ uint32_t bwd_lds_front_bytes(const PcGeom& g, uint32_t slot_bytes) {
     if (g.ww_lanes) return 0u;
-    return (static_cast<uint32_t>(g.k_slots) * (slot_bytes + 16u) + 1023u) & ~1023u;
+    return (static_cast<uint32_t>(g.k_slots) * (slot_bytes + 16u + 8u) + 1023u) & ~1023u;
 }
 
 // Where a lane sits: position p0 of its first element, its row inside the tile, and whether it is live.

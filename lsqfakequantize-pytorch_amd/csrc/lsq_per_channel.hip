@@ -63,6 +63,52 @@ __device__ __forceinline__ void build_channel_table(QSlot<T>* table, int k_count
     }
 }
 
+// The same in two steps, for kernels that put their first rows in flight before the table exists: the scale / shift loads
+// are ISSUED first (vector-memory operations retire in issue order: a wait for a load behind the rows' loads would be a wait
+// for the rows), the row loads follow, and the table is finished when its raw values are needed.  Up to kRawSlots table
+// slots per thread travel in registers; wider windows (last-axis windows of more than 512 channels) use build_channel_table.
+constexpr int kRawSlots = 2;
+template <typename T>
+struct ChannelRaw {
+    T s[kRawSlots], b[kRawSlots];
+};
+template <typename T>
+__device__ __forceinline__ ChannelRaw<T> load_channel_raw(int k_count, int64_t c_lo, int64_t C, const T* __restrict__ scale,
+                                                          const T* __restrict__ shift) {
+    ChannelRaw<T> raw;
+#pragma unroll
+    for (int i = 0; i < kRawSlots; ++i) {
+        const int k = threadIdx.x + i * kBlock;
+        int64_t c = c_lo + k;
+        c = (k < k_count && c < C) ? c : (C - 1);        // (a valid address for the lanes without a slot: the value is unused)
+        raw.s[i] = scale[c];
+        raw.b[i] = shift[c];
+    }
+    return raw;
+}
+template <typename T>
+__device__ __forceinline__ void finish_channel_table(QSlot<T>* table, int k_count, int64_t c_lo, int64_t C, const ChannelRaw<T>& raw,
+                                                     const Range<T>& r) {
+#pragma unroll
+    for (int i = 0; i < kRawSlots; ++i) {
+        const int k = threadIdx.x + i * kBlock;
+        if (k < k_count) {
+            QSlot<T> e;
+            if (c_lo + k < C) {
+                const QParams<T> q = make_qparams<T>(sanitize_scale_per_channel<T>(raw.s[i]), raw.b[i], r);
+                e.s = q.s; e.inv_s = q.inv_s; e.zp = q.zp; e.pad = static_cast<T>(0);
+            } else {
+                e.s = static_cast<T>(1); e.inv_s = static_cast<T>(1); e.zp = static_cast<T>(0); e.pad = static_cast<T>(0);
+            }
+            table[k] = e;
+        }
+    }
+}
+// first channel of workgroup blockIdx.x's window (LaneSite::c_lo without the per-lane part)
+__device__ __forceinline__ int64_t window_first_channel(const PcGeom& g) {
+    return g.R == 1 ? udiv(static_cast<int64_t>(blockIdx.x) * g.wpos, g.inner, g.fits32 != 0) : 0;
+}
+
 // CPL = channels a lane can touch: 1 (inner % V == 0), 2 (inner >= V), V (anything).
 template <typename T, int V, int CPL>
 struct LaneChannels {
@@ -142,10 +188,14 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     QSlot<T>* table = reinterpret_cast<QSlot<T>*>(smem);
 
+    // the window's raw scale / shift first (issue order = retirement order), then the first rows, then the table
+    const bool raw_first = g.k_slots <= kRawSlots * kBlock;
+    ChannelRaw<T> raw;
+    if (raw_first) raw = load_channel_raw<T>(g.k_slots, window_first_channel(g), g.C, scale, shift);
     const LaneSite site = lane_site(g, V);
     const RowWalk walk(g, site);
     // the first group of loads does not depend on the channel constants: put it in flight before the
-    // table build (global loads of scale/shift + a division + a barrier) so the two latencies overlap
+    // table build (a division + a barrier) so the two latencies overlap
     E first[UNROLL][V];
     const bool first_full = DMA > 0 ? false : walk.n_rows >= UNROLL;
     if (first_full) {
@@ -168,7 +218,8 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
     if constexpr (DMA > 0) {
         for (int64_t i = 0; i < DMA && i < dma_n; ++i) dma_issue(i);
     }
-    build_channel_table<T>(table, g.k_slots, site.c_lo, g.C, scale, shift, r);
+    if (raw_first) finish_channel_table<T>(table, g.k_slots, site.c_lo, g.C, raw, r);
+    else build_channel_table<T>(table, g.k_slots, site.c_lo, g.C, scale, shift, r);
     __syncthreads();
     LaneChannels<T, V, CPL> ch;
     ch.init(table, site, g);
@@ -323,6 +374,32 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
     double* lds_s = reinterpret_cast<double*>(smem + static_cast<size_t>(g.k_slots) * sizeof(QSlot<T>));
     double* lds_b = lds_s + g.k_slots;
 
+    // The window's raw scale / shift are requested FIRST: vector-memory operations retire in issue order, so a wait for loads
+    // issued behind the first rows' loads would be a wait for those rows (measured, tools/exp_timeline.py: the prologue of a
+    // workgroup took 3-7 us, a quarter of its life, most of it that wait).
+    //  * ring kernels (fp32 parameters): LDS-DMA dword copies into a staging area behind the fp64 slots -- asm like the
+    //    row copies, invisible to the compiler's own s_waitcnt bookkeeping, ordered below with a counted wait;
+    //  * register-loop kernels: ordinary loads into registers (the compiler counts its own loads in issue order).
+    constexpr bool STAGE = DMA > 0 && !WW && std::is_same<T, float>::value;
+    const bool raw_first = !WW && DMA == 0 && g.k_slots <= kRawSlots * kBlock;
+    float* raw_stage = reinterpret_cast<float*>(smem + static_cast<size_t>(g.k_slots) * (sizeof(QSlot<T>) + 16));   // [k_slots] scale, [k_slots] shift
+    ChannelRaw<T> raw;
+    if constexpr (STAGE) {
+        const int64_t c_first = window_first_channel(g);
+        const uint32_t stage_lds = __builtin_amdgcn_readfirstlane(lds_offset_of(raw_stage));
+        for (int k0 = 0; k0 < g.k_slots; k0 += kBlock) {          // uniform trip count
+            const int k = k0 + threadIdx.x;
+            if (k < g.k_slots) {                                  // (the other lanes stay out: their dwords would land in a neighbour's slots)
+                int64_t c = c_first + k;
+                c = c < g.C ? c : g.C - 1;                        // slots past the last channel copy a valid address
+                const uint32_t dst = __builtin_amdgcn_readfirstlane(stage_lds + static_cast<uint32_t>(k0 + (threadIdx.x & ~63)) * 4u);
+                glds4(scale + c, dst);
+                glds4(shift + c, dst + static_cast<uint32_t>(g.k_slots) * 4u);
+            }
+        }
+    } else if (raw_first) {
+        raw = load_channel_raw<T>(g.k_slots, window_first_channel(g), g.C, scale, shift);
+    }
     int32_t lane_in_group = 0;
     const LaneSite site = WW ? lane_site_ww(g, V, lane_in_group) : lane_site(g, V);
     const RowWalk walk(g, site);
@@ -353,21 +430,79 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
         glds16_rt(static_cast<const E*>(grad) + e, dst, g.ring_nt);
         glds16_rt(static_cast<const E*>(x) + e, dst + 64 * 16, g.ring_nt);
     };
+    // Row-group windows on the ring, fp32 parameters: the lane's own V scale / shift values are requested BEFORE its rows, as
+    // LDS-DMA copies into the last one or two ring stages (16 bytes per lane and copy; the row copies that belong into those
+    // stages are issued once the parameters have been read out): see STAGE above for why the order matters.
+    constexpr int kParCopies = (V * 4) / 16;                                       // 16-byte copies per parameter: 2 (V = 8), 1 (V = 4)
+    constexpr int kParStages = DMA > 0 ? (2 * kParCopies * 1024 + kDmaStageBytes - 1) / kDmaStageBytes : 0;
+    constexpr bool WSTAGE_ABLE = WW && DMA > kParStages && std::is_same<T, float>::value && LC::N == V && (V == 8 || V == 4);
+    const bool wstage = WSTAGE_ABLE && ((reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15u) == 0;
     if constexpr (DMA > 0) {
-        for (int64_t i = 0; i < DMA && i < dma_n; ++i) dma_issue(i);    // in flight before the constants are built
+        if (wstage) {
+            const int64_t c0 = site.live ? site.p0 : 0;
+            const uint32_t par_lds = ring_lds + static_cast<uint32_t>(DMA - kParStages) * kDmaStageBytes;
+#pragma unroll
+            for (int q4 = 0; q4 < kParCopies; ++q4) {
+                glds16<false>(scale + c0 + 4 * q4, par_lds + static_cast<uint32_t>(q4) * 1024u);
+                glds16<false>(shift + c0 + 4 * q4, par_lds + static_cast<uint32_t>(kParCopies + q4) * 1024u);
+            }
+            for (int64_t i = 0; i < DMA - kParStages && i < dma_n; ++i) dma_issue(i);
+        } else {
+            for (int64_t i = 0; i < DMA && i < dma_n; ++i) dma_issue(i);    // in flight before the constants are built
+        }
     }
     LC ch;
     if constexpr (WW) {
         // channel p0 + j is component j's own: constants straight into registers (lsq_kernel.h:157-158 + :12)
         ch.split = (CPL == 2) ? 1 : V;     // V == 2 (8-byte elements): LaneChannels' two-channel form, component 1 = channel 1
+        if (wstage) {
+            if constexpr (WSTAGE_ABLE) {
+                // younger than the parameter copies: the copies of the rows issued so far (two each)
+                const int64_t rows_out = dma_n < DMA - kParStages ? dma_n : DMA - kParStages;
+                wait_vm_upto(static_cast<int>(2 * rows_out));
+                const unsigned char* par = ring + (DMA - kParStages) * kDmaStageBytes + (threadIdx.x & 63) * 16;
+                float sv[V], bv[V];
 #pragma unroll
-        for (int j = 0; j < LC::N; ++j) {
-            const int64_t c = site.live ? site.p0 + j : 0;
-            ch.q[j] = make_qparams<T>(sanitize_scale_per_channel<T>(scale[c]), shift[c], r);
-            ch.key[j] = j * g.ww_lanes + lane_in_group;
+                for (int q4 = 0; q4 < kParCopies; ++q4) {
+                    __builtin_memcpy(&sv[4 * q4], par + q4 * 1024, 16);
+                    __builtin_memcpy(&bv[4 * q4], par + (kParCopies + q4) * 1024, 16);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the stages are in registers: the rows may land
+                for (int64_t i = DMA - kParStages; i < DMA && i < dma_n; ++i) dma_issue(i);
+#pragma unroll
+                for (int j = 0; j < LC::N; ++j) {
+                    ch.q[j] = make_qparams<T>(sanitize_scale_per_channel<T>(sv[j]), bv[j], r);
+                    ch.key[j] = j * g.ww_lanes + lane_in_group;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < LC::N; ++j) {
+                const int64_t c = site.live ? site.p0 + j : 0;
+                ch.q[j] = make_qparams<T>(sanitize_scale_per_channel<T>(scale[c]), shift[c], r);
+                ch.key[j] = j * g.ww_lanes + lane_in_group;
+            }
         }
     } else {
-        build_channel_table<T>(table, g.k_slots, site.c_lo, g.C, scale, shift, r);
+        if constexpr (STAGE) {
+            // younger than this wave's staging copies: the row copies just issued (two per row)
+            wait_vm_upto(static_cast<int>(2 * (dma_n < DMA ? dma_n : DMA)));
+            for (int k = threadIdx.x; k < g.k_slots; k += kBlock) {     // slot k was staged by this very wave
+                const int64_t c = site.c_lo + k;
+                QSlot<T> e;
+                if (c < g.C) {
+                    const QParams<T> q = make_qparams<T>(sanitize_scale_per_channel<T>(raw_stage[k]), raw_stage[g.k_slots + k], r);
+                    e.s = q.s; e.inv_s = q.inv_s; e.zp = q.zp; e.pad = static_cast<T>(0);
+                } else {
+                    e.s = static_cast<T>(1); e.inv_s = static_cast<T>(1); e.zp = static_cast<T>(0); e.pad = static_cast<T>(0);
+                }
+                table[k] = e;
+            }
+        } else if (raw_first) {
+            finish_channel_table<T>(table, g.k_slots, site.c_lo, g.C, raw, r);
+        } else {
+            build_channel_table<T>(table, g.k_slots, site.c_lo, g.C, scale, shift, r);
+        }
         if (!EVAL) {
             for (int k = threadIdx.x; k < g.k_slots; k += kBlock) {
                 lds_s[k] = 0.0;
@@ -1154,12 +1289,12 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
     if (vec > 1 && vec * sizeof(typename IO::elem) == 16 && v.dma != 1) {
         const int tgt = variant == 0 ? dev.cu_count * kDmaFwdBlocksPerCU<IO> : target;
         const PcGeom gd = make_geom(outer, channels, inner, vec, tgt, kFwdPerSlotRows<IO>);
-        const bool small_last_axis = cpl == vec && outer * channels * inner < (int64_t{1} << 24);
         const int64_t tiles_each = gd.n_tiles / std::max(1, gd.splits);
         const size_t lds_ring = ((static_cast<size_t>(gd.k_slots) * sizeof(QSlot<typename IO::arith>) + 1023) & ~size_t(1023)) +
                                 static_cast<size_t>(kBlock / 64) * kFwdDmaDepth * 1024;
         const bool table_big = lds_ring > 64 * 1024;
-        if (v.dma == 2 || (table_big && tiles_each >= kFwdDmaDepth && tiles_each <= 64 && !small_last_axis)) {
+        // (tiles_each >= 8 on the ring's grid with a 2048-slot table already implies >= 2^24 elements: no separate size rule)
+        if (v.dma == 2 || (table_big && tiles_each >= kFwdDmaDepth && tiles_each <= 64)) {
             g = gd;
             vv.dma = table_big ? 1 : 2;
             g.ring_nt = ring_nt_for(outer * channels * inner * static_cast<int64_t>(sizeof(typename IO::elem)), false, false);
@@ -1322,18 +1457,19 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
             const bool big_wide = WW && sizeof(typename IO::elem) >= 4 &&
                                   c.outer * c.C * static_cast<int64_t>(sizeof(typename IO::elem)) > (int64_t{160} << 20);
             if constexpr (WW && !EVAL) {
-                // Mid-sized tensors whose rows fit one window (8 M .. 48 M elements: [64,197,768], [256,197,768], NHWC
+                // Mid-sized tensors whose rows fit one window (8 M .. 80 M elements: [64,197,768], [256,197,768], NHWC
                 // [16,56,56,256]): ONE 768/1024-lane workgroup per CU instead of three or four 3-4-wave ones -- the same
                 // waves in flight, evenly over the four SIMDs (3-wave workgroups load them 3:2:2:2), a third of the partial
                 // rows, constants and epilogues.  6-12 % faster there, slower below (a [16,197,768] wants many short
-                // workgroups) and no gain above (profiles/r02_ww_big_ab.txt).
+                // workgroups) and no gain above (profiles/r02_ww_big_ab.txt; upper end, cold buffers:
+                // profiles/r03_ww_big_upper_ab.txt -- 16-bit storage -7 % at 48 M elements, -1 .. -4 % at 64 M, +1 .. +5 % at 96 M).
                 const int big = knob::get(knob::kWwBig);
                 const int64_t elems = c.outer * c.C;
                 // (4- and 8-byte storage only up to 64 MB -- tensors that are usually still cache-resident; from HBM the
                 // usual workgroups win there: [256,197,768] fp32 cold 91.5 vs 102.7 us, profiles/r02_cold_buffers_pc.txt)
                 const bool fits = sizeof(typename IO::elem) < 4 || elems * static_cast<int64_t>(sizeof(typename IO::elem)) <= (int64_t{64} << 20);
                 const bool use_big = big == 1 || (big == 0 && c.default_variant && c.C / V <= kBlock && fits &&
-                                                  elems >= (int64_t{1} << 23) && elems < (int64_t{3} << 24));
+                                                  elems >= (int64_t{1} << 23) && elems < (int64_t{5} << 24));
                 constexpr int kBigBlock = kBigBlockOf<sizeof(typename IO::elem)>;
                 if (use_big &&
                     run(bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, 1, true, true, false, WW, kDmaDepth, kBigBlock>, kDmaDepth,
@@ -1417,6 +1553,16 @@ static hipError_t bwd_seg_modes(const void* grad, const void* x, void* dx, const
 #undef LSQ_CASE
 }
 
+// Last-axis tensors under 512 MB take row-group windows in the backward; from there on the 256-lane windows, which read
+// 4 KiB contiguous per row and workgroup instead of 1 KiB from each of four rows, are level or ahead
+// (profiles/r03_ww_max_ab.txt, cold buffers: bf16 row groups -2 .. -12 % at 256 MB, -4 .. +7 % at 512 MB, level at 1 GB;
+// fp32 -3 .. -9 % at 512 MB for rows up to 2048 features, +6 .. +22 % for wider rows -- those decide the 4-byte bound).
+template <typename IO>
+inline int64_t ww_max_elems() {
+    const int k = knob::get(knob::kWwMaxLog2);      // tools builds: lsq_hip_debug_set_ww_max_log2
+    return k > 0 ? int64_t{1} << k : (int64_t{512} << 20) / static_cast<int64_t>(sizeof(typename IO::elem));
+}
+
 template <typename IO>
 hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void* ds, void* db, double* wide,
                                 int64_t outer, int64_t channels, int64_t inner, const void* scale,
@@ -1469,10 +1615,8 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
     // fatter workgroups win there in every shape swept (profiles/r01_lastaxis_sweep.txt: 2 per CU; [8192, 4096] fp32
     // 82 us against 100 us at 16 per CU, [200704, 256] 133 against 205).
     const bool last_axis = vecw > 1 && cpl == vecw;
-    // (not for tensors of 2^27 elements and more: on [32,2048,4096] -- 65536 rows -- the 256-lane windows, which read 4 KiB
-    // contiguous per row and workgroup instead of 1 KiB from each of four rows, are 7-12 % faster,
-    // profiles/r02_lastaxis_rowgroup_ab.txt; variant bit 11 (tools) forces them, for A/B runs)
-    if (last_axis && inner == 1 && !(variant & (1 << 11)) && (variant != 0 || outer * channels < (int64_t{1} << 27))) {
+    // (under 512 MB only, ww_max_elems; variant bit 11 (tools) forces the 256-lane windows, for A/B runs)
+    if (last_axis && inner == 1 && !(variant & (1 << 11)) && (variant != 0 || outer * channels < ww_max_elems<IO>())) {
         // the quantized axis is the last one ([tokens, features], channels-last): row-group windows, one round of what
         // the chip holds (variant: workgroups per CU requested, rounded to whole rounds)
         BwdPcCall<T> call{grad, x, dx, static_cast<T*>(ds), static_cast<T*>(db), wide, outer, channels, inner, scale, shift, &p,

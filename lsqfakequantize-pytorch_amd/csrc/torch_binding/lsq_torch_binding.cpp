@@ -445,6 +445,63 @@ void multi_rows(const std::vector<Tensor>& xs, const std::vector<Tensor>& scales
     }
 }
 
+// the two backend ops of the multi-tensor path (no autograd): what LsqForeachNode below calls from its forward / backward
+std::vector<Tensor> forward_per_channel_multi(at::TensorList xs, at::TensorList scales, at::TensorList shifts, at::IntArrayRef axes,
+                                              int64_t qmin, int64_t qmax, int64_t tmin, int64_t tmax, bool use_gs, double gs, bool sym,
+                                              bool eval_mode, bool init_mode) {
+    const size_t n = xs.size();
+    TORCH_CHECK(n > 0 && scales.size() == n && shifts.size() == n && axes.size() == n, "lsq_forward_per_channel_multi: list lengths differ");
+    const Scalars s{qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode};
+    std::vector<lsq_pc_item> rows;
+    std::vector<Tensor> keep;
+    multi_rows(xs.vec(), scales.vec(), shifts.vec(), axes.vec(), rows, keep, false, "lsq_forward_per_channel_multi");
+    std::vector<Tensor> ys(n);
+    for (size_t i = 0; i < n; ++i) {
+        ys[i] = at::empty_like(xs[i]);
+        rows[i].y = ys[i].data_ptr();
+    }
+    const lsq_params p = pack(s);
+    c10::DeviceGuard guard(xs[0].device());
+    status(lsq_hip_forward_per_channel_multi(dtype_code(xs[0].scalar_type(), "lsq_forward"), rows.data(), static_cast<int32_t>(n), &p,
+                                             stream_of(xs[0])),
+           "lsq_hip_forward_per_channel_multi");
+    return ys;
+}
+
+// returns [dx_0 .. dx_{n-1}, ds_0 .. ds_{n-1}, db_0 .. db_{n-1}]
+std::vector<Tensor> backward_per_channel_multi(at::TensorList grads, at::TensorList xs, at::TensorList scales, at::TensorList shifts,
+                                               at::IntArrayRef axes, int64_t qmin, int64_t qmax, int64_t tmin, int64_t tmax, bool use_gs,
+                                               double gs, bool sym, bool eval_mode, bool init_mode) {
+    const size_t n = xs.size();
+    TORCH_CHECK(n > 0 && grads.size() == n && scales.size() == n && shifts.size() == n && axes.size() == n,
+                "lsq_backward_per_channel_multi: list lengths differ");
+    const Scalars s{qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode};
+    std::vector<lsq_pc_item> rows;
+    std::vector<Tensor> keep;
+    multi_rows(xs.vec(), scales.vec(), shifts.vec(), axes.vec(), rows, keep, true, "lsq_backward_per_channel_multi");
+    std::vector<Tensor> out(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+        Tensor g = like_layout(grads[i], xs[i]);
+        check_backward_types(g, xs[i], scales[i], shifts[i]);
+        if (reinterpret_cast<uintptr_t>(g.data_ptr()) & 15u) g = g.clone();
+        keep.push_back(g);
+        const auto popt = xs[i].options().dtype(param_type(xs[i].scalar_type()));
+        out[i] = at::empty_like(xs[i]);
+        out[n + i] = at::empty({rows[i].channels}, popt);
+        out[2 * n + i] = at::empty({rows[i].channels}, popt);
+        rows[i].grad = g.data_ptr();
+        rows[i].dx = out[i].data_ptr();
+        rows[i].ds = out[n + i].data_ptr();
+        rows[i].db = out[2 * n + i].data_ptr();
+    }
+    const lsq_params p = pack(s);
+    c10::DeviceGuard guard(xs[0].device());
+    status(lsq_hip_backward_per_channel_multi(dtype_code(xs[0].scalar_type(), "lsq_backward"), rows.data(), static_cast<int32_t>(n), &p,
+                                              stream_of(xs[0])),
+           "lsq_hip_backward_per_channel_multi");
+    return out;
+}
+
 class LsqForeachNode : public torch::autograd::Function<LsqForeachNode> {
    public:
     // (the tensors arrive as at::TensorList: that is the list type custom Functions recognise as differentiable inputs)
@@ -453,22 +510,8 @@ class LsqForeachNode : public torch::autograd::Function<LsqForeachNode> {
                                                   int64_t tmax, bool use_gs, double gs, bool sym, bool eval_mode, bool init_mode) {
         at::AutoDispatchBelowADInplaceOrView below;
         const size_t n = tensors.size() / 3;
-        std::vector<Tensor> xs(tensors.begin(), tensors.begin() + n), scales(tensors.begin() + n, tensors.begin() + 2 * n),
-            shifts(tensors.begin() + 2 * n, tensors.end());
-        const Scalars s{qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode};
-        std::vector<lsq_pc_item> rows;
-        std::vector<Tensor> keep;
-        multi_rows(xs, scales, shifts, axes, rows, keep, false, "lsq_forward_per_channel_multi");
-        torch::autograd::variable_list ys(n);
-        for (size_t i = 0; i < n; ++i) {
-            ys[i] = at::empty_like(xs[i]);
-            rows[i].y = ys[i].data_ptr();
-        }
-        const lsq_params p = pack(s);
-        c10::DeviceGuard guard(xs[0].device());
-        status(lsq_hip_forward_per_channel_multi(dtype_code(xs[0].scalar_type(), "lsq_forward"), rows.data(),
-                                                 static_cast<int32_t>(n), &p, stream_of(xs[0])),
-               "lsq_hip_forward_per_channel_multi");
+        torch::autograd::variable_list ys = forward_per_channel_multi(tensors.slice(0, n), tensors.slice(n, n), tensors.slice(2 * n, n), axes,
+                                                                      qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode);
         ctx->save_for_backward(tensors.vec());
         const int64_t flags = (use_gs ? 1 : 0) | (sym ? 2 : 0) | (eval_mode ? 8 : 0) | (init_mode ? 16 : 0);
         ctx->saved_data["cfg"] = c10::IValue(std::vector<int64_t>{qmin, qmax, tmin, tmax, flags});
@@ -485,31 +528,13 @@ class LsqForeachNode : public torch::autograd::Function<LsqForeachNode> {
         const int64_t flags = cfg[4];
         const Scalars s{cfg[0], cfg[1], cfg[2], cfg[3], (flags & 1) != 0, ctx->saved_data["gs"].toDouble(), (flags & 2) != 0,
                         (flags & 8) != 0, (flags & 16) != 0};
-        std::vector<Tensor> xs(saved.begin(), saved.begin() + n), scales(saved.begin() + n, saved.begin() + 2 * n),
-            shifts(saved.begin() + 2 * n, saved.end());
-        std::vector<lsq_pc_item> rows;
-        std::vector<Tensor> keep;
-        multi_rows(xs, scales, shifts, axes, rows, keep, true, "lsq_backward_per_channel_multi");
+        const at::TensorList all(saved);
+        std::vector<Tensor> gl(n);
+        for (size_t i = 0; i < n; ++i) gl[i] = grads[i].defined() ? grads[i] : at::zeros_like(saved[i]);
+        const std::vector<Tensor> r = backward_per_channel_multi(gl, all.slice(0, n), all.slice(n, n), all.slice(2 * n, n), axes, s.qmin,
+                                                                 s.qmax, s.tmin, s.tmax, s.use_gs, s.gs, s.sym, s.eval_mode, s.init_mode);
         torch::autograd::variable_list out(3 * n + 10);
-        for (size_t i = 0; i < n; ++i) {
-            Tensor g = grads[i].defined() ? like_layout(grads[i], xs[i]) : at::zeros_like(xs[i]);
-            check_backward_types(g, xs[i], scales[i], shifts[i]);
-            if (reinterpret_cast<uintptr_t>(g.data_ptr()) & 15u) g = g.clone();
-            keep.push_back(g);
-            const auto popt = xs[i].options().dtype(param_type(xs[i].scalar_type()));
-            out[i] = at::empty_like(xs[i]);
-            out[n + i] = at::empty({rows[i].channels}, popt);
-            out[2 * n + i] = at::empty({rows[i].channels}, popt);
-            rows[i].grad = g.data_ptr();
-            rows[i].dx = out[i].data_ptr();
-            rows[i].ds = out[n + i].data_ptr();
-            rows[i].db = out[2 * n + i].data_ptr();
-        }
-        const lsq_params p = pack(s);
-        c10::DeviceGuard guard(xs[0].device());
-        status(lsq_hip_backward_per_channel_multi(dtype_code(xs[0].scalar_type(), "lsq_backward"), rows.data(),
-                                                  static_cast<int32_t>(n), &p, stream_of(xs[0])),
-               "lsq_hip_backward_per_channel_multi");
+        for (size_t i = 0; i < 3 * n; ++i) out[i] = r[i];
         return out;
     }
 };
@@ -618,6 +643,9 @@ TORCH_LIBRARY(torchlsq_native, m) {
     m.def("lsq_foreach(Tensor[] xs, Tensor[] scales, Tensor[] shifts, int[] axes, int quant_min, int quant_max, int type_min, "
           "int type_max, bool use_grad_scaling, float grad_scale, bool is_affine, bool eval_mode, bool init_mode) -> Tensor[]",
           &lsq_foreach);
+    m.def("lsq_forward_per_channel_multi(Tensor[] xs, Tensor[] scales, Tensor[] shifts, int[] axes, " LSQ_TAIL ") -> Tensor[]");
+    m.def("lsq_backward_per_channel_multi(Tensor[] grads, Tensor[] xs, Tensor[] scales, Tensor[] shifts, int[] axes, " LSQ_TAIL
+          ") -> Tensor[]");
     m.def("_abi_version() -> int", []() -> int64_t { return lsq_hip_abi_version(); });
     m.def("_set_single_launch_backward(bool on) -> ()", [](bool on) { g_use_ticket.store(on); });
 }
@@ -630,4 +658,6 @@ TORCH_LIBRARY_IMPL(torchlsq_native, CUDA, m) {  // PyTorch-ROCm dispatches HIP t
     m.impl("lsq_backward_per_tensor_wide", &backward_per_tensor_wide);
     m.impl("lsq_backward_per_channel_wide", &backward_per_channel_wide);
     m.impl("lsq_backward_from_mask", &backward_from_mask);
+    m.impl("lsq_forward_per_channel_multi", &forward_per_channel_multi);
+    m.impl("lsq_backward_per_channel_multi", &backward_per_channel_multi);
 }

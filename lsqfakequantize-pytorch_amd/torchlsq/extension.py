@@ -16,240 +16,26 @@ kernels are registered under "CUDA".  CPU tensors are served, like in the refere
 each other: a GPU tensor is only ever handled by the HIP library, and when `liblsq_hip.so` is missing
 the package refuses to work at all (`_assert_has_ops`), CPU tensors included.
 """
-import ctypes
-import os
-import threading
-
 import torch
 
-_HAS_OPS = False
-error_str = ""
-_LIB = None
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblsq_hip.so")
-
-# dtype codes of include/lsq_hip.h
-LSQ_F32, LSQ_F64, LSQ_BF16, LSQ_F16 = 0, 1, 2, 3
-_DTYPE_CODE = {torch.float32: LSQ_F32, torch.float64: LSQ_F64, torch.bfloat16: LSQ_BF16, torch.float16: LSQ_F16}
-
-
-class LsqParams(ctypes.Structure):
-    """struct lsq_params (include/lsq_hip.h)."""
-    _fields_ = [("quant_min", ctypes.c_int32), ("quant_max", ctypes.c_int32),
-                ("type_min", ctypes.c_int32), ("type_max", ctypes.c_int32),
-                ("use_grad_scaling", ctypes.c_int32), ("sym", ctypes.c_int32),
-                ("eval_mode", ctypes.c_int32), ("init_mode", ctypes.c_int32),
-                ("grad_scaler", ctypes.c_double), ("numel_for_scaler", ctypes.c_int64)]
+from . import _abi
+from ._abi import *  # noqa: F401,F403  (structures, C_ABI tables, loaders: the names tests and tools import from here)
+from ._abi import (ABI_VERSION, C_ABI, C_ABI_CPU, _assert_has_ops, _check_hip_version, _has_ops, host_binding,  # noqa: F401
+                   library, native_lsq, set_host_binding, set_library)
+from ._hip_host import *  # noqa: F401,F403
+from ._hip_host import (_SINGLE_LAUNCH_BWD, _TICKET_SLABS, _TICKETS, _WS_BYTES_PC, _WS_BYTES_PT, _check, _dense,  # noqa: F401
+                        _like_layout, _ocl, _param_dtype, _params, _physical_order, _ROW_MAJOR, hip_backward_from_mask,
+                        hip_backward_per_channel, hip_backward_per_channel_multi, hip_backward_per_tensor,
+                        hip_forward_per_channel, hip_forward_per_channel_multi, hip_forward_per_tensor, hip_meanstd,
+                        hip_minmax, hip_multi_eligible, hip_observer_update, set_single_launch_backward)
+from ._cpu_host import _cpu_meanstd, _cpu_minmax, cpu_backward, cpu_forward  # noqa: F401
 
 
-class LsqFwdExtras(ctypes.Structure):
-    """struct lsq_fwd_extras (include/lsq_hip.h)."""
-    _fields_ = [("levels", ctypes.c_void_p), ("level_bias", ctypes.c_int32), ("aux_kind", ctypes.c_int32)]
-
-
-class LsqBwdExtras(ctypes.Structure):
-    """struct lsq_bwd_extras (include/lsq_hip.h)."""
-    _fields_ = [("ticket", ctypes.c_void_p)]
-
-
-class LsqObserverUpdate(ctypes.Structure):
-    """struct lsq_observer_update (include/lsq_hip.h)."""
-    _fields_ = [("mode", ctypes.c_int32), ("first", ctypes.c_int32), ("averaging_constant", ctypes.c_float),
-                ("quant_min", ctypes.c_int32), ("quant_max", ctypes.c_int32), ("symmetric", ctypes.c_int32),
-                ("zero_point_symmetric", ctypes.c_int32), ("eps", ctypes.c_float)]
-
-
-class LsqPcItem(ctypes.Structure):
-    """struct lsq_pc_item (include/lsq_hip.h): one tensor of a multi-tensor launch."""
-    _fields_ = [("x", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("y", ctypes.c_void_p), ("dx", ctypes.c_void_p),
-                ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("ds", ctypes.c_void_p), ("db", ctypes.c_void_p),
-                ("outer", ctypes.c_int64), ("channels", ctypes.c_int64), ("inner", ctypes.c_int64)]
-
-
-LSQ_TICKET_BYTES = 4096
-ABI_VERSION = 3
-
-_vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
-_PP = ctypes.POINTER(LsqParams)
-_EP = ctypes.POINTER(LsqFwdExtras)
-_BP = ctypes.POINTER(LsqBwdExtras)
-
-# every symbol include/lsq_hip.h declares: (restype, argtypes)
-C_ABI = {
-    "lsq_hip_abi_version": (_int, []),
-    "lsq_hip_runtime_version": (_i64, []),
-    "lsq_hip_last_error": (ctypes.c_char_p, []),
-    "lsq_hip_grad_scaler": (ctypes.c_double, [_int, _int, _i64, ctypes.c_int32, _i64, ctypes.c_int32, ctypes.c_double]),
-    "lsq_hip_backward_per_tensor_workspace": (_sz, [_int, _i64]),
-    "lsq_hip_forward_per_tensor": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _PP, _EP, _vp]),
-    "lsq_hip_backward_per_tensor": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _PP, _BP, _vp, _sz, _vp]),
-    "lsq_hip_backward_per_channel_workspace": (_sz, [_int, _i64, _i64, _i64]),
-    "lsq_hip_forward_per_channel": (_int, [_int, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP, _EP, _vp]),
-    "lsq_hip_backward_per_channel": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP, _BP,
-                                            _vp, _sz, _vp]),
-    "lsq_hip_per_channel_multi_ok": (_int, [_int, _i64, _i64, _i64, _int]),
-    "lsq_hip_forward_per_channel_multi": (_int, [_int, ctypes.POINTER(LsqPcItem), ctypes.c_int32, _PP, _vp]),
-    "lsq_hip_backward_per_channel_multi": (_int, [_int, ctypes.POINTER(LsqPcItem), ctypes.c_int32, _PP, _vp]),
-    "lsq_hip_backward_from_mask": (_int, [_int, _vp, _vp, _vp, _i64, _vp]),
-    "lsq_hip_minmax_workspace": (_sz, [_int, _i64, _i64, _i64]),
-    "lsq_hip_minmax_per_tensor": (_int, [_int, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
-    "lsq_hip_minmax_per_channel": (_int, [_int, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
-    "lsq_hip_meanstd_workspace": (_sz, [_int, _i64, _i64, _i64]),
-    "lsq_hip_meanstd_per_tensor": (_int, [_int, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
-    "lsq_hip_meanstd_per_channel": (_int, [_int, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
-    "lsq_hip_observer_update": (_int, [_i64, _vp, _vp, _vp, _vp, ctypes.POINTER(LsqObserverUpdate), _vp, _vp, _vp]),
-}
-# NOT bound here: the `_ex` twins (a trailing launch-variant code) and the lsq_hip_debug_* knobs of csrc/lsq_internal.h.
-# They exist only in the tools build of the library (tools/_tune/liblsq_hip_tools.so), which tools/lsq_tools.py loads and
-# swaps in for this module's handle; the `variant` arguments below are for that build and raise on the production library.
-
-
-def _load_library():
-    """dlopen liblsq_hip.so and type its entry points (the replacement of reference extension.py:39-45)."""
-    global _LIB
-    if not os.path.isfile(_LIB_PATH):
-        raise ImportError("%s not found -- build it with `python __graft_entry__.py` or "
-                          "`make -C lsqfakequantize-pytorch_amd/csrc`" % _LIB_PATH)
-    lib = ctypes.CDLL(_LIB_PATH)
-    for name, (res, args) in C_ABI.items():
-        fn = getattr(lib, name)  # AttributeError -> OSError-like failure below
-        fn.restype = res
-        fn.argtypes = args
-    abi = lib.lsq_hip_abi_version()
-    if abi != ABI_VERSION:
-        raise ImportError("liblsq_hip.so has ABI version %d, this package needs %d" % (abi, ABI_VERSION))
-    _LIB = lib
-
-
-try:
-    _load_library()
-    _HAS_OPS = True
-except (ImportError, OSError, AttributeError) as e:  # surfaced by _assert_has_ops(), like the reference
-    error_str = str(e)
-
-
-# The kernels for tensors in host memory (include/lsq_cpu.h): the counterpart of the reference's CPU dispatch.
-_CPU_LIB = None
-_CPU_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblsq_cpu.so")
-cpu_error_str = ""
-C_ABI_CPU = {
-    "lsq_cpu_abi_version": (_int, []),
-    "lsq_cpu_last_error": (ctypes.c_char_p, []),
-    "lsq_cpu_set_num_threads": (None, [_int]),
-    "lsq_cpu_forward_per_tensor": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _PP]),
-    "lsq_cpu_backward_per_tensor": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _PP]),
-    "lsq_cpu_forward_per_channel": (_int, [_int, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP]),
-    "lsq_cpu_backward_per_channel": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP]),
-}
-
-
-def _load_cpu_library():
-    global _CPU_LIB, cpu_error_str
-    try:
-        lib = ctypes.CDLL(_CPU_LIB_PATH)
-        for name, (res, args) in C_ABI_CPU.items():
-            fn = getattr(lib, name)
-            fn.restype = res
-            fn.argtypes = args
-        if lib.lsq_cpu_abi_version() != ABI_VERSION:
-            raise OSError("liblsq_cpu.so was built for another ABI version")
-        _CPU_LIB = lib
-    except (OSError, AttributeError) as e:
-        cpu_error_str = str(e)
-
-
-_load_cpu_library()
-
-
-# The optional second host layer: torchlsq/_lsq_torch.so, the C++ torch binding of the same C ABI
-# (csrc/torch_binding/lsq_torch_binding.cpp, namespace `torchlsq_native`).  It adds no device code; it only
-# moves the per-call tensor bookkeeping and the autograd node from Python to C++.  `functional.lsq` prefers it
-# for GPU tensors; everything in this module keeps working without it.  TORCHLSQ_HOST_BINDING=ctypes skips it.
-_NATIVE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lsq_torch.so")
-_NATIVE_LSQ = None
-native_error_str = ""
-
-
-def _load_native_binding():
-    global _NATIVE_LSQ, native_error_str
-    if os.environ.get("TORCHLSQ_HOST_BINDING", "").lower() == "ctypes":
-        native_error_str = "disabled by TORCHLSQ_HOST_BINDING=ctypes"
-        return
-    if not os.path.isfile(_NATIVE_PATH):
-        native_error_str = "%s not found (make -C lsqfakequantize-pytorch_amd/csrc binding)" % _NATIVE_PATH
-        return
-    try:
-        torch.ops.load_library(_NATIVE_PATH)
-        if int(torch.ops.torchlsq_native._abi_version()) != ABI_VERSION:
-            raise OSError("_lsq_torch.so was built against another ABI version of liblsq_hip.so")
-        _NATIVE_LSQ = torch.ops.torchlsq_native.lsq.default
-    except (OSError, RuntimeError, AttributeError) as e:
-        native_error_str = str(e)
-
-
-if _HAS_OPS:
-    _load_native_binding()
-
-
-def native_lsq():
-    """`torch.ops.torchlsq_native.lsq` (the C++ front op + autograd node) or None when _lsq_torch.so is absent."""
-    return _NATIVE_LSQ
-
-
-def host_binding():
-    """'native' (C++ torch binding loaded) or 'ctypes'."""
-    return "native" if _NATIVE_LSQ is not None else "ctypes"
-
-
-def set_host_binding(kind):
-    """Switch `functional.lsq` between the two host layers at run time (tests, A/B measurements)."""
-    global _NATIVE_LSQ
-    if kind == "ctypes":
-        _NATIVE_LSQ = None
-    elif kind == "native":
-        if not hasattr(torch.ops, "torchlsq_native") or not os.path.isfile(_NATIVE_PATH):
-            raise RuntimeError("the C++ torch binding is not available: %s" % native_error_str)
-        try:
-            _NATIVE_LSQ = torch.ops.torchlsq_native.lsq.default
-        except (AttributeError, RuntimeError):
-            torch.ops.load_library(_NATIVE_PATH)
-            _NATIVE_LSQ = torch.ops.torchlsq_native.lsq.default
-    else:
-        raise ValueError("host binding must be 'native' or 'ctypes'")
-
-
-def _has_ops():
-    return _HAS_OPS
-
-
-def _assert_has_ops():
-    if not _HAS_OPS:
-        raise RuntimeError(
-            "torchlsq (MI355X build): the native HIP library could not be loaded, so the LSQ ops are "
-            "unavailable.  There is no CPU or eager fallback.  Build it with `python __graft_entry__.py` "
-            "(hipcc --offload-arch=gfx950).\n\nImport error details:\n\t%s" % error_str)
-
-
-def library():
-    """The ctypes handle of liblsq_hip.so (raises if it is missing)."""
-    _assert_has_ops()
-    return _LIB
-
-
-def _check_hip_version():
-    """Counterpart of the reference's _check_cuda_version (extension.py:71-96): the HIP runtime the
-    library was compiled against must have the same major version as the one PyTorch uses."""
-    if not _HAS_OPS:
-        return -1
-    v = int(_LIB.lsq_hip_runtime_version())
-    hip = getattr(torch.version, "hip", None)
-    if v > 0 and hip is not None:
-        lib_major = v // 10000000
-        t_major = int(hip.split(".")[0])
-        if lib_major != t_major:
-            raise RuntimeError("Detected that PyTorch and torchlsq were compiled with different HIP versions. "
-                               "PyTorch has HIP Version=%s and torchlsq has HIP_VERSION=%d. "
-                               "Please rebuild torchlsq against your PyTorch's ROCm." % (hip, v))
-    return v
+def __getattr__(name):
+    # loader state lives in _abi (it changes at run time: set_host_binding, set_library); read it through this module too
+    if name in ("_LIB", "_HAS_OPS", "_CPU_LIB", "_NATIVE_LSQ", "error_str", "cpu_error_str", "native_error_str"):
+        return getattr(_abi, name)
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))
 
 
 # -------------------------------------------------------------------------------------------------
@@ -291,597 +77,10 @@ _lib_def.define("lsq_quantize_per_channel(Tensor x, Tensor scale, Tensor shift, 
                 "int quant_max, int type_min, int type_max, int level_bias) -> (Tensor, Tensor)")
 
 
-# -------------------------------------------------------------------------------------------------
-# argument checks (same conditions and messages as the reference's TORCH_CHECKs)
-# -------------------------------------------------------------------------------------------------
-def _check(cond, msg):
-    if not cond:
-        raise RuntimeError(msg)
-
-
-def _param_dtype(x):
-    """dtype scale/shift must have for input x (reference: identical to x, lsq_cpu.cpp:28-29).
-    Extension: 16-bit inputs take fp32 parameters."""
-    return torch.float32 if x.dtype in (torch.bfloat16, torch.float16) else x.dtype
-
-
-def check_forward_dtypes(x, scale, shift):
-    _check(x.dtype in _DTYPE_CODE, '"lsq_forward" not implemented for \'%s\'' % str(x.dtype).replace("torch.", ""))
-    pd = _param_dtype(x)
-    _check(scale.dtype == pd, "`input` and `scale` must have the same floating-point type")
-    _check(shift.dtype == pd, "`input` and `shift` must have the same floating-point type")
-
-
-def check_backward_dtypes(grad, x, scale, shift):
-    _check(x.dtype in _DTYPE_CODE, '"lsq_backward" not implemented for \'%s\'' % str(x.dtype).replace("torch.", ""))
-    pd = _param_dtype(x)
-    _check(grad.dtype == x.dtype, "`grad` and `input` must have the same floating-point type")
-    _check(scale.dtype == pd, "`grad` and `scale` must have the same floating-point type")
-    _check(shift.dtype == pd, "`grad` and `shift` must have the same floating-point type")
-    _check(x.numel() == grad.numel(), "`x` and `grad` are not the same size")
-
-
-def check_channel_args(x, scale, shift, axis, backward):
-    _check(scale.numel() == shift.numel(), "scale and shift need to have the same dimensions")
-    # the reference forward accepts axis == x.dim() (lsq_cpu.cpp:163, off by one) and then fails in
-    # x.size(axis); both directions are rejected here with the reference's message.
-    _check(0 <= axis < x.dim(), "`axis` must be between 0 and number of dimensions of input")
-    _check(scale.numel() == x.size(axis), "dimensions of scale and shift are not consistent with input tensor")
-
 
 # -------------------------------------------------------------------------------------------------
-# memory layout: the kernels see dense memory; find the [outer, C, inner] view of the channel axis
+# the HIP backend ("CUDA" dispatch key on ROCm): _hip_host.py
 # -------------------------------------------------------------------------------------------------
-def _physical_order(t):
-    """dims of t from slowest to fastest varying, or None if t is not dense & non-overlapping."""
-    dims = [d for d in range(t.dim()) if t.size(d) != 1]
-    dims.sort(key=lambda d: (-t.stride(d), d))
-    expect = 1
-    for d in reversed(dims):
-        if t.stride(d) != expect:
-            return None
-        expect *= t.size(d)
-    return dims
-
-
-_ROW_MAJOR = "row-major"   # marker: plain contiguous tensor, physical order == logical order
-
-
-def _dense(t):
-    """(tensor, physical order) with the tensor dense in memory (a contiguous copy if it was not)."""
-    if t.is_contiguous():                      # the common case, one C call
-        return t, _ROW_MAJOR
-    order = _physical_order(t)
-    if order is None:
-        return t.contiguous(), _ROW_MAJOR
-    return t, order
-
-
-def _like_layout(g, x):
-    """grad laid out exactly like the dense x (same strides), copying only if it is not already."""
-    if g.shape == x.shape and g.stride() == x.stride():
-        return g
-    out = torch.empty_like(x)  # preserve_format: x is dense, so strides are kept
-    out.copy_(g.reshape(x.shape) if g.shape != x.shape else g)
-    return out
-
-
-def _ocl(x, order, axis):
-    """[outer, C, inner] of dense x for channel `axis`, in memory order."""
-    shape = x.shape
-    if order is _ROW_MAJOR:
-        outer = 1
-        for d in shape[:axis]:
-            outer *= d
-        inner = 1
-        for d in shape[axis + 1:]:
-            inner *= d
-        return outer, shape[axis], inner
-    if axis not in order:  # a size-1 channel dimension: one channel covering the whole tensor
-        return 1, 1, x.numel()
-    k = order.index(axis)
-    outer = 1
-    for d in order[:k]:
-        outer *= shape[d]
-    inner = 1
-    for d in order[k + 1:]:
-        inner *= shape[d]
-    return outer, shape[axis], inner
-
-
-# -------------------------------------------------------------------------------------------------
-# the HIP backend ("CUDA" dispatch key on ROCm).  Host cost per call matters for small layers, so the
-# steady-state path is: a few C-level tensor queries, one cached lsq_params struct, two or three
-# allocator calls, one ctypes call -- no context managers, no per-call struct construction.
-# -------------------------------------------------------------------------------------------------
-_PARAMS_CACHE = {}
-
-
-def _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode, numel_for_scaler=0):
-    """(struct, byref) for the scalar arguments; immutable, cached per distinct argument tuple."""
-    key = (qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode, numel_for_scaler)
-    hit = _PARAMS_CACHE.get(key)
-    if hit is not None:
-        return hit
-    for name, v in (("quant_min", qmin), ("quant_max", qmax), ("type_min", tmin), ("type_max", tmax)):
-        _check(-2 ** 31 <= int(v) < 2 ** 31, "%s=%d does not fit a 32-bit integer" % (name, v))
-    p = LsqParams(int(qmin), int(qmax), int(tmin), int(tmax), int(bool(use_gs)), int(bool(sym)),
-                  int(bool(eval_mode)), int(bool(init_mode)), float(gs), int(numel_for_scaler))
-    hit = (p, ctypes.byref(p))
-    if len(_PARAMS_CACHE) < 4096:
-        _PARAMS_CACHE[key] = hit
-    return hit
-
-
-def _status(rc, what):
-    if rc != 0:
-        raise RuntimeError("%s failed (%d): %s" % (what, rc, _LIB.lsq_hip_last_error().decode("utf-8", "replace")))
-
-
-def _entry(name, variant):
-    """(C entry point, trailing arguments): the include/lsq_hip.h symbol, or -- `variant` != 0, tools build only -- its
-    `_ex` twin with the launch-variant code appended."""
-    if not variant:
-        return getattr(_LIB, name), ()
-    fn = getattr(_LIB, name + "_ex", None)
-    if fn is None:
-        raise RuntimeError("launch variants need the tools build of the library (make -C lsqfakequantize-pytorch_amd/csrc "
-                           "tools; tools/lsq_tools.py): liblsq_hip.so exports only include/lsq_hip.h")
-    return fn, (int(variant),)
-
-
-_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
-
-
-def _stream_of(index):
-    if _raw_stream is not None:
-        return _raw_stream(index)
-    return torch.cuda.current_stream(index).cuda_stream
-
-
-def _on_device(index, fn, *args):
-    """Call the C entry point with `index` as the current HIP device (kernels launch on the current device)."""
-    if torch.cuda.current_device() == index:
-        return fn(*args)
-    with torch.cuda.device(index):
-        return fn(*args)
-
-
-_WS_BYTES_PT = [0]
-
-
-def _workspace(device, nbytes):
-    # a fresh caching-allocator block per call: stream-ordered reuse is the allocator's job, and
-    # forward/backward threads never share one.
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
-
-
-# ---- tickets (lsq_bwd_extras): persistent per-stream arrival counters that make the backward ONE launch -------------
-# The C ABI wants LSQ_TICKET_BYTES of zero-initialised device memory that outlives the call and is never shared by
-# launches that can run concurrently.  One slab of _TICKET_SLOTS tickets per device is allocated (and zeroed) at the
-# first eager backward on that device; streams get a slot each on first use.  Kernels of one stream are serialised by the
-# stream; launches captured into a HIP graph take no ticket (see _ticket).
-# Measured on MI355X (profiles/r02_ticket_single_launch.txt): the single-launch route is NOT faster -- the last workgroup's
-# serial chain (drain its dx stores, agent-scope counter round trip, agent-scope loads of the partials) costs as much
-# as the finalize kernel's launch (config 1 backward 8.0 us against 6.9 us; config 2 / 4 unchanged) -- so it is off unless
-# asked for: TORCHLSQ_SINGLE_LAUNCH_BACKWARD=1 or set_single_launch_backward(True).
-_SINGLE_LAUNCH_BWD = [os.environ.get("TORCHLSQ_SINGLE_LAUNCH_BACKWARD", "0") == "1"]
-
-
-def set_single_launch_backward(on):
-    """Use tickets (one launch per backward) in both host layers from now on."""
-    _SINGLE_LAUNCH_BWD[0] = bool(on)
-    if hasattr(torch.ops, "torchlsq_native") and _NATIVE_LSQ is not None:
-        torch.ops.torchlsq_native._set_single_launch_backward(bool(on))
-
-
-_TICKET_SLOTS = 64
-_TICKET_SLABS = {}     # device index -> (slab tensor, base pointer, [next free slot])
-_TICKETS = {}          # (device index, raw stream) -> byref(LsqBwdExtras)
-_TICKET_KEEP = []      # the structs behind the byrefs
-_TICKET_LOCK = threading.Lock()   # backward runs on autograd engine threads (one per device), forward-side callers on others
-
-
-def _ticket(idx, stream):
-    # A launch that is being CAPTURED into a HIP graph gets no ticket (two-launch route): the graph may later be replayed on
-    # any stream, next to eager work or another replay on the capture stream, and two concurrent launches must never share
-    # an arrival counter.
-    if torch.cuda.is_current_stream_capturing():
-        return None
-    key = (idx, stream)
-    hit = _TICKETS.get(key)          # (a dict read is atomic under the GIL; entries are never removed or changed)
-    if hit is not None:
-        return hit
-    with _TICKET_LOCK:
-        return _ticket_locked(idx, stream, key)
-
-
-def _ticket_locked(idx, stream, key):
-    hit = _TICKETS.get(key)
-    if hit is not None:
-        return hit
-    slab = _TICKET_SLABS.get(idx)
-    if slab is None:
-        t = torch.zeros(_TICKET_SLOTS * LSQ_TICKET_BYTES // 4, dtype=torch.int32, device=torch.device("cuda", idx))
-        torch.cuda.current_stream(idx).synchronize()      # zeroed before any other stream may use a slot (one-off)
-        slab = _TICKET_SLABS[idx] = (t, t.data_ptr(), [0])
-    if slab[2][0] >= _TICKET_SLOTS:
-        return None                                       # more streams than slots: two-launch route for the rest
-    ex = LsqBwdExtras(slab[1] + slab[2][0] * LSQ_TICKET_BYTES)
-    slab[2][0] += 1
-    _TICKET_KEEP.append(ex)
-    hit = _TICKETS[key] = ctypes.byref(ex)
-    return hit
-
-
-def _require_gpu(what, *tensors):
-    """Every tensor of a call lives on the GPU the kernel is launched on (the first tensor's): raw pointers of
-    another device would only work by accident of peer access."""
-    dev = tensors[0].device
-    for t in tensors:
-        if not t.is_cuda:
-            raise RuntimeError("%s: expected a tensor on the GPU (HIP device) but got device %s" % (what, t.device))
-        if t.device != dev:
-            raise RuntimeError("%s: expected all tensors on %s but got one on %s" % (what, dev, t.device))
-
-
-def _require_param(what, scale, shift):
-    if scale.numel() < 1 or shift.numel() < 1:
-        raise RuntimeError("%s: scale and shift need at least one element" % what)
-
-
-def _aux_output(xd, levels_bias, want_mask):
-    """(aux tensor, byref(lsq_fwd_extras)) for the optional one-byte-per-element output of the forward."""
-    if levels_bias is None and not want_mask:
-        return None, None
-    aux = torch.empty_strided(xd.shape, xd.stride(), dtype=torch.int8, device=xd.device)
-    ex = LsqFwdExtras(aux.data_ptr(), 0 if want_mask else int(levels_bias), 1 if want_mask else 0)
-    return aux, ctypes.byref(ex)
-
-
-def hip_forward_per_tensor(x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode,
-                           levels_bias=None, variant=0, want_mask=False):
-    _assert_has_ops()
-    check_forward_dtypes(x, scale, shift)
-    _require_gpu("lsq_forward_per_tensor", x, scale, shift)
-    xd, _ = _dense(x)
-    y = torch.empty_like(xd)
-    n = xd.numel()
-    has_aux = levels_bias is not None or want_mask
-    if n == 0:
-        return (y, torch.empty(x.shape, dtype=torch.int8, device=x.device)) if has_aux else y
-    _require_param("lsq_forward_per_tensor", scale, shift)
-    lv, ex = _aux_output(xd, levels_bias, want_mask)
-    _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
-    scale_c, shift_c = scale.contiguous(), shift.contiguous()
-    idx = x.device.index
-    fn, tail = _entry("lsq_hip_forward_per_tensor", variant)
-    rc = _on_device(idx, fn, _DTYPE_CODE[x.dtype], xd.data_ptr(), y.data_ptr(), n,
-                    scale_c.data_ptr(), shift_c.data_ptr(), pref, ex, _stream_of(idx), *tail)
-    if rc:
-        _status(rc, "lsq_hip_forward_per_tensor")
-    return (y, lv) if has_aux else y
-
-
-def hip_backward_per_tensor(grad, x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode,
-                            numel_for_scaler=0, want_wide=False, variant=0, use_ticket=None):
-    _assert_has_ops()
-    check_backward_dtypes(grad, x, scale, shift)
-    if x.numel() <= 0:  # lsq_cpu.cpp:76-78 returns (x, scale, shift) themselves
-        if want_wide:
-            return x.clone(), torch.zeros(2, dtype=torch.float64, device=x.device)
-        return x.clone(), scale.clone(), shift.clone()
-    _require_gpu("lsq_backward_per_tensor", x, grad, scale, shift)
-    _require_param("lsq_backward_per_tensor", scale, shift)
-    xd, _ = _dense(x)
-    gd = _like_layout(grad, xd)
-    dx = torch.empty_like(xd)
-    pd = _param_dtype(x)
-    dev = x.device
-    ds = torch.empty(1, dtype=pd, device=dev)
-    db = torch.empty(1, dtype=pd, device=dev)
-    wide = torch.empty(2, dtype=torch.float64, device=dev) if want_wide else None
-    _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode, numel_for_scaler)
-    code = _DTYPE_CODE[x.dtype]
-    scale_c, shift_c = scale.contiguous(), shift.contiguous()
-    if not _WS_BYTES_PT[0]:
-        _WS_BYTES_PT[0] = int(_LIB.lsq_hip_backward_per_tensor_workspace(code, xd.numel()))   # a constant
-    ws = _workspace(dev, _WS_BYTES_PT[0])
-    idx = dev.index
-    stream = _stream_of(idx)
-    if use_ticket is None:
-        use_ticket = _SINGLE_LAUNCH_BWD[0]
-    fn, tail = _entry("lsq_hip_backward_per_tensor", variant)
-    rc = _on_device(idx, fn, code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(),
-                    ds.data_ptr(), db.data_ptr(), wide.data_ptr() if want_wide else None, xd.numel(),
-                    scale_c.data_ptr(), shift_c.data_ptr(), pref, _ticket(idx, stream) if use_ticket else None,
-                    ws.data_ptr(), ws.numel(), stream, *tail)
-    if rc:
-        _status(rc, "lsq_hip_backward_per_tensor")
-    if want_wide:
-        return dx, wide
-    return dx, ds, db
-
-
-def hip_forward_per_channel(x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode,
-                            levels_bias=None, variant=0, want_mask=False):
-    _assert_has_ops()
-    check_forward_dtypes(x, scale, shift)
-    check_channel_args(x, scale, shift, axis, backward=False)
-    _require_gpu("lsq_forward_per_channel", x, scale, shift)
-    xd, order = _dense(x)
-    y = torch.empty_like(xd)
-    has_aux = levels_bias is not None or want_mask
-    if x.numel() == 0:
-        return (y, torch.empty(x.shape, dtype=torch.int8, device=x.device)) if has_aux else y
-    outer, C, inner = _ocl(xd, order, axis)
-    lv, ex = _aux_output(xd, levels_bias, want_mask)
-    _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
-    scale_c, shift_c = scale.contiguous(), shift.contiguous()
-    idx = x.device.index
-    fn, tail = _entry("lsq_hip_forward_per_channel", variant)
-    rc = _on_device(idx, fn, _DTYPE_CODE[x.dtype], xd.data_ptr(), y.data_ptr(), outer,
-                    C, inner, scale_c.data_ptr(), shift_c.data_ptr(), pref, ex, _stream_of(idx), *tail)
-    if rc:
-        _status(rc, "lsq_hip_forward_per_channel")
-    return (y, lv) if has_aux else y
-
-
-def hip_backward_from_mask(grad, mask):
-    """dx = grad * mask: the eval-mode backward (lsq_kernel.h:126-145) from the one-byte inside mask the
-    forward saved (`want_mask=True`) -- per-tensor and per-channel alike."""
-    _assert_has_ops()
-    _check(grad.dtype in _DTYPE_CODE, '"lsq_backward" not implemented for \'%s\'' % str(grad.dtype).replace("torch.", ""))
-    _check(mask.dtype == torch.int8 and mask.numel() == grad.numel(), "`mask` must be the int8 inside mask of the forward")
-    _require_gpu("lsq_backward_from_mask", grad, mask)
-    if grad.shape == mask.shape and grad.stride() == mask.stride():
-        gd = grad
-    else:
-        gd = torch.empty_strided(mask.shape, mask.stride(), dtype=grad.dtype, device=grad.device)
-        gd.copy_(grad.reshape(mask.shape) if grad.shape != mask.shape else grad)
-    dx = torch.empty_strided(mask.shape, mask.stride(), dtype=grad.dtype, device=grad.device)
-    if grad.numel() == 0:
-        return dx
-    idx = grad.device.index
-    rc = _on_device(idx, _LIB.lsq_hip_backward_from_mask, _DTYPE_CODE[grad.dtype], gd.data_ptr(), mask.data_ptr(),
-                    dx.data_ptr(), gd.numel(), _stream_of(idx))
-    if rc:
-        _status(rc, "lsq_hip_backward_from_mask")
-    return dx
-
-
-def _pc_workspace_bytes(idx, code, outer, C, inner):
-    return int(_on_device(idx, _LIB.lsq_hip_backward_per_channel_workspace, code, outer, C, inner))
-
-
-_WS_BYTES_PC = {}
-
-
-def hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode,
-                             init_mode, numel_for_scaler=0, want_wide=False, variant=0, use_ticket=None):
-    _assert_has_ops()
-    check_backward_dtypes(grad, x, scale, shift)
-    check_channel_args(x, scale, shift, axis, backward=True)
-    if x.numel() <= 0:  # lsq_cpu.cpp:221-223
-        if want_wide:
-            return x.clone(), torch.zeros(2, scale.numel(), dtype=torch.float64, device=x.device)
-        return x.clone(), scale.clone(), shift.clone()
-    _require_gpu("lsq_backward_per_channel", x, grad, scale, shift)
-    xd, order = _dense(x)
-    gd = _like_layout(grad, xd)
-    dx = torch.empty_like(xd)
-    outer, C, inner = _ocl(xd, order, axis)
-    pd = _param_dtype(x)
-    dev = x.device
-    idx = dev.index
-    ds = torch.empty(C, dtype=pd, device=dev)
-    db = torch.empty(C, dtype=pd, device=dev)
-    wide = torch.empty(2, C, dtype=torch.float64, device=dev) if want_wide else None
-    _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode, numel_for_scaler)
-    code = _DTYPE_CODE[x.dtype]
-    scale_c, shift_c = scale.contiguous(), shift.contiguous()
-    wkey = (idx, code, outer, C, inner)
-    nbytes = _WS_BYTES_PC.get(wkey)
-    if nbytes is None:
-        nbytes = _pc_workspace_bytes(idx, code, outer, C, inner)
-        if len(_WS_BYTES_PC) < 4096:
-            _WS_BYTES_PC[wkey] = nbytes
-    ws = _workspace(dev, nbytes)
-    stream = _stream_of(idx)
-    if use_ticket is None:
-        use_ticket = _SINGLE_LAUNCH_BWD[0]
-    fn, tail = _entry("lsq_hip_backward_per_channel", variant)
-    rc = _on_device(idx, fn, code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(),
-                    ds.data_ptr(), db.data_ptr(), wide.data_ptr() if want_wide else None, outer, C, inner,
-                    scale_c.data_ptr(), shift_c.data_ptr(), pref, _ticket(idx, stream) if use_ticket else None,
-                    ws.data_ptr(), ws.numel(), stream, *tail)
-    if rc:
-        _status(rc, "lsq_hip_backward_per_channel")
-    if want_wide:
-        return dx, wide
-    return dx, ds, db
-
-
-# ---- many per-channel quantizers in one launch (lsq_hip_*_per_channel_multi) ----------------------------------------------
-_MULTI_OK = {}
-
-
-def hip_multi_eligible(x, axis):
-    """Can the per-channel quantizer of GPU tensor `x` along `axis` take part in a multi-tensor launch?  (Tensors the
-    single-tensor policy walks with one workgroup per channel: conv / linear weights on axis 0 and the like.)"""
-    if not _HAS_OPS or not x.is_cuda or x.dtype not in _DTYPE_CODE or x.numel() == 0 or not (0 <= axis < x.dim()):
-        return False
-    if not x.is_contiguous() or (x.data_ptr() & 15):
-        return False
-    shape = tuple(x.shape)
-    key = (x.device.index, x.dtype, shape, axis)
-    hit = _MULTI_OK.get(key)
-    if hit is None:
-        outer, C, inner = _ocl(x, _ROW_MAJOR, axis)
-        hit = bool(_on_device(x.device.index, _LIB.lsq_hip_per_channel_multi_ok, _DTYPE_CODE[x.dtype], outer, C, inner, 1))
-        if len(_MULTI_OK) < 65536:
-            _MULTI_OK[key] = hit
-    return hit
-
-
-def _multi_table(n):
-    return (LsqPcItem * n)()
-
-
-def hip_forward_per_channel_multi(xs, scales, shifts, axes, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode):
-    """y_i = fake_quant(x_i) for every tensor of the lists in ONE launch per 32 tensors.  Every x_i must satisfy
-    hip_multi_eligible(x_i, axes[i]); all tensors on one GPU, one storage type."""
-    _assert_has_ops()
-    n = len(xs)
-    dev, dt = xs[0].device, xs[0].dtype
-    table = _multi_table(n)
-    ys = []
-    for i in range(n):
-        x, scale, shift = xs[i], scales[i], shifts[i]
-        check_forward_dtypes(x, scale, shift)
-        check_channel_args(x, scale, shift, axes[i], backward=False)
-        _require_gpu("lsq_forward_per_channel_multi", xs[0], x, scale, shift)
-        _check(x.dtype == dt, "lsq_forward_per_channel_multi: all tensors must have the same floating-point type")
-        _check(hip_multi_eligible(x, axes[i]), "lsq_forward_per_channel_multi: tensor %d cannot take part in a multi-tensor launch" % i)
-        y = torch.empty_like(x)
-        outer, C, inner = _ocl(x, _ROW_MAJOR, axes[i])
-        sc, sh = scale.contiguous(), shift.contiguous()
-        it = table[i]
-        it.x, it.y, it.scale, it.shift = x.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr()
-        it.outer, it.channels, it.inner = outer, C, inner
-        ys.append((y, sc, sh))
-    _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
-    idx = dev.index
-    rc = _on_device(idx, _LIB.lsq_hip_forward_per_channel_multi, _DTYPE_CODE[dt], table, n, pref, _stream_of(idx))
-    if rc:
-        _status(rc, "lsq_hip_forward_per_channel_multi")
-    return [y for y, _, _ in ys]
-
-
-def hip_backward_per_channel_multi(grads, xs, scales, shifts, axes, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode,
-                                   init_mode):
-    """(dx_i, ds_i, db_i) for every tensor of the lists in ONE launch per 32 tensors (no workspace, no finalize launch)."""
-    _assert_has_ops()
-    n = len(xs)
-    dev, dt = xs[0].device, xs[0].dtype
-    table = _multi_table(n)
-    outs, keep = [], []
-    for i in range(n):
-        x, g, scale, shift = xs[i], grads[i], scales[i], shifts[i]
-        check_backward_dtypes(g, x, scale, shift)
-        check_channel_args(x, scale, shift, axes[i], backward=True)
-        _require_gpu("lsq_backward_per_channel_multi", xs[0], x, g, scale, shift)
-        _check(x.dtype == dt, "lsq_backward_per_channel_multi: all tensors must have the same floating-point type")
-        _check(hip_multi_eligible(x, axes[i]), "lsq_backward_per_channel_multi: tensor %d cannot take part in a multi-tensor launch" % i)
-        gd = _like_layout(g, x)
-        if gd.data_ptr() & 15:
-            gd = gd.clone()
-        dx = torch.empty_like(x)
-        outer, C, inner = _ocl(x, _ROW_MAJOR, axes[i])
-        pd = _param_dtype(x)
-        ds = torch.empty(C, dtype=pd, device=dev)
-        db = torch.empty(C, dtype=pd, device=dev)
-        sc, sh = scale.contiguous(), shift.contiguous()
-        it = table[i]
-        it.x, it.grad, it.dx, it.scale, it.shift = x.data_ptr(), gd.data_ptr(), dx.data_ptr(), sc.data_ptr(), sh.data_ptr()
-        it.ds, it.db = ds.data_ptr(), db.data_ptr()
-        it.outer, it.channels, it.inner = outer, C, inner
-        outs.append((dx, ds, db))
-        keep.append((gd, sc, sh))
-    _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
-    idx = dev.index
-    rc = _on_device(idx, _LIB.lsq_hip_backward_per_channel_multi, _DTYPE_CODE[dt], table, n, pref, _stream_of(idx))
-    if rc:
-        _status(rc, "lsq_hip_backward_per_channel_multi")
-    return outs
-
-
-_WS_BYTES_MM = {}
-
-
-def _two_stats(x, axis, what, ws_fn, pt_fn, pc_fn):
-    """Shared host path of the one-pass statistics kernels: two results, scalar (axis None) or per channel."""
-    _assert_has_ops()
-    _check(x.dtype in _DTYPE_CODE, '"%s" not implemented for \'%s\'' % (what, str(x.dtype).replace("torch.", "")))
-    _check(x.numel() > 0, "%s: cannot reduce an empty tensor" % what)
-    _require_gpu(what, x)
-    xd, order = _dense(x.detach())
-    pd = _param_dtype(x)
-    dev = x.device
-    idx = dev.index
-    code = _DTYPE_CODE[x.dtype]
-    if axis is None:
-        outer, C, inner = 1, 1, xd.numel()
-    else:
-        _check(0 <= axis < x.dim(), "`axis` must be between 0 and number of dimensions of input")
-        outer, C, inner = _ocl(xd, order, axis)
-    a = torch.empty(C, dtype=pd, device=dev)
-    b = torch.empty(C, dtype=pd, device=dev)
-    wkey = (what, idx, code, outer, C, inner)
-    nbytes = _WS_BYTES_MM.get(wkey)
-    if nbytes is None:
-        nbytes = int(_on_device(idx, ws_fn, code, outer, C, inner))
-        if len(_WS_BYTES_MM) < 4096:
-            _WS_BYTES_MM[wkey] = nbytes
-    ws = _workspace(dev, nbytes)
-    if axis is None:
-        rc = _on_device(idx, pt_fn, code, xd.data_ptr(), xd.numel(), a.data_ptr(), b.data_ptr(),
-                        ws.data_ptr(), ws.numel(), _stream_of(idx))
-    else:
-        rc = _on_device(idx, pc_fn, code, xd.data_ptr(), outer, C, inner, a.data_ptr(),
-                        b.data_ptr(), ws.data_ptr(), ws.numel(), _stream_of(idx))
-    if rc:
-        _status(rc, what)
-    if axis is None:
-        return a.reshape(()), b.reshape(())
-    return a, b
-
-
-_OBS_UPDATE_CACHE = {}
-
-
-def hip_observer_update(cur_min, cur_max, min_state, max_state, scale_out, shift_out, mode, first, averaging_constant,
-                        quant_min, quant_max, symmetric, zero_point_symmetric, eps):
-    """One launch: fold the batch's min / max into an observer's running state (in place), derive torch's qparams
-    from it and store the LSQ parameters scale / shift = -zero_point * scale (lsq_hip_observer_update).  All fp32,
-    one element per channel; nothing is read back to the host."""
-    _assert_has_ops()
-    tensors = (cur_min, cur_max, min_state, max_state, scale_out, shift_out)
-    _require_gpu("lsq_observer_update", *tensors)
-    n = min_state.numel()
-    for t in tensors:
-        _check(t.dtype == torch.float32 and t.numel() == n and t.is_contiguous(),
-               "lsq_observer_update: every tensor must be a contiguous float32 tensor with one element per channel")
-    key = (mode, first, float(averaging_constant), quant_min, quant_max, bool(symmetric), zero_point_symmetric, float(eps))
-    hit = _OBS_UPDATE_CACHE.get(key)
-    if hit is None:
-        u = LsqObserverUpdate(int(mode), int(first), float(averaging_constant), int(quant_min), int(quant_max),
-                              int(bool(symmetric)), int(zero_point_symmetric), float(eps))
-        hit = _OBS_UPDATE_CACHE[key] = (u, ctypes.byref(u))
-    idx = min_state.device.index
-    rc = _on_device(idx, _LIB.lsq_hip_observer_update, n, cur_min.data_ptr(), cur_max.data_ptr(), min_state.data_ptr(),
-                    max_state.data_ptr(), hit[1], scale_out.data_ptr(), shift_out.data_ptr(), _stream_of(idx))
-    if rc:
-        _status(rc, "lsq_hip_observer_update")
-
-
-def hip_minmax(x, axis=None):
-    """(min, max) of x -- over everything (axis None) or per channel along `axis` -- in one read-only pass.
-    torch.aminmax semantics (a NaN makes both results NaN); results are fp32 (fp64 for fp64 input)."""
-    _assert_has_ops()
-    return _two_stats(x, axis, "lsq_minmax", _LIB.lsq_hip_minmax_workspace, _LIB.lsq_hip_minmax_per_tensor,
-                      _LIB.lsq_hip_minmax_per_channel)
-
-
-def hip_meanstd(x, axis=None):
-    """(mean, unbiased std) of x -- over everything (axis None) or per channel along `axis`, over the other axes --
-    in one read-only pass (reference observers.py:329-337 uses torch.mean + torch.std); fp64 accumulation,
-    results fp32 (fp64 for fp64 input)."""
-    _assert_has_ops()
-    return _two_stats(x, axis, "lsq_meanstd", _LIB.lsq_hip_meanstd_workspace, _LIB.lsq_hip_meanstd_per_tensor,
-                      _LIB.lsq_hip_meanstd_per_channel)
-
-
 def _impl_minmax_pt(x):
     return hip_minmax(x, None)
 
@@ -954,114 +153,8 @@ _lib_hip.impl("lsq_meanstd_per_tensor", _impl_meanstd_pt)
 _lib_hip.impl("lsq_meanstd_per_channel", _impl_meanstd_pc)
 
 
-# -------------------------------------------------------------------------------------------------
-# the CPU backend ("CPU" dispatch key): host-memory tensors -> liblsq_cpu.so, the counterpart of the reference's
-# TORCH_LIBRARY_IMPL(torchlsq, CPU) (lsq_cpu.cpp:298-311).  Same checks, same layout handling, same outputs as the HIP
-# backend above; never reached by a GPU tensor.
-# -------------------------------------------------------------------------------------------------
-def _cpu_lib(what):
-    _assert_has_ops()      # the package as a whole needs its HIP library: CPU tensors do not make it usable on their own
-    if _CPU_LIB is None:
-        raise NotImplementedError("%s: the CPU kernels (liblsq_cpu.so) are not available: %s" % (what, cpu_error_str))
-    _CPU_LIB.lsq_cpu_set_num_threads(torch.get_num_threads())     # the loops follow torch's intra-op thread setting
-    return _CPU_LIB
 
-
-def _require_cpu(what, *tensors):
-    for t in tensors:
-        if t.device.type != "cpu":
-            raise RuntimeError("%s: expected all tensors on the CPU but got one on %s" % (what, t.device))
-
-
-def _cpu_status(rc, what):
-    if rc != 0:
-        raise RuntimeError("%s failed (%d): %s" % (what, rc, _CPU_LIB.lsq_cpu_last_error().decode("utf-8", "replace")))
-
-
-def _cpu_dtype(x, what):
-    _check(x.dtype in (torch.float32, torch.float64, torch.bfloat16),
-           '"%s" not implemented for \'%s\'' % (what, str(x.dtype).replace("torch.", "")))
-    return _DTYPE_CODE[x.dtype]
-
-
-def cpu_forward(x, scale, shift, axis, per_channel, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode):
-    what = "lsq_forward_per_channel" if per_channel else "lsq_forward_per_tensor"
-    lib = _cpu_lib(what)
-    code = _cpu_dtype(x, "lsq_forward")
-    check_forward_dtypes(x, scale, shift)
-    if per_channel:
-        check_channel_args(x, scale, shift, axis, backward=False)
-    _require_cpu(what, x, scale, shift)
-    xd, order = _dense(x)
-    y = torch.empty_like(xd)
-    if xd.numel() == 0:
-        return y
-    _require_param(what, scale, shift)
-    _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
-    sc, sh = scale.contiguous(), shift.contiguous()
-    if per_channel:
-        outer, C, inner = _ocl(xd, order, axis)
-        rc = lib.lsq_cpu_forward_per_channel(code, xd.data_ptr(), y.data_ptr(), outer, C, inner, sc.data_ptr(), sh.data_ptr(), pref)
-    else:
-        rc = lib.lsq_cpu_forward_per_tensor(code, xd.data_ptr(), y.data_ptr(), xd.numel(), sc.data_ptr(), sh.data_ptr(), pref)
-    _cpu_status(rc, what)
-    return y
-
-
-def cpu_backward(grad, x, scale, shift, axis, per_channel, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode,
-                 numel_for_scaler=0, want_wide=False):
-    what = "lsq_backward_per_channel" if per_channel else "lsq_backward_per_tensor"
-    lib = _cpu_lib(what)
-    code = _cpu_dtype(x, "lsq_backward")
-    check_backward_dtypes(grad, x, scale, shift)
-    if per_channel:
-        check_channel_args(x, scale, shift, axis, backward=True)
-    C = scale.numel() if per_channel else 1
-    if x.numel() <= 0:  # lsq_cpu.cpp:76-78, :221-223 return (x, scale, shift) themselves
-        if want_wide:
-            return x.clone(), torch.zeros((2, C) if per_channel else (2,), dtype=torch.float64)
-        return x.clone(), scale.clone(), shift.clone()
-    _require_cpu(what, x, grad, scale, shift)
-    _require_param(what, scale, shift)
-    xd, order = _dense(x)
-    gd = _like_layout(grad, xd)
-    dx = torch.empty_like(xd)
-    pd = _param_dtype(x)
-    ds, db = torch.empty(C, dtype=pd), torch.empty(C, dtype=pd)
-    wide = torch.empty((2, C) if per_channel else (2,), dtype=torch.float64) if want_wide else None
-    _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode, numel_for_scaler)
-    sc, sh = scale.contiguous(), shift.contiguous()
-    wptr = wide.data_ptr() if want_wide else None
-    if per_channel:
-        outer, C_, inner = _ocl(xd, order, axis)
-        rc = lib.lsq_cpu_backward_per_channel(code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(), ds.data_ptr(), db.data_ptr(),
-                                              wptr, outer, C_, inner, sc.data_ptr(), sh.data_ptr(), pref)
-    else:
-        rc = lib.lsq_cpu_backward_per_tensor(code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(), ds.data_ptr(), db.data_ptr(),
-                                             wptr, xd.numel(), sc.data_ptr(), sh.data_ptr(), pref)
-    _cpu_status(rc, what)
-    if want_wide:
-        return dx, wide
-    return dx, ds, db
-
-
-def _cpu_minmax(x, axis=None):
-    """torch's own reductions: the stock observers' arithmetic (reference observers.py:446-449 calls them on CPU tensors)"""
-    y = x.detach().to(_param_dtype(x))
-    if axis is None:
-        return torch.aminmax(y)
-    dims = [d for d in range(x.dim()) if d != axis]
-    return torch.amin(y, dims), torch.amax(y, dims)
-
-
-def _cpu_meanstd(x, axis=None):
-    y = x.detach().to(_param_dtype(x))
-    if axis is None:
-        return y.mean(), y.std()
-    dims = [d for d in range(x.dim()) if d != axis]
-    return torch.mean(y, dims), torch.std(y, dims)
-
-
+# the CPU backend ("CPU" dispatch key): _cpu_host.py
 _lib_cpu = torch.library.Library("torchlsq", "IMPL", "CPU")
 _lib_cpu.impl("lsq_forward_per_tensor", lambda x, s, b, *a: cpu_forward(x, s, b, 0, False, *a))
 _lib_cpu.impl("lsq_backward_per_tensor", lambda g, x, s, b, *a: cpu_backward(g, x, s, b, 0, False, *a))
@@ -1220,7 +313,7 @@ _lib_def.impl("lsq", _lsq_front, "CompositeImplicitAutograd")
 def _runtime_version():
     """torchlsq::_cuda_version of this build: the HIP_VERSION the kernels were compiled with, or -1
     when the native library is missing (reference torchlsq.cpp:25-31 returns CUDA_VERSION / -1)."""
-    return int(_LIB.lsq_hip_runtime_version()) if _HAS_OPS else -1
+    return int(_abi._LIB.lsq_hip_runtime_version()) if _abi._HAS_OPS else -1
 
 
 _lib_def.impl("_cuda_version", _runtime_version, "CompositeExplicitAutograd")

@@ -116,13 +116,14 @@ def test_cpu_library_exports_its_header_and_devices_never_substitute():
     y = torch.ops.torchlsq.lsq_forward_per_tensor(x, s, b, 0, 127, 0, 255, True, 1.0, False, False, False)
     assert y.device.type == "cpu" and y.shape == x.shape and not torch.equal(y, x)
     # the package is the MI355X build: no HIP library -> nothing works, CPU tensors included
-    saved = E._HAS_OPS
-    E._HAS_OPS = False
+    from torchlsq import _abi
+    saved = _abi._HAS_OPS
+    _abi._HAS_OPS = False
     try:
         with pytest.raises(RuntimeError, match="native HIP library could not be loaded"):
             torch.ops.torchlsq.lsq_forward_per_tensor(x, s, b, 0, 127, 0, 255, True, 1.0, False, False, False)
     finally:
-        E._HAS_OPS = saved
+        _abi._HAS_OPS = saved
     # a CPU parameter next to a GPU tensor (or the reverse) is an error, not a silent copy
     with pytest.raises(RuntimeError, match="expected all tensors on the CPU"):
         E.cpu_forward(x, s.to("meta"), b, 0, False, 0, 127, 0, 255, True, 1.0, False, False, False)

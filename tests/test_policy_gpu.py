@@ -67,14 +67,20 @@ def _rows(elements, C):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_small_tensor_floor_2p21_elements(T, dtype):
-    """below 2^21 elements a workgroup takes as few rows as the grid target allows (latency regime), above it at least the
-    rows that keep the partial-sum traffic under ~5 %"""
-    lo, hi = _rows(1 << 21, 768)
-    (_, b_lo), (_, b_hi) = _case(T, (lo, 768), 1, dtype), _case(T, (hi, 768), 1, dtype)
-    assert b_lo["kind"] == b_hi["kind"] == "row-groups"
-    rows_per_wg = lambda note, rows: rows / note["grid_y"]
-    assert rows_per_wg(b_lo, lo) < rows_per_wg(b_hi, hi), (b_lo, b_hi)      # the floor binds only above the threshold
+def test_rows_per_workgroup_floor_gives_way_to_one_workgroup_per_cu(T, dtype):
+    """the floor on the rows a workgroup walks (partial-sum traffic under ~5 %) binds only once every CU has a workgroup:
+    smaller tensors spread their row tiles over the CUs instead -- a smooth rule, no size switch: as soon as there are row
+    tiles for every CU the grid covers the chip (within the rounding to whole tiles per workgroup), on both sides of the 2^21
+    elements where round 2 switched, and a small tensor is not cut into more pieces than it has rows"""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    for rows in (128, 600, 1900, 2730, 2731, 3600, 8000):
+        _, b = _case(T, (rows, 768), 1, dtype)
+        wgs = b["grid_x"] * b["grid_y"]
+        assert b["kind"] == "row-groups", (rows, b)
+        assert wgs <= b["grid_x"] * rows, (rows, b)
+        assert wgs >= min(b["grid_x"] * (rows // 4), cus) * 0.75, (rows, b)     # (a row tile: one to four rows)
+    (_, lo), (_, hi) = _case(T, (2730, 768), 1, dtype), _case(T, (2731, 768), 1, dtype)
+    assert abs(lo["grid_x"] * lo["grid_y"] - hi["grid_x"] * hi["grid_y"]) <= lo["grid_x"], (lo, hi)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -88,20 +94,20 @@ def test_streaming_hint_above_32_mb(T, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_big_row_group_workgroups_band(T, dtype):
-    """one 768/1024-lane workgroup per CU for last-axis tensors of 2^23 .. 3 * 2^24 elements whose rows fit one window
+    """one 768/1024-lane workgroup per CU for last-axis tensors of 2^23 .. 5 * 2^24 elements whose rows fit one window
     (4-byte storage: only up to 64 MB)"""
-    big = 1024 if dtype == torch.float32 else 768
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    is_big = lambda note: note["block"] > 256 and note["grid_x"] * note["grid_y"] == cus    # one fat workgroup per CU
     lo, hi = _rows(1 << 23, 768)
     (_, a), (_, b) = _case(T, (lo, 768), 1, dtype), _case(T, (hi, 768), 1, dtype)
-    assert (a["block"], b["block"]) == (192 if dtype == torch.float32 else 192, big), (a, b)
+    assert not is_big(a) and is_big(b), (a, b)
+    assert b["block"] <= (1024 if dtype == torch.float32 else 768)
     if dtype == torch.float32:
         lo, hi = _rows(64 * MB // 4 + 1, 768)          # the 64 MB cap of 4-byte storage
-        (_, a), (_, b) = _case(T, (lo, 768), 1, dtype), _case(T, (hi, 768), 1, dtype)
-        assert a["block"] == big and b["block"] < big, (a, b)
     else:
-        lo, hi = _rows(3 << 24, 768)                   # the upper end of the band
-        (_, a), (_, b) = _case(T, (lo, 768), 1, dtype), _case(T, (hi, 768), 1, dtype)
-        assert a["block"] == big and b["block"] < big, (a, b)
+        lo, hi = _rows(5 << 24, 768)                   # the upper end of the band
+    (_, a), (_, b) = _case(T, (lo, 768), 1, dtype), _case(T, (hi, 768), 1, dtype)
+    assert is_big(a) and not is_big(b), (a, b)
 
 
 def test_fp32_row_groups_leave_the_ring_above_160_mb(T):
@@ -112,8 +118,9 @@ def test_fp32_row_groups_leave_the_ring_above_160_mb(T):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_row_groups_give_way_to_windows_at_2p27_elements(T, dtype):
-    lo, hi = _rows(1 << 27, 2048)
+def test_row_groups_give_way_to_windows_at_512_mb(T, dtype):
+    esz = 4 if dtype == torch.float32 else 2
+    lo, hi = _rows(512 * MB // esz, 2048)
     (_, a), (_, b) = _case(T, (lo, 2048), 1, dtype), _case(T, (hi, 2048), 1, dtype)
     assert (a["kind"], b["kind"]) == ("row-groups", "windows"), (a, b)
 
@@ -139,12 +146,13 @@ def test_segment_mode_few_rows_long_channels(T):
     assert b1["grid_x"] == 512 and b1["grid_y"] == 1          # one workgroup per channel: d_scale finished in the kernel
 
 
-def test_forward_of_16_bit_last_axis_takes_the_coarser_grid_above_2p24_elements(T):
+def test_forward_of_16_bit_last_axis_takes_the_coarser_grid_when_it_has_the_rows(T):
     """16-bit last-axis forwards with a 32 KiB channel table (2048 channels per window) run 4 workgroups per CU (half the table
-    builds) once the tensor has 2^24 elements; smaller ones keep 16 per CU"""
-    lo, hi = _rows(1 << 24, 4096)
-    (a, _), (b, _) = _case(T, (lo, 4096), 1, torch.bfloat16), _case(T, (hi, 4096), 1, torch.bfloat16)
+    builds of the usual 16 per CU) once a workgroup of that grid walks at least 8 rows -- [8192,4096]; with fewer rows the usual
+    grid stays -- [4096,4096], where the rows-per-table floor makes the two coincide anyway"""
+    (a, _), (b, _) = _case(T, (4096, 4096), 1, torch.bfloat16), _case(T, (8192, 4096), 1, torch.bfloat16)
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     wg = lambda n: n["grid_x"] * n["grid_y"]
-    assert wg(a) > 8 * cus and wg(b) <= 6 * cus, (a, b)
+    rows = lambda n, r: r / n["grid_y"]
+    assert rows(a, 4096) < 14 and rows(b, 8192) >= 14 and wg(b) <= 4 * cus + 2, (a, b)
     assert a["ring_depth"] == b["ring_depth"] == 0          # register loops either way

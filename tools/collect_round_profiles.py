@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
-"""After tools/gpu_profile_round2.sh ran on the GPU box: copy its summaries (gpurun_out/summ2) into profiles/ and rebuild
-profiles/traffic_latest.json from the live PMC measurements the bench lines carry."""
-import glob, json, os, shutil
+"""After tools/gpu_profile_round<N>.sh ran on the GPU box: copy its summaries (gpurun_out/summ<N>) into profiles/ and rebuild
+profiles/traffic_latest.json from the live PMC measurements the bench lines carry.   usage: collect_round_profiles.py [round=3]"""
+import glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "summ2")
+RND = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+TAG = "r%02d_" % RND
+SRC = os.path.join(ROOT, "gpurun_out", "summ%d" % RND)
 DST = os.path.join(ROOT, "profiles")
-for f in sorted(glob.glob(os.path.join(SRC, "r02_*"))):
+for f in sorted(glob.glob(os.path.join(SRC, TAG + "*"))):
     if f.endswith(".err"):
         continue
     shutil.copy(f, os.path.join(DST, os.path.basename(f)))
 tpath = os.path.join(DST, "traffic_latest.json")
 doc = json.load(open(tpath))
-for f in sorted(glob.glob(os.path.join(SRC, "r02_bench_*_n1.json"))):
+for f in sorted(glob.glob(os.path.join(SRC, TAG + "bench_*_n1.json"))):
     lines = [l for l in open(f).read().splitlines() if l.startswith("{")]
     if not lines:
         continue
@@ -20,7 +22,7 @@ for f in sorted(glob.glob(os.path.join(SRC, "r02_bench_*_n1.json"))):
     src = r.get("traffic_source")
     if r.get("traffic") is None or not isinstance(src, dict):
         continue
-    w = os.path.basename(f)[len("r02_bench_"):-len("_n1.json")]
+    w = os.path.basename(f)[len(TAG + "bench_"):-len("_n1.json")]
     alg = r.get("algorithmic_bytes_per_launch") or r.get("bytes_per_launch")
     e = {"n_local": d["config"].get("n_local", d["config"].get("elements_per_gpu")),
          "bwd_hbm_bytes_per_launch": r["traffic"],

@@ -43,6 +43,29 @@ def step_fused(xs, gs, ss, bs):
     return torch.autograd.grad(ys, xs + ss, gs)
 
 
+# the backend ops alone (what bench.py times for the single-tensor workloads): no autograd graph, forward op + backward op
+TAIL = (-128, 127, -128, 127, True, 1.0, True, False, False)
+
+
+def ops_single(xs, gs, ss, bs):
+    ops = torch.ops.torchlsq_native if E.host_binding() == "native" else torch.ops.torchlsq
+    out = []
+    for x, g, s, b in zip(xs, gs, ss, bs):
+        y = ops.lsq_forward_per_channel(x, s, b, 0, *TAIL)
+        out.append(ops.lsq_backward_per_channel(g, x, s, b, 0, *TAIL))
+    return out
+
+
+def ops_fused(xs, gs, ss, bs):
+    n = len(xs)
+    if E.host_binding() == "native":
+        nat = torch.ops.torchlsq_native
+        ys = nat.lsq_forward_per_channel_multi(xs, ss, bs, [0] * n, *TAIL)
+        return nat.lsq_backward_per_channel_multi(gs, xs, ss, bs, [0] * n, *TAIL)
+    ys = E.hip_forward_per_channel_multi(xs, ss, bs, [0] * n, *TAIL)
+    return E.hip_backward_per_channel_multi(gs, xs, ss, bs, [0] * n, *TAIL)
+
+
 def wall(fn, args, reps=30):
     for _ in range(5):
         fn(*args)
@@ -76,6 +99,7 @@ def gpu(fn, args, reps=10):
 def main():
     print("# tools/exp_foreach.py on one MI355X: N per-channel qint8 weight quantizers (axis 0, symmetric), forward + backward per step")
     print("# single = N x (lsq forward + backward), fused = one lsq_foreach (one launch per 32 tensors each way); us per step")
+    print("# autograd = through functional.lsq / lsq_foreach and torch.autograd.grad; ops only = the backend ops called directly (as bench.py does)")
     resnetish = [(64, 64, 3, 3)] * 4 + [(128, 128, 3, 3)] * 4 + [(256, 256, 3, 3)] * 6 + [(512, 512, 3, 3)] * 3 + \
                 [(128, 64, 3, 3), (256, 128, 3, 3), (512, 256, 3, 3), (1000, 512)]
     vit_block = [(2304, 768), (768, 768), (3072, 768), (768, 3072)] * 12
@@ -94,8 +118,14 @@ def main():
             ws, wf = wall(step_single, args), wall(step_fused, args)
             gs_, gf = gpu(step_single, args), gpu(step_fused, args)
             esz = args[0][0].element_size()
-            print("%-50s %-7s fusable %2d/%2d | wall: single %8.1f  fused %8.1f  (%.2fx) | GPU: single %8.1f  fused %8.1f  (%.2fx, %.2f TB/s)" % (
-                name, binding, fusable, len(shapes), ws, wf, ws / wf, gs_, gf, gs_ / gf, 5 * esz * elems / gf / 1e6), flush=True)
+            line = "%-50s %-7s fusable %2d/%2d | autograd, wall: single %8.1f  fused %8.1f  (%.2fx) | GPU: single %8.1f  fused %8.1f  (%.2fx, %.2f TB/s)" % (
+                name, binding, fusable, len(shapes), ws, wf, ws / wf, gs_, gf, gs_ / gf, 5 * esz * elems / gf / 1e6)
+            if fusable == len(shapes):
+                with torch.no_grad():
+                    plain = [[t.detach() for t in lst] for lst in args]
+                    os_, of = wall(ops_single, plain), wall(ops_fused, plain)
+                line += " | ops only, wall: single %8.1f  fused %8.1f  (%.2fx)" % (os_, of, os_ / of)
+            print(line, flush=True)
             del args
         E.set_host_binding("native" if E.native_lsq() is not None else "ctypes")
 

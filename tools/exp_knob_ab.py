@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""A/B of one policy knob of the tools library on last-axis [rows, C] tensors, backward op, cold inputs:
+    python tools/exp_knob_ab.py set_ww_big 1 2 bf16 65536x768 87381x768 ...
+(three interleaved rounds of HIP-graph replays, inputs rotated through > 1 GB; the launch each setting produced is printed)."""
+import sys
+
+import torch
+
+from exp_ww_max import time_bwd
+
+
+def main():
+    knob, a, b, dt = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[dt]
+    print("# lsq_hip_debug_%s(%d) against (%d), %s, backward op, cold" % (knob, a, b, dt))
+    for spec in sys.argv[5:]:
+        rows, C = (int(v) for v in spec.split("x"))
+        r = time_bwd((rows, C), dtype, (("a", a), ("b", b)), knob)
+        (ta, ka), (tb, kb) = r["a"], r["b"]
+        n = rows * C
+        print("[%7d,%5d] %10d elements  %d: %8.1f us %5.2f ps/el (%s) | %d: %8.1f us %5.2f ps/el (%s) | %+5.1f %%"
+              % (rows, C, n, a, ta, ta * 1e6 / n, ka, b, tb, tb * 1e6 / n, kb, (ta / tb - 1) * 100), flush=True)
+
+
+if __name__ == "__main__":
+    main()

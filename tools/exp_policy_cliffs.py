@@ -87,18 +87,18 @@ def main():
     f32, bf16 = torch.float32, torch.bfloat16
     last = lambda C: (lambda r: (r, C))
     for dt in (f32, bf16):
-        sweep("2^21 elements: small-tensor floor on rows per workgroup (row-group windows, [rows,768])", last(768), 1 << 21, 1, dt)
+        sweep("2^21 elements: NO switch here any more -- rows per workgroup now follow a smooth rule (row-group windows, [rows,768]; round 2 had a cliff here)", last(768), 1 << 21, 1, dt)
     for dt in (f32, bf16):
         sweep("32 MB: streaming hint on the ring copies (256-lane windows, [rows,2048,7] axis 1)", lambda r: (r, 2048, 7),
               32 * MB // (4 if dt == f32 else 2) + 1, 1, dt, (-8, 7, -128, 127))
     for dt in (f32, bf16):
         sweep("2^23 elements: one 768/1024-lane workgroup per CU from here ([rows,768])", last(768), 1 << 23, 1, dt)
     sweep("64 MB: ... and for 4-byte storage only up to here ([rows,768])", last(768), 64 * MB // 4 + 1, 1, f32)
-    sweep("3 * 2^24 elements: ... for 16-bit storage up to here ([rows,768])", last(768), 3 << 24, 1, bf16)
+    sweep("5 * 2^24 elements: ... for 16-bit storage up to here ([rows,768])", last(768), 5 << 24, 1, bf16)
     sweep("160 MB: fp32 row groups leave the ring ([rows,768])", last(768), 160 * MB // 4 + 1, 1, f32)
     for dt in (f32, bf16):
-        sweep("2^27 elements: row groups give way to 256-lane windows ([rows,2048])", last(2048), 1 << 27, 1, dt)
-    sweep("2^24 elements: 16-bit last-axis forward takes 4 workgroups per CU from here ([rows,4096])", last(4096), 1 << 24, 1, bf16)
+        sweep("512 MB: row groups give way to 256-lane windows ([rows,2048])", last(2048), 512 * MB // (4 if dt == f32 else 2), 1, dt)
+    sweep("2^24 elements: NO switch here any more -- the 16-bit last-axis forward rule was implied by its tiles-per-workgroup condition ([rows,4096])", last(4096), 1 << 24, 1, bf16)
 
 
 if __name__ == "__main__":

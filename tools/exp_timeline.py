@@ -83,25 +83,65 @@ def main():
         waves = note["grid_x"] * note["grid_y"] * (note["block"] // 64)
         rec = buf[:waves * 8].view(waves, 8).cpu().numpy().astype(np.float64)
         rec = rec[rec[:, 0] > 0]
-        t_begin, t_end = rec[:, 0].min(), rec[:, 3].max()
-        span = t_end - t_begin
-        # the shader clock per us: the span of the stamps against the op's event time minus the finalize launch (~4.5 us + gap)
+        # every XCD counts its own shader clock: stamps are comparable inside one XCC only, so entry / exit times are taken
+        # relative to the first entry on the same XCC; the HW_ID register (bits 8-11 CU, 13-15 SE on gfx9) gives the CU
+        xcc = rec[:, 7].astype(np.int64) & 0xf
+        hw = rec[:, 6].astype(np.int64)
+        cu_key = xcc * 65536 + ((hw >> 8) & 0xff)            # HW_ID: CU id bits 8-11, SH id bit 12, SE id bits 13-15
+        base = np.zeros(len(rec)); last = np.zeros(len(rec))
+        per_cu = []
+        for k in np.unique(cu_key):
+            m = cu_key == k
+            base[m] = rec[m, 0].min()
+            last[m] = rec[m, 3].max()
+            per_cu.append((last[m][0] - base[m][0], int(m.sum())))
+        xcc = cu_key                                             # (the statistics below are per CU)
         op_us = e0.elapsed_time(e1) * 1e3
-        print("## %s: grid %d x %d x %d lanes, ring depth %d, %d waves stamped; op (kernel + finalize launch) %.1f us; stamps span %.0f cycles" % (
-            name, note["grid_x"], note["grid_y"], note["block"], note["ring_depth"], len(rec), op_us, span))
-        for label, ghz in (("at 2.1 GHz", 2100.0), ("at 2.4 GHz", 2400.0)):
+        print("## %s: grid %d x %d x %d lanes, ring depth %d, nt %d, %d resident per CU assumed, %d waves stamped; this op (kernel + finalize launch) %.1f us" % (
+            name, note["grid_x"], note["grid_y"], note["block"], note["ring_depth"], note["ring_nt"], note["resident_per_cu"], len(rec), op_us))
+        for label, ghz in (("at 2.1 GHz", 2100.0),):
             us = lambda c: c / ghz
-            q_ = lambda v: "min %6.2f  p10 %6.2f  median %6.2f  p90 %6.2f  max %6.2f" % tuple(us(np.percentile(v, p)) for p in (0, 10, 50, 90, 100))
-            print("  [%s] kernel span (first entry -> last exit) %.2f us" % (label, us(span)))
-            print("    wave entry after first entry      " + q_(rec[:, 0] - t_begin))
+            q_ = lambda v: "min %6.2f  p10 %6.2f  p25 %6.2f  median %6.2f  p75 %6.2f  p90 %6.2f  max %6.2f" % tuple(us(np.percentile(v, p)) for p in (0, 10, 25, 50, 75, 90, 100))
+            spans = np.array([p_[0] for p_ in per_cu])
+            print("  [%s] %d CUs seen; busy span per CU (its first wave's entry -> its last wave's exit): " % (label, len(per_cu)) + q_(spans) +
+                  ";  waves per CU min %d max %d" % (min(p_[1] for p_ in per_cu), max(p_[1] for p_ in per_cu)))
+            print("    wave entry after its CU's first   " + q_(rec[:, 0] - base))
             print("    prologue (entry -> row loop)      " + q_(rec[:, 1] - rec[:, 0]))
             print("    row loop                          " + q_(rec[:, 2] - rec[:, 1]))
             print("      of which in the ring's waits    " + q_(rec[:, 4]))
             print("      per row                         " + q_((rec[:, 2] - rec[:, 1]) / np.maximum(rec[:, 5], 1)))
             print("    epilogue (row loop -> exit)       " + q_(rec[:, 3] - rec[:, 2]))
-            print("    wave exit before last exit        " + q_(t_end - rec[:, 3]))
-        xcc = rec[:, 7].astype(np.int64) & 0xf
-        print("    waves per XCC: %s" % np.bincount(xcc, minlength=8).tolist())
+            print("    wave life (entry -> exit)         " + q_(rec[:, 3] - rec[:, 0]))
+            print("    wave exit before its CU's last    " + q_(last - rec[:, 3]))
+            # how the waves of a CU spread over its four SIMDs (HW_ID bits 4-5), and what a wave's row costs by the company it keeps
+            simd = (hw >> 4) & 3
+            simd_key = cu_key * 4 + simd
+            uniq, inv, cnt = np.unique(simd_key, return_inverse=True, return_counts=True)
+            per_row = us((rec[:, 2] - rec[:, 1]) / np.maximum(rec[:, 5], 1))
+            print("    waves per SIMD over the launch: " + " ".join("%d:%d" % (v, int((cnt == v).sum())) for v in np.unique(cnt)) +
+                  "   (SIMDs seen: %d of %d)" % (len(uniq), 4 * len(per_cu)))
+            # concurrency: waves of the same SIMD alive at this wave's mid-loop
+            mid = (rec[:, 1] + rec[:, 2]) / 2
+            conc = np.zeros(len(rec), dtype=np.int64)
+            order = np.argsort(simd_key, kind="stable")
+            start = 0
+            sk = simd_key[order]
+            for end in list(np.nonzero(np.diff(sk))[0] + 1) + [len(sk)]:
+                idx = order[start:end]
+                for i in idx:
+                    conc[i] = int(((rec[idx, 0] <= mid[i]) & (rec[idx, 3] > mid[i])).sum())
+                start = end
+            for c_ in np.unique(conc):
+                m_ = conc == c_
+                print("      waves with %d wave(s) alive on their SIMD at mid-loop: %5d   row time median %.2f us  (p10 %.2f, p90 %.2f)" % (
+                    c_, int(m_.sum()), np.median(per_row[m_]), np.percentile(per_row[m_], 10), np.percentile(per_row[m_], 90)))
+            # waves alive over time on one CU (the one with the most waves)
+            kbig = max(np.unique(cu_key), key=lambda k: int((cu_key == k).sum()))
+            m = cu_key == kbig
+            t0s, t3s = us(rec[m, 0] - base[m]), us(rec[m, 3] - base[m])
+            grid_t = np.linspace(0, t3s.max(), 16)
+            alive = [int(((t0s <= t) & (t3s > t)).sum()) for t in grid_t]
+            print("    waves alive on one CU at t = " + " ".join("%.1f:%d" % (t, a_) for t, a_ in zip(grid_t, alive)))
         sys.stdout.flush()
         del xs, gs, buf
         torch.cuda.empty_cache()

@@ -33,7 +33,7 @@ def internal_abi():
            ("lsq_hip_forward_per_tensor", "lsq_hip_backward_per_tensor", "lsq_hip_forward_per_channel",
             "lsq_hip_backward_per_channel")}
     for n in ("force_ring", "set_ww_min_rows", "set_ww_split64", "set_ww_big", "set_ring_nt", "set_fin_ch",
-              "set_observe_wg_per_cu"):
+              "set_observe_wg_per_cu", "set_ww_max_log2"):
         tab["lsq_hip_debug_" + n] = (None, [_int])
     tab["lsq_hip_debug_last_launch"] = (None, [ctypes.POINTER(ctypes.c_int * 8)])
     return tab
@@ -58,8 +58,8 @@ def activate(path=TOOLS_LIB):
     if _state["lib"] is None:
         _state["lib"] = load(path)
     if _state["saved"] is None:
-        _state["saved"] = (E._LIB, E.host_binding())
-    E._LIB = _state["lib"]
+        _state["saved"] = (E.library(), E.host_binding())
+    E.set_library(_state["lib"])
     E._WS_BYTES_PC.clear()           # the tools build sizes the scratch for every variant: do not reuse production answers
     E.set_host_binding("ctypes")
     return _state["lib"]
@@ -69,7 +69,7 @@ def deactivate():
     from torchlsq import extension as E
     if _state["saved"] is not None:
         reset_knobs()
-        E._LIB = _state["saved"][0]
+        E.set_library(_state["saved"][0])
         E._WS_BYTES_PC.clear()
         if _state["saved"][1] == "native":
             E.set_host_binding("native")
@@ -80,7 +80,7 @@ def reset_knobs():
     lib = _state["lib"]
     if lib is not None:
         for n in ("force_ring", "set_ww_min_rows", "set_ww_split64", "set_ww_big", "set_ring_nt", "set_fin_ch",
-                  "set_observe_wg_per_cu"):
+                  "set_observe_wg_per_cu", "set_ww_max_log2"):
             getattr(lib, "lsq_hip_debug_" + n)(0)
 
 
