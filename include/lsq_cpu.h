@@ -5,7 +5,7 @@
  *   /root/reference/torchlsq/csrc/ops/cpu/lsq_cpu.cpp:298-311
  * -- so that a model can be prepared, calibrated, evaluated or exported on the CPU with the same operators.  It is NOT a
  * fallback of the GPU path: GPU tensors are dispatched to liblsq_hip.so only, and a missing liblsq_hip.so disables the
- * package as a whole (torchlsq/extension.py::_assert_has_ops).
+ * package as a whole (torchlsq/_abi.py::_assert_has_ops).
  *
  * Same conventions as lsq_hip.h with HOST pointers and no stream: caller-owned dense buffers, the [outer, C, inner] view
  * for per-channel ops, `lsq_params` (shared with lsq_hip.h, incl. numel_for_scaler), 0 / negative status codes, never

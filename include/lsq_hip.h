@@ -173,8 +173,9 @@ int lsq_hip_backward_per_channel(int dtype, const void* grad, const void* x, voi
  * same-named argument of the single-tensor entry points: the forward reads x, scale, shift and writes y; the backward reads
  * grad, x, scale, shift and writes dx, ds[channels], db[channels].  All tensors share `dtype` and `p` (numel_for_scaler must
  * be <= 0: every tensor's gradient scaler uses its own element count).  Every tensor must satisfy
- * lsq_hip_per_channel_multi_ok -- the tensors the single-tensor launch policy walks with one workgroup per channel (long,
- * packet-aligned channel rows, few outer indices: conv / linear weights quantized along axis 0); results are then bit-identical
+ * lsq_hip_per_channel_multi_ok -- the tensors the single-tensor launch policy walks with one workgroup per channel
+ * (packet-aligned channel rows of at least an eighth of a workgroup's 4 KiB span, few outer indices: conv / linear weights
+ * quantized along axis 0); results are then bit-identical
  * to the single-tensor calls (the same walk and summation order).  Other tensors go through the single-tensor entry points. */
 typedef struct lsq_pc_item {
     const void* x;

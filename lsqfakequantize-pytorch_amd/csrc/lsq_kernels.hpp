@@ -57,7 +57,7 @@ constexpr int kDefaultPcSegNarrowVariant = encode_variant(1, true, true, 16);   
 // constant 0 ("no override"), the policy code that consults it folds away, no lsq_hip_debug_* symbol is exported, and the
 // library keeps no mutable global state (include/lsq_hip.h).
 namespace knob {
-enum Id { kForceRing, kWwMinRows, kWwSplit64, kWwBig, kRingNt, kFinCh, kObserveWgPerCu, kWwMaxLog2, kCount };
+enum Id { kForceRing, kWwMinRows, kWwSplit64, kWwBig, kRingNt, kFinCh, kObserveWgPerCu, kWwMaxLog2, kSegMinDiv, kCount };
 #ifdef LSQ_TOOLS
 inline std::atomic<int>& slot(Id id) {
     static std::atomic<int> v[kCount];
@@ -75,7 +75,11 @@ inline std::atomic<unsigned long long*>& timeline_buffer() {     // lsq_hip_debu
 }
 #endif
 // all geometry knobs as one key (the workspace memo of lsq_capi.hip)
-inline int geometry_key() { return get(kWwMinRows) | (get(kWwSplit64) << 16) | (get(kWwBig) << 20) | (get(kRingNt) << 24) | (get(kWwMaxLog2) << 26); }
+inline int geometry_key() {
+    int k = 0;
+    for (Id id : {kWwMinRows, kWwSplit64, kWwBig, kRingNt, kWwMaxLog2, kSegMinDiv}) k = k * 41 + get(id);
+    return k;
+}
 }  // namespace knob
 
 inline Variant decode_variant(int code, int dflt) {

@@ -101,7 +101,7 @@ template <typename IO>
 bool multi_eligible(int64_t outer, int64_t channels, int64_t inner, bool aligned16) {
     if (outer <= 0 || channels <= 0 || inner <= 0 || channels > 0x3fffffffLL) return false;
     const int vec = pick_vec(IO::VEC, channels * inner, aligned16);
-    if (vec != IO::VEC || !pick_segment_mode(vec, outer, channels, inner)) return false;
+    if (vec != IO::VEC || !pick_segment_mode(vec, outer, channels, inner, device_info().cu_count)) return false;
     const SegGeom sg = make_seg_geom(outer, channels, inner, vec, device_info().cu_count * 16);     // the segment kernels' default grid
     return sg.segs == 1 && sg.osplits == 1;
 }

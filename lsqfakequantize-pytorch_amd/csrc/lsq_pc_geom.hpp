@@ -375,11 +375,23 @@ struct SegWalk {
     }
 };
 
-// few rows + long, packet-aligned channel rows -> one channel per workgroup
-static inline bool pick_segment_mode(int vec, int64_t outer, int64_t C, int64_t inner) {
+// few rows + packet-aligned channel rows -> one channel per workgroup (conv / linear weights on axis 0).
+// Rows of at least one workgroup's span (W = 256 lanes x 16 bytes) always.  `short_rows_cus` > 0 (the forward and the
+// backward op; the CU count) adds SHORT rows, where part of the workgroup idles but the walk still wins because it needs no
+// partials and no finalize launch (profiles/r03_seg_min_ab.txt, forward / backward op against the window kernels):
+//   up to 16 workgroups per CU, rows of at least W/8:  [768,768] fp32 -14 % / -47 %, [64,64,3,3] -20 % / -50 %,
+//       [3072,768] bf16 -1 % / -5 %, [1000,512] bf16 -1 % / -27 %;
+//   any channel count, rows of at least 3W/4:  [50257,768] fp32 -13 % / -33 %;
+//   not shorter rows on many channels: [32768,256] fp32 +60 % / +50 %, [16384,768] bf16 (3W/8) +18 % / +53 %.
+static inline bool pick_segment_mode(int vec, int64_t outer, int64_t C, int64_t inner, int short_rows_cus = 0) {
     if (vec == 1 || inner % vec != 0) return false;
     const int64_t W = static_cast<int64_t>(kBlock) * vec;
-    return outer < 8 && inner >= W && C * ((inner + W - 1) / W) <= 0x7fffffffLL;
+    if (outer >= 8 || C * ((inner + W - 1) / W) > 0x7fffffffLL) return false;
+    if (inner >= W) return true;
+    if (short_rows_cus <= 0) return false;
+    const int div = knob::get(knob::kSegMinDiv);     // tools builds, lsq_hip_debug_set_seg_min_div: rows of at least W/div
+    if (div > 0) return inner * div >= W;
+    return C <= static_cast<int64_t>(short_rows_cus) * 16 ? inner * 8 >= W : inner * 4 >= 3 * W;
 }
 
 static inline bool grid_fits(const SegGeom& g) { return g.C * g.segs <= 0x7fffffffLL && g.osplits <= 65535; }

@@ -1140,7 +1140,7 @@ static size_t bwd_pc_workspace_bytes_any(int io_vec, int64_t outer, int64_t chan
                     }
                 }
             }
-            if (vi < 2 && pick_segment_mode(vecs[vi], outer, channels, inner)) {
+            if (vi < 2 && pick_segment_mode(vecs[vi], outer, channels, inner, dev.cu_count)) {
                 const SegGeom sgm = make_seg_geom(outer, channels, inner, vecs[vi], dev.cu_count * bpc);
                 need = std::max(need, static_cast<size_t>(channels) * sgm.segs * sgm.osplits * sizeof(double2));
             }
@@ -1256,7 +1256,7 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
     const DeviceInfo& dev = device_info();
     const bool aligned = is_aligned16(x) && is_aligned16(y) && (!levels || (reinterpret_cast<uintptr_t>(levels) & 7u) == 0);
     const int vec = pick_vec(IO::VEC, channels * inner, aligned);
-    const bool seg = pick_segment_mode(vec, outer, channels, inner);
+    const bool seg = pick_segment_mode(vec, outer, channels, inner, dev.cu_count);
     const Variant v = decode_variant(variant, seg ? (sizeof(typename IO::elem) >= 4 ? kDefaultPcSegVariant : kDefaultPcSegNarrowVariant)
                                                   : kDefaultPcFwdVariant);
     const int target = dev.cu_count * v.blocks_per_cu;
@@ -1573,7 +1573,7 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
     const DeviceInfo& dev = device_info();
     const bool aligned = is_aligned16(grad) && is_aligned16(x) && is_aligned16(dx);
     const int vec = pick_vec(IO::VEC, channels * inner, aligned);
-    const bool seg = pick_segment_mode(vec, outer, channels, inner);
+    const bool seg = pick_segment_mode(vec, outer, channels, inner, dev.cu_count);
     const Variant v = decode_variant(variant, seg ? (sizeof(typename IO::elem) >= 4 ? kDefaultPcSegVariant : kDefaultPcSegNarrowVariant)
                                                   : (sizeof(typename IO::elem) >= 4 ? kDefaultPcBwdWideVariant
                                                                                     : kDefaultPcBwdNarrowVariant));

@@ -136,11 +136,11 @@ def test_ring_needs_as_many_row_tiles_as_stages(T, dtype):
 
 def test_segment_mode_few_rows_long_channels(T):
     """few outer indices + long packet-aligned channel rows -> one channel per workgroup (conv / linear weights on axis 0);
-    8 outer indices or a short row -> windows"""
+    8 outer indices or a very short row -> windows (short rows: test_short_channel_rows_take_the_segment_walk)"""
     (f1, b1) = _case(T, (512, 512, 3, 3), 0, torch.float32, (-128, 127, -128, 127))
     (f2, b2) = _case(T, (7, 64, 4096), 1, torch.float32)
     (f3, b3) = _case(T, (8, 64, 4096), 1, torch.float32)
-    (f4, b4) = _case(T, (512, 512), 0, torch.float32, (-128, 127, -128, 127))          # 512 elements per channel: under one window
+    (f4, b4) = _case(T, (512, 64), 0, torch.float32, (-128, 127, -128, 127))           # 64 elements per channel: a sixteenth of the span
     assert f1["kind"] == b1["kind"] == f2["kind"] == b2["kind"] == "segment"
     assert f3["kind"] == b3["kind"] == f4["kind"] == b4["kind"] == "windows"
     assert b1["grid_x"] == 512 and b1["grid_y"] == 1          # one workgroup per channel: d_scale finished in the kernel
@@ -156,3 +156,23 @@ def test_forward_of_16_bit_last_axis_takes_the_coarser_grid_when_it_has_the_rows
     rows = lambda n, r: r / n["grid_y"]
     assert rows(a, 4096) < 14 and rows(b, 8192) >= 14 and wg(b) <= 4 * cus + 2, (a, b)
     assert a["ring_depth"] == b["ring_depth"] == 0          # register loops either way
+
+
+def test_short_channel_rows_take_the_segment_walk(T):
+    """weights on axis 0 whose channel rows are shorter than a workgroup's span (256 lanes x 16 bytes): one workgroup per
+    channel -- no partials, no finalize launch -- for rows of at least 1/8 of the span on up to 16 workgroups per CU, for rows of
+    at least 3/4 of it on any channel count; window kernels otherwise (profiles/r03_seg_min_ab.txt)"""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    f32, bf16 = torch.float32, torch.bfloat16
+    q = (-128, 127, -128, 127)
+    many = 16 * cus + 8
+    for shape, dtype, want in (((768, 768), f32, "segment"), ((64, 64, 3, 3), f32, "segment"), ((768, 768), bf16, "segment"),
+                               ((512, 128), f32, "segment"), ((512, 124), f32, "windows"),          # 1/8 of 1024 elements
+                               ((512, 256), bf16, "segment"), ((512, 248), bf16, "windows"),        # 1/8 of 2048
+                               ((16 * cus, 256), f32, "segment"), ((many, 256), f32, "windows"),    # 16 workgroups per CU
+                               ((many, 768), f32, "segment"), ((many, 764), f32, "windows"),        # 3/4 of the span: any count
+                               ((many, 1536), bf16, "segment"), ((many, 1528), bf16, "windows"),
+                               ((8, 512, 768), f32, "windows")):                                    # eight "rows" of channels: not a weight
+        axis = 1 if len(shape) == 3 and shape[0] == 8 else 0
+        f, b = _case(T, shape, axis, dtype, q)
+        assert (f["kind"], b["kind"]) == (want, want), (shape, dtype, f, b)

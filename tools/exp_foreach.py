@@ -107,9 +107,10 @@ def main():
              ("50 x [512,512,3,3] bf16", [(512, 512, 3, 3)] * 50, torch.bfloat16),
              ("ResNet-18-like conv stack, 21 weights fp32", resnetish, torch.float32),
              ("ViT-B linear weights, 48 tensors fp32", vit_block, torch.float32)]
+    have_native = E.native_lsq() is not None
     for name, shapes, dtype in cases:
         for binding in ("native", "ctypes"):
-            if binding == "native" and E.native_lsq() is None:
+            if binding == "native" and not have_native:
                 continue
             E.set_host_binding(binding)
             args = make(shapes, dtype)
@@ -127,7 +128,7 @@ def main():
                 line += " | ops only, wall: single %8.1f  fused %8.1f  (%.2fx)" % (os_, of, os_ / of)
             print(line, flush=True)
             del args
-        E.set_host_binding("native" if E.native_lsq() is not None else "ctypes")
+        E.set_host_binding("native" if have_native else "ctypes")
 
 
 if __name__ == "__main__":

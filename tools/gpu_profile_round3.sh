@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 evidence run on one MI355X box (via gpurun): the default bench line (headline + secondary records, live PMC traffic,
 # CPU baseline), rocprofv3 --kernel-trace --stats of the same command and of the secondary workloads, SQ counters of the 16-bit
-# per-channel backward, reduction margins, multi-tensor table, policy threshold sweep, K4 timeline, the 2-rank smoke.
+# per-channel backward, reduction margins, multi-tensor table, K4 timeline, the 2-rank smoke.
 # Summaries into gpurun_out/summ3/ (copied into profiles/ by tools/collect_round3.py).
 export TMPDIR=/tmp
 O=gpurun_out/summ3
@@ -36,7 +36,5 @@ python3 tools/exp_reduction_margin.py > $O/r03_reduction_margin.txt 2>/dev/null
 python3 tools/exp_foreach.py > $O/r03_foreach_weights.txt 2>/dev/null
 cat $O/r03_foreach_weights.txt | cut -c1-330
 python3 tools/exp_timeline.py > $O/r03_k4_timeline.txt 2>/dev/null
-python3 tools/exp_policy_cliffs.py > $O/r03_policy_cliffs.txt 2>/dev/null
-grep -c "CLIFF" $O/r03_policy_cliffs.txt; grep "threshold" $O/r03_policy_cliffs.txt | cut -c1-260
 python3 bench.py --gpus 2 --backend gloo --single-device --steps 20 --warmup 5 --no-cpu-baseline > $O/r03_bench_2ranks_one_device_gloo.json 2> $O/r03_bench_2ranks.err
 tail -1 $O/r03_bench_2ranks_one_device_gloo.json | cut -c1-400
