@@ -161,8 +161,14 @@ Tensor byte_workspace(const Tensor& like, size_t nbytes) {
 // after the HIP runtime at process exit -- and streams get a slot each on first use.  A launch that is being captured
 // into a HIP graph gets no ticket (two-launch route): the graph may be replayed on any stream, next to eager work on the
 // capture stream, and two concurrent launches must never share an arrival counter.
-// Off by default: measured on MI355X the single-launch route is not faster than kernel + finalize launch.
-std::atomic<bool> g_use_ticket{[] { const char* e = std::getenv("TORCHLSQ_SINGLE_LAUNCH_BACKWARD"); return e && e[0] == '1'; }()};
+// Mode 2 ("auto", the default): per-tensor tensors of at most 8 MB -- host-bound in eager mode, where one launch less is
+// 11-15 % of the forward + backward wall time; on the GPU the single-launch route is not faster, and 2-3 us slower where the
+// kernel is busy (profiles/r03_ticket_sizes.txt).  TORCHLSQ_SINGLE_LAUNCH_BACKWARD=1: always, =0: never.
+constexpr int64_t kTicketAutoBytes = int64_t{8} << 20;
+std::atomic<int> g_ticket_mode{[] {
+    const char* e = std::getenv("TORCHLSQ_SINGLE_LAUNCH_BACKWARD");
+    return !e ? 2 : (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2));
+}()};
 constexpr int kTicketSlots = 64;
 struct TicketSlab {
     char* base = nullptr;
@@ -172,8 +178,10 @@ std::mutex g_ticket_mutex;
 std::map<int, TicketSlab> g_ticket_slabs;                    // device index -> slab
 std::map<std::pair<int, void*>, void*> g_tickets;            // (device index, stream) -> ticket
 
-void* ticket_for(const Tensor& x, void* stream) {
-    if (!g_use_ticket.load(std::memory_order_relaxed)) return nullptr;
+void* ticket_for(const Tensor& x, void* stream, bool per_channel) {
+    const int mode = g_ticket_mode.load(std::memory_order_relaxed);
+    if (mode == 0 || (mode == 2 && (per_channel || x.numel() * static_cast<int64_t>(x.element_size()) > kTicketAutoBytes)))
+        return nullptr;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &st) != hipSuccess || st != hipStreamCaptureStatusNone)
         return nullptr;                                       // captured launches: two-launch route
@@ -262,7 +270,7 @@ BackwardOut backward_impl(const Tensor& grad, const Tensor& x, const Tensor& sca
     const auto popt = x.options().dtype(param_type(x.scalar_type()));
     c10::DeviceGuard guard(x.device());
     void* const stream = stream_of(x);
-    const lsq_bwd_extras extras{ticket_for(x, stream)};
+    const lsq_bwd_extras extras{ticket_for(x, stream, per_channel)};
     Tensor wide;
     if (per_channel) {
         const Geometry g = geometry(xd, axis);
@@ -647,7 +655,7 @@ TORCH_LIBRARY(torchlsq_native, m) {
     m.def("lsq_backward_per_channel_multi(Tensor[] grads, Tensor[] xs, Tensor[] scales, Tensor[] shifts, int[] axes, " LSQ_TAIL
           ") -> Tensor[]");
     m.def("_abi_version() -> int", []() -> int64_t { return lsq_hip_abi_version(); });
-    m.def("_set_single_launch_backward(bool on) -> ()", [](bool on) { g_use_ticket.store(on); });
+    m.def("_set_single_launch_backward(int mode) -> ()", [](int64_t mode) { g_ticket_mode.store(mode < 0 || mode > 2 ? 2 : static_cast<int>(mode)); });
 }
 
 TORCH_LIBRARY_IMPL(torchlsq_native, CUDA, m) {  // PyTorch-ROCm dispatches HIP tensors under the CUDA key

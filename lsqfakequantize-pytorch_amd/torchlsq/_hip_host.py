@@ -184,18 +184,30 @@ def _workspace(device, nbytes):
 # launches that can run concurrently.  One slab of _TICKET_SLOTS tickets per device is allocated (and zeroed) at the
 # first eager backward on that device; streams get a slot each on first use.  Kernels of one stream are serialised by the
 # stream; launches captured into a HIP graph take no ticket (see _ticket).
-# Measured on MI355X (profiles/r02_ticket_single_launch.txt): the single-launch route is NOT faster -- the last workgroup's
-# serial chain (drain its dx stores, agent-scope counter round trip, agent-scope loads of the partials) costs as much
-# as the finalize kernel's launch (config 1 backward 8.0 us against 6.9 us; config 2 / 4 unchanged) -- so it is off unless
-# asked for: TORCHLSQ_SINGLE_LAUNCH_BACKWARD=1 or set_single_launch_backward(True).
-_SINGLE_LAUNCH_BWD = [os.environ.get("TORCHLSQ_SINGLE_LAUNCH_BACKWARD", "0") == "1"]
+# Measured on MI355X: on the GPU the single-launch route is NOT faster -- the last workgroup's serial chain (drain its dx
+# stores, agent-scope counter round trip, agent-scope loads of the partials) costs as much as the finalize kernel's launch
+# (profiles/r02_ticket_single_launch.txt) and 2-3 us more where the kernel is busy -- but tensors of up to 8 MB are HOST-bound
+# in eager mode, and there one launch less is 11-15 % of the forward + backward wall time (profiles/r03_ticket_sizes.txt:
+# fp32 up to 2^21 elements, bf16 up to 2^22; +14 % at the next size up).  So the default is "auto": per-tensor backward of at
+# most _TICKET_AUTO_BYTES through a ticket, everything else through kernel + finalize.  TORCHLSQ_SINGLE_LAUNCH_BACKWARD=1 /
+# set_single_launch_backward(True): always; =0 / False: never.
+_TICKET_AUTO_BYTES = 8 << 20
+_TICKET_MODES = {"0": 0, "1": 1, "auto": 2}
+_SINGLE_LAUNCH_BWD = [_TICKET_MODES.get(os.environ.get("TORCHLSQ_SINGLE_LAUNCH_BACKWARD", "auto").lower(), 2)]    # 0 never, 1 always, 2 auto
 
 
 def set_single_launch_backward(on):
-    """Use tickets (one launch per backward) in both host layers from now on."""
-    _SINGLE_LAUNCH_BWD[0] = bool(on)
+    """Tickets (one launch per backward) in both host layers from now on: True = always, False = never, "auto" = the default
+    (per-tensor tensors of at most 8 MB, the host-bound ones)."""
+    mode = 2 if on == "auto" else (1 if on else 0)
+    _SINGLE_LAUNCH_BWD[0] = mode
     if hasattr(torch.ops, "torchlsq_native") and _abi._NATIVE_LSQ is not None:
-        torch.ops.torchlsq_native._set_single_launch_backward(bool(on))
+        torch.ops.torchlsq_native._set_single_launch_backward(mode)
+
+
+def _wants_ticket(nbytes):
+    mode = _SINGLE_LAUNCH_BWD[0]
+    return mode == 1 or (mode == 2 and nbytes <= _TICKET_AUTO_BYTES)
 
 
 _TICKET_SLOTS = 64
@@ -313,7 +325,7 @@ def hip_backward_per_tensor(grad, x, scale, shift, qmin, qmax, tmin, tmax, use_g
     idx = dev.index
     stream = _stream_of(idx)
     if use_ticket is None:
-        use_ticket = _SINGLE_LAUNCH_BWD[0]
+        use_ticket = _wants_ticket(xd.numel() * xd.element_size())
     fn, tail = _entry("lsq_hip_backward_per_tensor", variant)
     rc = _on_device(idx, fn, code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(),
                     ds.data_ptr(), db.data_ptr(), wide.data_ptr() if want_wide else None, xd.numel(),
@@ -412,7 +424,7 @@ def hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax
     ws = _workspace(dev, nbytes)
     stream = _stream_of(idx)
     if use_ticket is None:
-        use_ticket = _SINGLE_LAUNCH_BWD[0]
+        use_ticket = _SINGLE_LAUNCH_BWD[0] == 1      # (the per-channel entry point takes a ticket and ignores it)
     fn, tail = _entry("lsq_hip_backward_per_channel", variant)
     rc = _on_device(idx, fn, code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(),
                     ds.data_ptr(), db.data_ptr(), wide.data_ptr() if want_wide else None, outer, C, inner,

@@ -99,7 +99,9 @@ def test_ticket_survives_many_launches_graphs_and_streams(E):
     for o in captured:
         assert _bits(o[1]) == _bits(want[1]) and _bits(o[2]) == _bits(want[2])
     assert int(E._TICKET_SLABS[0][0].abs().sum()) == 0
-    assert len(E._TICKETS) == 5      # default stream + 4 side streams; none for the capture stream
+    keys = set(E._TICKETS)             # (device, raw stream): the default stream, the 4 side streams; none for the capture stream
+    assert all((0, s_.cuda_stream) in keys for s_ in streams) and (0, torch.cuda.default_stream().cuda_stream) in keys
+    assert (0, st.cuda_stream) not in keys
 
 
 def test_native_binding_uses_tickets_and_matches(E):
@@ -119,5 +121,31 @@ def test_native_binding_uses_tickets_and_matches(E):
     dx, wide = nat.lsq_backward_per_tensor_wide(g, x, scale, shift, *args, 4 * x.numel())
     dx2, wide2 = E.hip_backward_per_tensor(g, x, scale, shift, *args, numel_for_scaler=4 * x.numel(), want_wide=True,
                                            use_ticket=False)
-    E.set_single_launch_backward(False)
+    E.set_single_launch_backward("auto")
     assert _bits(wide) == _bits(wide2) and _bits(dx) == _bits(dx2)
+
+
+def test_default_policy_takes_a_ticket_for_host_bound_tensors_only(E):
+    """"auto" (the default): per-tensor tensors of at most 8 MB go through the one-launch route (host-bound in eager mode:
+    profiles/r03_ticket_sizes.txt), bigger ones and every per-channel tensor through kernel + finalize launch; same bits"""
+    dev = torch.device("cuda:0")
+    E.set_single_launch_backward("auto")
+    assert E._wants_ticket(8 << 20) and not E._wants_ticket((8 << 20) + 4)
+    args = (0, 127, 0, 255, True, 1.0, False, False, False)
+    scale, shift = torch.tensor([0.03], device=dev), torch.tensor([0.0], device=dev)
+    for n in (802816, (8 << 20) // 4, (8 << 20) // 4 + 1024):
+        x, g = _inputs(n, torch.float32, dev)
+        want = E.hip_backward_per_tensor(g, x, scale, shift, *args, use_ticket=False)
+        got = E.hip_backward_per_tensor(g, x, scale, shift, *args)                      # policy
+        outs = [got]
+        if E.native_lsq() is not None:
+            outs.append(torch.ops.torchlsq_native.lsq_backward_per_tensor(g, x, scale, shift, *args))
+        for o in outs:
+            for u, v in zip(o, want):
+                assert _bits(u) == _bits(v), n
+    E.set_single_launch_backward(False)
+    assert not E._wants_ticket(1024)
+    E.set_single_launch_backward(True)
+    assert E._wants_ticket(1 << 30)
+    E.set_single_launch_backward("auto")
+    assert int(E._TICKET_SLABS[0][0].abs().sum()) == 0
