@@ -21,27 +21,33 @@ dev = torch.device("cuda:0")
 MB = 1 << 20
 
 
-def time_bwd(shape, dtype, settings, knob="set_ww_max_log2"):
+def time_bwd(shape, dtype, settings, knob="set_ww_max_log2", axis=1, fwd=False):
     setter = getattr(lib, "lsq_hip_debug_" + knob)
-    n = shape[0] * shape[1]
+    n = 1
+    for d in shape:
+        n *= d
     esz = 2 if dtype == torch.bfloat16 else 4
     K = max(2, min(8, -(-(1100 * MB) // (2 * n * esz))))
     xs = [synth.normal_like(n, 10 + k, 0.5, 1.0, dtype=dtype, device=dev).view(shape) for k in range(K)]
     gs = [synth.normal_like(n, 50 + k, 0.0, 1e-3, dtype=dtype, device=dev).view(shape) for k in range(K)]
-    s = synth.uniform_like(shape[1], 3, 0.01, 0.05, device=dev)
-    b = synth.normal_like(shape[1], 4, 0.0, 0.1, device=dev)
+    s = synth.uniform_like(shape[axis], 3, 0.01, 0.05, device=dev)
+    b = synth.normal_like(shape[axis], 4, 0.0, 0.1, device=dev)
     q = (0, 127, 0, 255, True, 1.0, False, False, False)
+    if fwd:
+        op = lambda k: E.hip_forward_per_channel(xs[k], s, b, axis, *q)
+    else:
+        op = lambda k: E.hip_backward_per_channel(gs[k], xs[(k + K // 2) % K], s, b, axis, *q)
     graphs = {}
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):
         for name, v in settings:
             setter(v)
             for k in range(K):
-                E.hip_backward_per_channel(gs[k], xs[(k + K // 2) % K], s, b, 1, *q)
+                op(k)
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr, stream=st):
                 for k in range(2 * K):
-                    E.hip_backward_per_channel(gs[k % K], xs[(k + K // 2) % K], s, b, 1, *q)
+                    op(k % K)
             note = lsq_tools.last_launch()
             graphs[name] = (gr, "%s %dx%d of %d lanes%s" % (note["kind"], note["grid_x"], note["grid_y"], note["block"],
                                                         ", ring %d" % note["ring_depth"] if note["ring_depth"] else ""))
