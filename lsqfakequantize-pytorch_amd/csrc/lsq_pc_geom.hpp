@@ -134,6 +134,7 @@ struct PcGeom {
     int32_t ww_lanes;        // row-group windows (make_geom_ww): lanes per row group; 0 otherwise
     int32_t block_threads;   // workgroup size to launch (kBlock except for row-group windows)
     int32_t ring_nt;         // LDS-DMA ring: issue its copies with the streaming hint (global_load_lds ... nt)
+    int32_t direct;          // forward, a lane's components are different channels: no LDS table, the lane reads its own scale / shift
 #ifdef LSQ_TOOLS
     int32_t interleave;      // A/B knob: row tiles dealt to the splits round-robin (tile t -> split t % splits) instead of in contiguous runs
 #endif
@@ -195,6 +196,7 @@ static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec,
     g.ww_lanes = 0;
     g.block_threads = kBlock;
     g.ring_nt = 0;
+    g.direct = 0;
 #ifdef LSQ_TOOLS
     g.interleave = knob::get(knob::kRowInterleave) == 1 ? 1 : 0;     // lsq_hip_debug_set_row_interleave
 #endif
@@ -236,6 +238,7 @@ static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_
                                   bool split64 = false, int block = kBlock) {
     PcGeom g;
     g.ring_nt = 0;
+    g.direct = 0;
 #ifdef LSQ_TOOLS
     g.interleave = knob::get(knob::kRowInterleave) == 1 ? 1 : 0;     // lsq_hip_debug_set_row_interleave
 #endif

@@ -139,6 +139,62 @@ struct LaneChannels {
             q[j].s = e.s; q[j].inv_s = e.inv_s; q[j].zp = e.zp;
         }
     }
+    // CPL == V without a table: a lane whose V components are V (mostly) different channels -- the quantized axis is the last
+    // or nearly the last one -- reads ITS channels' scale / shift itself.  A 256-lane window then shares nothing through the
+    // table (2048 channels, 2048 lanes' worth of slots), so building one is pure latency: global loads -> divisions -> LDS
+    // writes -> barrier -> LDS reads.  Two steps, like load_channel_raw / finish_channel_table: the loads are issued before
+    // the first rows' loads, the divisions happen when the rows are in flight.
+    __device__ __forceinline__ void load_direct(const T* __restrict__ scale, const T* __restrict__ shift, const LaneSite& s,
+                                                const PcGeom& g, T (&rs)[N], T (&rb)[N]) {
+        const bool f32 = g.fits32 != 0;
+        const int64_t p0 = s.live ? s.p0 : s.c_lo * g.inner;
+        if constexpr (CPL == V && V > 2) {
+            split = V;
+            const bool wide = g.inner == 1 && p0 + V <= g.C &&
+                              ((reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15u) == 0;
+            if (wide) {      // V consecutive channels from a multiple of V on: 16-byte loads
+                struct alignas(16) Pack { T v[N]; };
+                const Pack a = *reinterpret_cast<const Pack*>(scale + p0);
+                const Pack b = *reinterpret_cast<const Pack*>(shift + p0);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    key[j] = static_cast<int32_t>(p0 + j - s.c_lo);
+                    rs[j] = a.v[j];
+                    rb[j] = b.v[j];
+                }
+                return;
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                int64_t c = udiv(p0 + j, g.inner, f32);
+                c = c < g.C ? c : g.C - 1;
+                key[j] = static_cast<int32_t>(c - s.c_lo);
+                rs[j] = scale[c];
+                rb[j] = shift[c];
+            }
+        } else {
+            // one channel, or two with a split point (init() above, from global memory instead of the table)
+            const int64_t c0 = udiv(p0, g.inner, f32);
+            int32_t sp = V;
+            if (CPL == 2) {
+                const int64_t left = (c0 + 1) * g.inner - p0;
+                sp = (s.live && left < V) ? static_cast<int32_t>(left) : V;
+            }
+            split = sp;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                int64_t c = c0 + ((j > 0 && sp < V) ? 1 : 0);
+                c = c < g.C ? c : g.C - 1;
+                key[j] = static_cast<int32_t>(c - s.c_lo);
+                rs[j] = scale[c];
+                rb[j] = shift[c];
+            }
+        }
+    }
+    __device__ __forceinline__ void finish_direct(const T (&rs)[N], const T (&rb)[N], const Range<T>& r) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) q[j] = make_qparams<T>(sanitize_scale_per_channel<T>(rs[j]), rb[j], r);
+    }
     // constants of component j, by select (never a runtime-indexed register array -> no scratch)
     __device__ __forceinline__ QParams<T> params(int j) const {
         if (N == 1) return q[0];
@@ -188,12 +244,21 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     QSlot<T>* table = reinterpret_cast<QSlot<T>*>(smem);
 
+    // no table at all (LaneChannels::load_direct) where a lane's components are different channels: forward_per_channel's choice
+    using LC = LaneChannels<T, V, CPL>;
+    constexpr bool kDirectAble = DMA == 0;
+    const bool direct = kDirectAble && g.direct != 0;
     // the window's raw scale / shift first (issue order = retirement order), then the first rows, then the table
-    const bool raw_first = g.k_slots <= kRawSlots * kBlock;
+    const bool raw_first = !direct && g.k_slots <= kRawSlots * kBlock;
     ChannelRaw<T> raw;
     if (raw_first) raw = load_channel_raw<T>(g.k_slots, window_first_channel(g), g.C, scale, shift);
     const LaneSite site = lane_site(g, V);
     const RowWalk walk(g, site);
+    LC ch;
+    T direct_s[LC::N], direct_b[LC::N];
+    if constexpr (kDirectAble) {
+        if (direct) ch.load_direct(scale, shift, site, g, direct_s, direct_b);
+    }
     // the first group of loads does not depend on the channel constants: put it in flight before the
     // table build (a division + a barrier) so the two latencies overlap
     E first[UNROLL][V];
@@ -218,11 +283,14 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
     if constexpr (DMA > 0) {
         for (int64_t i = 0; i < DMA && i < dma_n; ++i) dma_issue(i);
     }
-    if (raw_first) finish_channel_table<T>(table, g.k_slots, site.c_lo, g.C, raw, r);
-    else build_channel_table<T>(table, g.k_slots, site.c_lo, g.C, scale, shift, r);
-    __syncthreads();
-    LaneChannels<T, V, CPL> ch;
-    ch.init(table, site, g);
+    if (direct) {
+        if constexpr (kDirectAble) ch.finish_direct(direct_s, direct_b, r);
+    } else {
+        if (raw_first) finish_channel_table<T>(table, g.k_slots, site.c_lo, g.C, raw, r);
+        else build_channel_table<T>(table, g.k_slots, site.c_lo, g.C, scale, shift, r);
+        __syncthreads();
+        ch.init(table, site, g);
+    }
     const T bias = static_cast<T>(level_bias);
 
     // fp32 arithmetic on packets: two elements at a time (forward_pair: packed multiplies and adds), the lane's constants
@@ -1198,12 +1266,13 @@ static hipError_t launch_fwd_pc(const void* x, void* y, int8_t* levels, int bias
     using T = typename IO::arith;
     const Range<T> r = make_range<T>(p);
     const dim3 grid(static_cast<unsigned>(g.n_windows), static_cast<unsigned>(g.splits));
-    const size_t lds = static_cast<size_t>(g.k_slots) * sizeof(QSlot<T>);
+    const size_t table_bytes = static_cast<size_t>(g.k_slots) * sizeof(QSlot<T>);
+    const size_t lds = g.direct ? 0 : table_bytes;     // (direct: every lane reads its own channels)
     // LDS-DMA ring (16-byte packets): forward_per_channel decided (v.dma == 2) and sized the grid for it
     constexpr bool kDmaAble = V * sizeof(typename IO::elem) == 16;
     constexpr int kDmaDepth = kFwdDmaDepth;
     if constexpr (kDmaAble) {
-        const size_t lds_dma = ((lds + 1023) & ~size_t(1023)) + static_cast<size_t>(kBlock / 64) * kDmaDepth * 1024;
+        const size_t lds_dma = ((table_bytes + 1023) & ~size_t(1023)) + static_cast<size_t>(kBlock / 64) * kDmaDepth * 1024;
         if (v.dma == 2 && lds_dma <= 64 * 1024) {
             hipLaunchKernelGGL((fwd_pc_kernel<IO, V, CPL, INIT, LEVELS, 1, true, true, kDmaDepth>), grid, dim3(kBlock), lds_dma, stream,
                                x, y, levels, bias, aux_kind, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r);
@@ -1286,7 +1355,19 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
     // profiles/r02_fwd_lastaxis_grid.txt).
     Variant vv = v;
     vv.dma = 1;
-    if (vec > 1 && vec * sizeof(typename IO::elem) == 16 && v.dma != 1) {
+    // A lane whose components are different channels (cpl == vec: the quantized axis is the last or nearly the last one)
+    // reads its own scale / shift: no LDS table (fwd_pc_kernel, LaneChannels::load_direct) -- profiles/r03_fwd_direct_ab.txt,
+    // cold: [12608,768] bf16 11.9 -> 9.5 us, [8192,4096] bf16 29.6 -> 26.8 us, [65536,1024] bf16 51.4 -> 46.6 us, [3152,768]
+    // fp32 8.8 -> 7.1 us, the big fp32 tensors -1 .. -4 %.
+    // tools builds, lsq_hip_debug_set_fwd_direct: 1 = direct on the usual grid, 2 = the table, 3 = the policy
+    const int direct_knob = knob::get(knob::kFwdDirect);
+    // tools knob 4: also the lanes of one or two channels (cpl < vec) -- A/B
+    const bool direct = direct_knob == 4 || (vec > 2 && cpl == vec && direct_knob != 2);
+    g.direct = direct ? 1 : 0;
+    // (the grid rule that was found for the 32 KiB table stays on the direct path: [8192,4096] bf16 26.8 us against 27.5 us on
+    // the usual grid, [16384,8192] 97.0 vs 99.5 us -- profiles/r03_fwd_direct_ab.txt)
+    const bool table_grid_rule = direct_knob != 1;
+    if (vec > 1 && vec * sizeof(typename IO::elem) == 16 && v.dma != 1 && (table_grid_rule || v.dma == 2)) {
         const int tgt = variant == 0 ? dev.cu_count * kDmaFwdBlocksPerCU<IO> : target;
         const PcGeom gd = make_geom(outer, channels, inner, vec, tgt, kFwdPerSlotRows<IO>);
         const int64_t tiles_each = gd.n_tiles / std::max(1, gd.splits);
@@ -1297,6 +1378,7 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
         if (v.dma == 2 || (table_big && tiles_each >= kFwdDmaDepth && tiles_each <= 64)) {
             g = gd;
             vv.dma = table_big ? 1 : 2;
+            g.direct = (direct && vv.dma == 1) ? 1 : 0;
             g.ring_nt = ring_nt_for(outer * channels * inner * static_cast<int64_t>(sizeof(typename IO::elem)), false, false);
         }
     }

@@ -176,3 +176,33 @@ def test_short_channel_rows_take_the_segment_walk(T):
         axis = 1 if len(shape) == 3 and shape[0] == 8 else 0
         f, b = _case(T, shape, axis, dtype, q)
         assert (f["kind"], b["kind"]) == (want, want), (shape, dtype, f, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float64, torch.float16])
+def test_last_axis_forward_without_the_channel_table(T, dtype):
+    """a lane whose packet components are different channels (quantized axis last, or rows of fewer elements than a packet)
+    reads its own scale / shift instead of building the window's LDS table: same bits as the table path (tools knob 2), also
+    with scale / shift that are only 4-byte aligned, a ragged last window and the int8 levels"""
+    from torchlsq import extension as E, synth
+    lib = T.activate()
+    dev = torch.device("cuda:0")
+    q = (0, 127, 0, 255, True, 1.0, False, False, False)
+    for shape, axis in (((1024, 4096), 1), ((197, 768), 1), ((64, 7, 7, 256), 3), ((33, 40), 1), ((4096, 8, 3), 1), ((512, 2056), 1)):
+        n = int(np.prod(shape))
+        C = shape[axis]
+        x = synth.normal_like(n, 71, 0.5, 1.0, dtype=dtype, device=dev).view(shape)
+        pdt = torch.float64 if dtype == torch.float64 else torch.float32
+        sbuf = synth.uniform_like(C + 1, 72, 0.01, 0.05, device=dev, dtype=pdt)
+        bbuf = synth.normal_like(C + 1, 73, 0.0, 0.1, device=dev, dtype=pdt)
+        for s, b in ((sbuf[:C], bbuf[:C]), (sbuf[1:], bbuf[1:])):       # 16-byte aligned / only element-aligned parameters
+            outs = []
+            for knob in (2, 0, 1, 3):
+                lib.lsq_hip_debug_set_fwd_direct(knob)
+                y = E.hip_forward_per_channel(x, s, b, axis, *q)
+                yq, lv = E.hip_forward_per_channel(x, s, b, axis, *q, levels_bias=0)
+                outs.append((y, yq, lv))
+            lib.lsq_hip_debug_set_fwd_direct(0)
+            torch.cuda.synchronize()
+            for o in outs[1:]:
+                for u, v in zip(o, outs[0]):
+                    assert torch.equal(u.view(torch.uint8) if u.dtype != torch.int8 else u, v.view(torch.uint8) if v.dtype != torch.int8 else v), (shape, dtype)
