@@ -246,7 +246,11 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
 
     // no table at all (LaneChannels::load_direct) where a lane's components are different channels: forward_per_channel's choice
     using LC = LaneChannels<T, V, CPL>;
+#ifdef LSQ_TOOLS     // (knob 4: also lanes of one or two channels -- measured neutral, +-2 %, profiles/r03_fwd_direct_ab.txt)
     constexpr bool kDirectAble = DMA == 0;
+#else
+    constexpr bool kDirectAble = CPL == V && V > 2 && DMA == 0;     // (V == 2: CPL == 2 is the two-channel form)
+#endif
     const bool direct = kDirectAble && g.direct != 0;
     // the window's raw scale / shift first (issue order = retirement order), then the first rows, then the table
     const bool raw_first = !direct && g.k_slots <= kRawSlots * kBlock;
