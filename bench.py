@@ -278,7 +278,7 @@ def run_rank(a):
     ops = torch.ops.torchlsq_native if binding == "native" else torch.ops.torchlsq
     ops_of = {"native": getattr(torch.ops, "torchlsq_native", None), "ctypes": torch.ops.torchlsq}
 
-    def measure(workload, steps, warmup, graph=False, buffers=0, ops=ops):
+    def measure(workload, steps, warmup, graph=False, buffers=0, ops=ops, warm_ms=0.0):
         """Time `steps` steps (forward op + backward op) of one workload after `warmup` untimed ones; returns the raw
         measurements (K-step wall time bracketed by barrier + synchronize, max over ranks; per-op HIP-event times)."""
         cfg_name, dtype_name, axis_override = WORKLOADS[workload]
@@ -366,19 +366,27 @@ def run_rank(a):
                     cur[0] = k
                     fwd(); bwd()
                     gr = torch.cuda.CUDAGraph()
-                    with torch.cudgraph(gr, stream=st):
+                    with torch.cuda.graph(gr, stream=st):
                         y = fwd()
                         r = bwd()
                     step_graphs.append(gr)
             torch.cuda.synchronize()
 
-        for i in range(warmup):
+        # `warmup` untimed steps -- and, for the secondary records, as many more as it takes to fill `warm_ms` of wall time:
+        # they are timed after this process has sat through the CPU baseline (GPU idle for 20 s), and twenty steps of a
+        # 20 us workload do not bring the clocks back
+        t_warm = time.perf_counter()
+        i = 0
+        while i < warmup or (warm_ms > 0 and (time.perf_counter() - t_warm) * 1e3 < warm_ms):
             cur[0] = i % n_sets
             if step_graphs is not None:
                 step_graphs[cur[0]].replay()
             else:
                 y = fwd()
                 r = bwd()
+            i += 1
+            if warm_ms > 0 and i % 64 == 0:
+                torch.cuda.synchronize()
         drain()
         torch.cuda.synchronize()
 
@@ -574,7 +582,7 @@ def run_rank(a):
             sec = []
             for w in SECONDARY:
                 try:
-                    sm = measure(w, a.secondary_steps, 20)
+                    sm = measure(w, a.secondary_steps, 20, warm_ms=60.0)
                     sb_f, sb_b = 2 * sm["esz"], 3 * sm["esz"]
                     rec = {"workload": w, "shape": sm["shape"], "storage": sm["dtype_name"],
                            "value": round(sm["n_global"] * sm["steps"] / sm["elapsed_max"] / 1e9, 3), "unit": "GElem/s",
@@ -589,7 +597,7 @@ def run_rank(a):
                     del sm
                     if n_small and binding == "native":
                         # launch-bound sizes: the Python / ctypes host layer next to the C++ binding (same kernels)
-                        sm = measure(w, a.secondary_steps, 20, ops=ops_of["ctypes"])
+                        sm = measure(w, a.secondary_steps, 20, ops=ops_of["ctypes"], warm_ms=30.0)
                         rec["ms_per_step_ctypes_binding"] = round(sm["elapsed_max"] / sm["steps"] * 1e3, 5)
                         del sm
                     torch.cuda.empty_cache()

@@ -38,3 +38,5 @@ cat $O/r03_foreach_weights.txt | cut -c1-330
 python3 tools/exp_timeline.py > $O/r03_k4_timeline.txt 2>/dev/null
 python3 bench.py --gpus 2 --backend gloo --single-device --steps 20 --warmup 5 --no-cpu-baseline > $O/r03_bench_2ranks_one_device_gloo.json 2> $O/r03_bench_2ranks.err
 tail -1 $O/r03_bench_2ranks_one_device_gloo.json | cut -c1-400
+python3 __graft_entry__.py smoke > $O/r03_smoke.log 2>&1; tail -5 $O/r03_smoke.log
+( time python3 bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/r03_bench_driver_cmd.json 2> $O/r03_bench_driver_cmd.err; tail -4 $O/r03_bench_driver_cmd.err
