@@ -41,7 +41,6 @@ void lsq_hip_debug_set_ww_big(int v);       /* 1024-lane row-group workgroups: 0
 /* tools only: channels (slots) per finalize workgroup, a power of two <= 32 (0 = the built-in rule) */
 void lsq_hip_debug_set_ww_max_log2(int v);  /* row-group windows for last-axis tensors below 2^v elements: 0 = policy */
 void lsq_hip_debug_set_seg_min_div(int v);  /* forward / backward: segment mode for channel rows of at least 1/v of a workgroup's span (1 = whole spans only): 0 = policy */
-void lsq_hip_debug_set_row_interleave(int v); /* window kernels: 1 = row tiles dealt to the row splits round-robin, 0 = contiguous runs (policy) */
 void lsq_hip_debug_set_fwd_direct(int v);   /* last-axis forward: 0 / 3 = policy (lanes read their own scale / shift), 1 = the same on the usual grid, 2 = LDS table */
 void lsq_hip_debug_set_fin_ch(int v);
 /* tuning only: override the workgroups-per-CU of the observer-statistics kernels (0 = defaults) */

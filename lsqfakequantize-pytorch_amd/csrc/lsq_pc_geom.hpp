@@ -135,9 +135,6 @@ struct PcGeom {
     int32_t block_threads;   // workgroup size to launch (kBlock except for row-group windows)
     int32_t ring_nt;         // LDS-DMA ring: issue its copies with the streaming hint (global_load_lds ... nt)
     int32_t direct;          // forward, a lane's components are different channels: no LDS table, the lane reads its own scale / shift
-#ifdef LSQ_TOOLS
-    int32_t interleave;      // A/B knob: row tiles dealt to the splits round-robin (tile t -> split t % splits) instead of in contiguous runs
-#endif
 #ifdef LSQ_TIMELINE
     unsigned long long* timeline;   // experiment build (tools/exp_timeline.py): 8 x u64 per wave of the window backward
 #endif
@@ -197,9 +194,6 @@ static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec,
     g.block_threads = kBlock;
     g.ring_nt = 0;
     g.direct = 0;
-#ifdef LSQ_TOOLS
-    g.interleave = knob::get(knob::kRowInterleave) == 1 ? 1 : 0;     // lsq_hip_debug_set_row_interleave
-#endif
 #ifdef LSQ_TIMELINE
     g.timeline = nullptr;
 #endif
@@ -239,9 +233,6 @@ static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_
     PcGeom g;
     g.ring_nt = 0;
     g.direct = 0;
-#ifdef LSQ_TOOLS
-    g.interleave = knob::get(knob::kRowInterleave) == 1 ? 1 : 0;     // lsq_hip_debug_set_row_interleave
-#endif
 #ifdef LSQ_TIMELINE
     g.timeline = nullptr;
 #endif
@@ -330,19 +321,8 @@ struct RowWalk {
     int64_t o_begin, step, n_rows;
     int64_t n_tiles_split;      // tiles of this workgroup's split: the same for every lane (n_rows is per lane)
     __device__ __forceinline__ RowWalk(const PcGeom& g, const LaneSite& site) {
-#ifdef LSQ_TOOLS
-        if (g.interleave) {
-            // A/B (profiles/r03_row_interleave_ab.txt: within +-5 % either way, +9 .. +16 % on two forwards -- not adopted):
-            // split y owns the row tiles y, y + splits, y + 2 splits, ..., so that the workgroups of a launch stream one
-            // compact, advancing band of rows (the access pattern of the per-tensor kernels)
-            const int64_t y = blockIdx.y;
-            n_tiles_split = y < g.n_tiles ? (g.n_tiles - y + g.splits - 1) / g.splits : 0;
-            o_begin = y * g.R + site.row_in_tile;
-            step = static_cast<int64_t>(g.splits) * g.R;
-            n_rows = (site.live && o_begin < g.outer) ? (g.outer - o_begin + step - 1) / step : 0;
-            return;
-        }
-#endif
+        // (dealing the tiles round-robin instead -- one compact advancing band of rows per launch -- was measured: within +-5 %
+        // on the backward, +9 .. +16 % on two forwards, profiles/r03_row_interleave_ab.txt; the code is in the history)
         // split y of `splits` owns the row tiles [y * n_tiles / splits, (y + 1) * n_tiles / splits): sizes differ by at
         // most one tile (a uniform ceil(n / splits) leaves the last workgroup a short remainder and the rest too much)
         const int64_t t0 = static_cast<int64_t>(blockIdx.y) * g.n_tiles / g.splits;
