@@ -68,6 +68,29 @@ class _LSQOnDevice(torch.autograd.Function):
         return dx, ds, db, None
 
 
+class _LSQOnHost(torch.autograd.Function):
+    """The same for tensors in host memory (liblsq_cpu.so, the counterpart of the reference's CPU dispatch key): straight to
+    the kernels' host layer instead of through the dispatcher -- torch.library's Python autograd wrapper costs ~70 us per call
+    (schema defaults, two re-entries), several times the kernel on a small tensor.  Mirrors lsq_autograd.cpp:16-74,111-173:
+    saves {input, scale, shift}; the eval backward recomputes the mask from them (no mask variant here)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, cfg):
+        (qmin, qmax, tmin, tmax, axis, use_gs, gs, sym, per_channel, eval_mode, init_mode, _) = cfg
+        ctx.save_for_backward(x, scale, shift)
+        ctx.cfg = cfg
+        return _E.cpu_forward(x, scale, shift, axis, per_channel, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        x, scale, shift = ctx.saved_tensors
+        (qmin, qmax, tmin, tmax, axis, use_gs, gs, sym, per_channel, eval_mode, init_mode, _) = ctx.cfg
+        dx, ds, db = _E.cpu_backward(grad_out, x, scale, shift, axis, per_channel, qmin, qmax, tmin, tmax, use_gs, gs, sym,
+                                     eval_mode, init_mode)
+        return dx, ds, db, None
+
+
 def lsq(x: Tensor, scale: Tensor, shift: Tensor,
         quant_min: int = 0,
         quant_max: int = 255,
@@ -127,10 +150,11 @@ def lsq(x: Tensor, scale: Tensor, shift: Tensor,
         type_min = quant_min
     if type_max is None:
         type_max = quant_max
-    if x.is_cuda and scale.is_cuda and shift.is_cuda and not torch.jit.is_tracing() \
-            and not torch.compiler.is_compiling():
+    on_gpu = x.is_cuda and scale.is_cuda and shift.is_cuda
+    on_host = not (x.is_cuda or scale.is_cuda or shift.is_cuda) and x.device.type == "cpu"
+    if (on_gpu or on_host) and not torch.jit.is_tracing() and not torch.compiler.is_compiling():
         # front-op checks and routing of quantops::ops::lsq (lsq.cpp:104-134), then straight to the kernels
-        native = _E._NATIVE_LSQ
+        native = _E._NATIVE_LSQ if on_gpu else None
         if native is not None:      # C++ front op + autograd node (csrc/torch_binding): same kernels, less host time
             if not mask_backward:
                 native = torch.ops.torchlsq_native.lsq_keep_input.default
@@ -148,7 +172,7 @@ def lsq(x: Tensor, scale: Tensor, shift: Tensor,
                 shift = shift.repeat(size)
         cfg = (quant_min, quant_max, type_min, type_max, axis, bool(use_grad_scaling), float(grad_scaler),
                not is_affine, bool(is_perchannel), bool(eval_mode), bool(init_mode), bool(mask_backward))
-        return _LSQOnDevice.apply(x, scale, shift, cfg)
+        return (_LSQOnDevice if on_gpu else _LSQOnHost).apply(x, scale, shift, cfg)
     return torch.ops.torchlsq.lsq(x, scale, shift, quant_min, quant_max, type_min, type_max,
                                   axis, use_grad_scaling, grad_scaler, is_affine, is_perchannel,
                                   eval_mode, init_mode)
