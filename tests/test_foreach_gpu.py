@@ -147,3 +147,45 @@ def test_weight_group_on_a_qat_model():
     close(outs[0][1], outs[1][1], "input gradient")
     for n, g0 in outs[0][2].items():
         close(g0, outs[1][2][n], n)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_foreach_random_weight_lists(seed):
+    """random lists of weight-like tensors (channels first, any row length: whole spans, short rows the segment walk takes,
+    rows it leaves to the window kernels, rows that are not packet-aligned), more than one launch's worth, random modes:
+    lsq_foreach == the single calls, bit for bit, on both host layers"""
+    from torchlsq import extension as E
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(7000 + seed)
+    dtype = [torch.float32, torch.bfloat16, torch.float16][seed % 3]      # (fp64 outputs of the window kernels agree run to run
+                                                                           # only to fp64 rounding: DESIGN.md, Reproducibility)
+    n_tensors = int(rng.integers(2, 70))
+    shapes = []
+    for _ in range(n_tensors):
+        C = int(rng.choice([1, 3, 8, 64, 100, 256, 500]))
+        tail = [int(rng.choice([1, 2, 3, 7, 8, 16, 64, 96, 128, 576, 1000, 1024, 2048, 4608]))]
+        if rng.random() < 0.4:
+            tail.append(int(rng.choice([1, 3, 4])))
+        if C * int(np.prod(tail)) > 1_500_000:
+            tail = [128]
+        shapes.append((C, *tail))
+    xs, gs, ss, bs = _weights(shapes, dtype, dev, 100 * seed)
+    mode = ["sym", "affine", "eval", "init"][int(rng.integers(0, 4))]
+    kw = dict(quant_min=-128, quant_max=127, type_min=-128, type_max=127, is_affine=(mode != "sym"),
+              eval_mode=(mode == "eval"), init_mode=(mode == "init"), use_grad_scaling=bool(rng.random() < 0.8),
+              grad_scaler=float(rng.choice([1.0, 0.5])))
+    saved = E.host_binding()
+    try:
+        for binding in (("native", "ctypes") if E.native_lsq() is not None or saved == "native" else ("ctypes",)):
+            E.set_host_binding(binding)
+            single = _run(None, xs, gs, ss, bs, kw, fused=False)
+            fused = _run(None, xs, gs, ss, bs, kw, fused=True)
+            for what, a, b in zip(("y", "dx", "d_scale", "d_shift"), single, fused):
+                for i, (u, v) in enumerate(zip(a, b)):
+                    if u is None or v is None:
+                        assert u is None and v is None, (what, i)
+                        continue
+                    assert u.shape == v.shape and _bits(u) == _bits(v), "%s of tensor %d %s differs (%s, %s, %s)" % (
+                        what, i, shapes[i], dtype, mode, binding)
+    finally:
+        E.set_host_binding(saved)
