@@ -9,6 +9,12 @@
 
 namespace lsq {
 
+constexpr int kSegUpFront = 8;     // walks of up to this many iterations are issued as one group (seg_forward)
+// ... the backward holds two packets per iteration and unpacks them to fp32: five (4- / 8-byte storage) or three (16-bit)
+// iterations up front keep it at three waves per SIMD -- BASELINE config 3 is five / three iterations
+template <typename IO>
+constexpr int kSegUpFrontBwd = sizeof(typename IO::elem) >= 4 ? 5 : 3;
+
 // Segment mode with ONE workgroup per channel (segs == osplits == 1: every conv / linear weight whose channel row is
 // not worth splitting -- the usual weight quantizer): the workgroup's sums ARE the channel's sums, so the kernel
 // rounds and stores d_scale / d_shift itself and the finalize launch (3-4 us, a third of the backward of a
@@ -83,6 +89,23 @@ __device__ __forceinline__ void seg_forward(const void* __restrict__ x, void* __
 #pragma unroll
         for (int u = 0; u < H; ++u) emit(e[u], in[u], ok[u]);
     };
+    // A weight channel is a handful of iterations (BASELINE config 3: five in fp32, three in bf16): up to kSegUpFront of them go
+    // out as ONE group of exactly that size -- every load of the walk in flight before the first use, one memory round trip
+    // instead of one per UNROLL-sized group (the order of the arithmetic, hence every sum, is unchanged).
+    if (w.n_it <= kSegUpFront) {
+        switch (static_cast<int>(w.n_it)) {
+            case 1: group(0, std::integral_constant<int, 1>{}); break;
+            case 2: group(0, std::integral_constant<int, 2>{}); break;
+            case 3: group(0, std::integral_constant<int, 3>{}); break;
+            case 4: group(0, std::integral_constant<int, 4>{}); break;
+            case 5: group(0, std::integral_constant<int, 5>{}); break;
+            case 6: group(0, std::integral_constant<int, 6>{}); break;
+            case 7: group(0, std::integral_constant<int, 7>{}); break;
+            case 8: group(0, std::integral_constant<int, 8>{}); break;
+            default: break;
+        }
+        return;
+    }
     int64_t it = 0;
     for (; it + UNROLL <= w.n_it; it += UNROLL) group(it, std::integral_constant<int, UNROLL>{});
     if constexpr (UNROLL >= 8) if (it + 4 <= w.n_it) { group(it, std::integral_constant<int, 4>{}); it += 4; }
@@ -148,6 +171,17 @@ __device__ __forceinline__ void seg_backward(const void* __restrict__ grad, cons
         for (int u = 0; u < H; ++u) emit(e[u], gi[u], xi[u], ok[u]);
     };
     int64_t it = 0;
+    if (w.n_it <= kSegUpFrontBwd<IO>) {       // see seg_forward: the whole walk as one group
+        switch (static_cast<int>(w.n_it)) {
+            case 1: group(0, std::integral_constant<int, 1>{}); break;
+            case 2: group(0, std::integral_constant<int, 2>{}); break;
+            case 3: group(0, std::integral_constant<int, 3>{}); break;
+            case 4: if constexpr (kSegUpFrontBwd<IO> >= 4) group(0, std::integral_constant<int, 4>{}); break;
+            case 5: if constexpr (kSegUpFrontBwd<IO> >= 5) group(0, std::integral_constant<int, 5>{}); break;
+            default: break;
+        }
+        it = w.n_it;
+    }
     for (; it + UNROLL <= w.n_it; it += UNROLL) group(it, std::integral_constant<int, UNROLL>{});
     if constexpr (UNROLL >= 8) if (it + 4 <= w.n_it) { group(it, std::integral_constant<int, 4>{}); it += 4; }
     if constexpr (UNROLL >= 4) if (it + 2 <= w.n_it) { group(it, std::integral_constant<int, 2>{}); it += 2; }
