@@ -381,7 +381,7 @@ def run_rank(a):
         # 20 us workload do not bring the clocks back
         t_warm = time.perf_counter()
         i = 0
-        while i < warmup or (warm_ms > 0 and (time.perf_counter() - t_warm) * 1e3 < warm_ms):
+        while i < warmup or (warm_ms > 0 and world == 1 and (time.perf_counter() - t_warm) * 1e3 < warm_ms):
             cur[0] = i % n_sets
             if step_graphs is not None:
                 step_graphs[cur[0]].replay()
@@ -415,11 +415,12 @@ def run_rank(a):
             dist.barrier()
             torch.cuda.synchronize()
 
-        # HIP events bracket the forward and the backward op on every `stride`-th step of the timed region (an
-        # event record drains the queue, so bracketing every op of every step would itself cost a few % of a
-        # 0.7 ms step); at least 10 steps are sampled.  (Under --graph the ops are nodes of one graph launch, so the
-        # per-op split comes from a second, un-timed pass of eager launches.)
-        stride = max(1, min(4, steps // 10))
+        # HIP events bracket the forward and the backward op on every `stride`-th step of the timed region: ten to nineteen
+        # sampled steps.  (An event record is 2-3 us of host time and drains the queue: bracketing every op of every step
+        # would cost a few % of a 0.7 ms step, and three records on every fourth step -- the earlier rule -- still cost the
+        # host-bound 20 us workloads about a tenth of their step.  Under --graph the ops are nodes of one graph launch, so
+        # the per-op split comes from a second, un-timed pass of eager launches.)
+        stride = max(1, steps // 10)
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] if i % stride == 0 else None for i in range(steps)]
         if world > 1:
             dist.barrier()
@@ -471,7 +472,7 @@ def run_rank(a):
 
     # the non-headline workloads are small (20-100 us per step): W warm-up steps are over before the GPU's clocks have come up,
     # so they warm up for at least 60 ms of wall time (the headline workload, cfg2, does exactly its W steps)
-    warm_floor_ms = 0.0 if a.workload == "cfg2" else 60.0
+    warm_floor_ms = 0.0 if (a.workload == "cfg2" or world > 1) else 60.0      # (N > 1: every rank must run the same steps)
     m = measure(a.workload, a.steps, a.warmup, a.graph, a.buffers, warm_ms=warm_floor_ms)
     c, dtype_name, esz, per_channel, shape, axis = m["c"], m["dtype_name"], m["esz"], m["per_channel"], m["shape"], m["axis"]
     scaling, n_local, n_global, n_sets, set_bytes = m["scaling"], m["n_local"], m["n_global"], m["n_sets"], m["set_bytes"]

@@ -71,7 +71,7 @@ def test_default_line_carries_the_per_channel_half():
     sec = {s["workload"]: s for s in out["secondary"]}
     assert sorted(sec) == ["cfg1", "cfg3", "cfg5", "cfg5_bf16"]
     for s in sec.values():
-        assert "error" not in s and s["value"] > 0 and s["launch"] == "eager" and 0 < s["step_frac"] < 1
+        assert "error" not in s and s["value"] > 0 and s["launch"] == "eager" and 0 < s["step_frac"] < 1, s
     assert "ms_per_step_ctypes_binding" in sec["cfg1"] and sec["cfg5_bf16"]["storage"] == "bfloat16"
 
 
