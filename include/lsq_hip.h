@@ -96,8 +96,9 @@ typedef struct lsq_fwd_extras {
  * share a ticket -- keep one per stream and give captured launches none.
  * Honoured by lsq_hip_backward_per_tensor only.  lsq_hip_backward_per_channel accepts the argument and IGNORES it (it always
  * takes the two-launch route -- or a single launch where one workgroup owns a whole channel, e.g. conv / linear weights):
- * measured on MI355X the folded finalize is not faster than the finalize launch, so the window and
- * segment kernels never got one. */
+ * measured on MI355X the folded finalize is not faster than the finalize launch -- for the per-tensor kernel (DESIGN.md
+ * section 4; the host layers still use it for small tensors, where the saved launch is host time) and for a per-window fold
+ * built for the window kernels (profiles/r03_pc_fused_fold_ab.txt) -- so the per-channel kernels have none. */
 #define LSQ_TICKET_BYTES 4096
 typedef struct lsq_bwd_extras {
     void* ticket;
