@@ -56,7 +56,9 @@ def main():
     cases = [("cfg5 bf16 [256,2048,7,7] axis 1", (256, 2048, 7, 7), 1, torch.bfloat16, (-8, 7, -128, 127)),
              ("cfg5 fp32 [256,2048,7,7] axis 1", (256, 2048, 7, 7), 1, torch.float32, (-8, 7, -128, 127)),
              ("tok bf16 [8192,4096] axis 1", (8192, 4096), 1, torch.bfloat16, (0, 127, 0, 255)),
-             ("[32,256,56,56] bf16 axis 1", (32, 256, 56, 56), 1, torch.bfloat16, (-8, 7, -128, 127))]
+             ("[32,256,56,56] bf16 axis 1", (32, 256, 56, 56), 1, torch.bfloat16, (-8, 7, -128, 127)),
+             ("vit bf16 [64,197,768] axis 2", (64, 197, 768), 2, torch.bfloat16, (0, 127, 0, 255)),
+             ("vit fp32 [64,197,768] axis 2", (64, 197, 768), 2, torch.float32, (0, 127, 0, 255))]
     print("# tools/exp_timeline.py: per-wave shader-clock stamps of the window-mode backward (one launch, cold inputs); us")
     for name, shape, axis, dtype, q in cases:
         n = int(np.prod(shape))
