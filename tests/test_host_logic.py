@@ -344,3 +344,19 @@ def test_lsq_foreach_on_cpu_tensors_is_the_loop(oracle_cpu_backend):
     want = [lsq(x, s, b, axis=0, is_perchannel=True, **kw) for x, s, b in zip(xs, ss, bs)]
     for g, w in zip(got, want):
         assert torch.equal(g, w)
+
+
+def test_single_launch_policy_modes():
+    """TORCHLSQ_SINGLE_LAUNCH_BACKWARD / set_single_launch_backward: "auto" (default) = per-tensor tensors of at most 8 MB,
+    True = always, False = never (host logic only: no GPU needed)"""
+    from torchlsq import extension as E
+    saved = E._SINGLE_LAUNCH_BWD[0]
+    try:
+        E.set_single_launch_backward("auto")
+        assert E._wants_ticket(1) and E._wants_ticket(8 << 20) and not E._wants_ticket((8 << 20) + 1)
+        E.set_single_launch_backward(True)
+        assert E._wants_ticket(1 << 40)
+        E.set_single_launch_backward(False)
+        assert not E._wants_ticket(1)
+    finally:
+        E._SINGLE_LAUNCH_BWD[0] = saved
