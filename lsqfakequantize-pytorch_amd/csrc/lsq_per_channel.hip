@@ -1086,17 +1086,17 @@ __global__ __launch_bounds__(kBlock) void finalize_ww_kernel(const double2* __re
 // =================================================================================================
 // SEGMENT mode: one channel per workgroup
 // =================================================================================================
-template <typename IO, int V, bool INIT, bool LEVELS, int UNROLL, bool NTL, bool NTS>
+template <typename IO, int V, bool INIT, bool LEVELS, int UNROLL, bool NTL, bool NTS, int WALK>
 __global__ __launch_bounds__(kBlock) void fwd_seg_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                          int8_t* __restrict__ levels, int level_bias, int aux_kind, SegGeom g,
                                                          const typename IO::arith* __restrict__ scale,
                                                          const typename IO::arith* __restrict__ shift,
                                                          Range<typename IO::arith> r) {
-    seg_forward<IO, V, INIT, LEVELS, UNROLL, NTL, NTS>(x, y, levels, level_bias, aux_kind, g, SegWalk(g), scale, shift, r);
+    seg_forward<IO, V, INIT, LEVELS, UNROLL, NTL, NTS, WALK>(x, y, levels, level_bias, aux_kind, g, SegWalk(g), scale, shift, r);
 }
 
 // (SegDirect, seg_forward, seg_backward: lsq_seg_body.hpp)
-template <typename IO, int V, bool SYM, bool INIT, bool EVAL, int UNROLL, bool NTL, bool NTS>
+template <typename IO, int V, bool SYM, bool INIT, bool EVAL, int UNROLL, bool NTL, bool NTS, int WALK>
 __global__ __launch_bounds__(kBlock) void bwd_seg_kernel(const void* __restrict__ grad, const void* __restrict__ x,
                                                          void* __restrict__ dx, SegGeom g,
                                                          const typename IO::arith* __restrict__ scale,
@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(kBlock) void bwd_seg_kernel(const void* __restrict_
                                                          Range<typename IO::arith> r, typename IO::arith grad_scaler,
                                                          double2* __restrict__ partials,
                                                          SegDirect<typename IO::arith> direct) {
-    seg_backward<IO, V, SYM, INIT, EVAL, UNROLL, NTL, NTS>(grad, x, dx, g, SegWalk(g), scale, shift, r, grad_scaler, partials,
+    seg_backward<IO, V, SYM, INIT, EVAL, UNROLL, NTL, NTS, WALK>(grad, x, dx, g, SegWalk(g), scale, shift, r, grad_scaler, partials,
                                                            static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x, direct);
 }
 
@@ -1299,9 +1299,17 @@ static hipError_t launch_fwd_seg(const void* x, void* y, int8_t* levels, int bia
     using T = typename IO::arith;
     const Range<T> r = make_range<T>(p);
     const dim3 grid(static_cast<unsigned>(g.C * g.segs), static_cast<unsigned>(g.osplits));
-#define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                      \
-    hipLaunchKernelGGL((fwd_seg_kernel<IO, IO::VEC, INIT, LEVELS, U, NTLF, NTSF>), grid, dim3(kBlock), 0, stream, x, y, levels, \
-                       bias, aux_kind, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r)
+    // the most iterations a workgroup walks: short walks (a weight's channel) and long ones are two kernels (seg_forward)
+    const bool short_walk = g.sub_per_seg * g.o_per_split <= kSegUpFront;
+#define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                              \
+    do {                                                                                                                       \
+        if (short_walk)                                                                                                        \
+            hipLaunchKernelGGL((fwd_seg_kernel<IO, IO::VEC, INIT, LEVELS, U, NTLF, NTSF, 1>), grid, dim3(kBlock), 0, stream, x, y, \
+                               levels, bias, aux_kind, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r);     \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((fwd_seg_kernel<IO, IO::VEC, INIT, LEVELS, U, NTLF, NTSF, 2>), grid, dim3(kBlock), 0, stream, x, y, \
+                               levels, bias, aux_kind, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r);     \
+    } while (0)
     [[maybe_unused]] constexpr bool kFull = !INIT && !LEVELS && (std::is_same<IO, io_f32>::value || std::is_same<IO, io_bf16>::value);
     LSQ_DISPATCH_VARIANT(kFull, kSegUnroll<IO>, v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH
@@ -1598,9 +1606,16 @@ static hipError_t launch_bwd_seg(const void* grad, const void* x, void* dx, cons
     using T = typename IO::arith;
     const Range<T> r = make_range<T>(p);
     const dim3 grid(static_cast<unsigned>(g.C * g.segs), static_cast<unsigned>(g.osplits));
-#define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                         \
-    hipLaunchKernelGGL((bwd_seg_kernel<IO, IO::VEC, SYM, INIT, EVAL, U, NTLF, NTSF>), grid, dim3(kBlock), 0, stream, grad, x, dx, \
-                       g, static_cast<const T*>(scale), static_cast<const T*>(shift), r, gs, partials, direct)
+    const bool short_walk = g.sub_per_seg * g.o_per_split <= kSegUpFrontBwd<IO>;
+#define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                                 \
+    do {                                                                                                                          \
+        if (short_walk)                                                                                                           \
+            hipLaunchKernelGGL((bwd_seg_kernel<IO, IO::VEC, SYM, INIT, EVAL, U, NTLF, NTSF, 1>), grid, dim3(kBlock), 0, stream, grad, \
+                               x, dx, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r, gs, partials, direct);  \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((bwd_seg_kernel<IO, IO::VEC, SYM, INIT, EVAL, U, NTLF, NTSF, 2>), grid, dim3(kBlock), 0, stream, grad, \
+                               x, dx, g, static_cast<const T*>(scale), static_cast<const T*>(shift), r, gs, partials, direct);  \
+    } while (0)
     [[maybe_unused]] constexpr bool kFull = !INIT && !EVAL && (std::is_same<IO, io_f32>::value || std::is_same<IO, io_bf16>::value);
     LSQ_DISPATCH_VARIANT(kFull, kSegUnroll<IO>, v, LSQ_LAUNCH);
 #undef LSQ_LAUNCH

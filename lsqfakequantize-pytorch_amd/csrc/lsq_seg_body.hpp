@@ -36,7 +36,10 @@ struct SegDirect {
 };
 
 // One channel segment of the forward: the workgroup's walk `w` over channel w.c of the [outer, C, inner] tensor.
-template <typename IO, int V, bool INIT, bool LEVELS, int UNROLL, bool NTL, bool NTS>
+// WALK: 0 = any walk (the multi-tensor kernels), 1 = short walks only (at most kSegUpFront iterations: the caller checked),
+// 2 = the loop only -- the single-tensor kernels are compiled per kind so that the up-front groups' registers do not cost the
+// long walks their occupancy ([4,8,1048576] bf16 forward 24.4 -> 26.9 us when both forms shared one kernel).
+template <typename IO, int V, bool INIT, bool LEVELS, int UNROLL, bool NTL, bool NTS, int WALK = 0>
 __device__ __forceinline__ void seg_forward(const void* __restrict__ x, void* __restrict__ y, int8_t* __restrict__ levels,
                                             int level_bias, int aux_kind, const SegGeom& g, const SegWalk& w,
                                             const typename IO::arith* __restrict__ scale,
@@ -92,20 +95,23 @@ __device__ __forceinline__ void seg_forward(const void* __restrict__ x, void* __
     // A weight channel is a handful of iterations (BASELINE config 3: five in fp32, three in bf16): up to kSegUpFront of them go
     // out as ONE group of exactly that size -- every load of the walk in flight before the first use, one memory round trip
     // instead of one per UNROLL-sized group (the order of the arithmetic, hence every sum, is unchanged).
-    if (w.n_it <= kSegUpFront) {
-        switch (static_cast<int>(w.n_it)) {
-            case 1: group(0, std::integral_constant<int, 1>{}); break;
-            case 2: group(0, std::integral_constant<int, 2>{}); break;
-            case 3: group(0, std::integral_constant<int, 3>{}); break;
-            case 4: group(0, std::integral_constant<int, 4>{}); break;
-            case 5: group(0, std::integral_constant<int, 5>{}); break;
-            case 6: group(0, std::integral_constant<int, 6>{}); break;
-            case 7: group(0, std::integral_constant<int, 7>{}); break;
-            case 8: group(0, std::integral_constant<int, 8>{}); break;
-            default: break;
+    if constexpr (WALK != 2) {
+        if (WALK == 1 || w.n_it <= kSegUpFront) {
+            switch (static_cast<int>(w.n_it)) {
+                case 1: group(0, std::integral_constant<int, 1>{}); break;
+                case 2: group(0, std::integral_constant<int, 2>{}); break;
+                case 3: group(0, std::integral_constant<int, 3>{}); break;
+                case 4: group(0, std::integral_constant<int, 4>{}); break;
+                case 5: group(0, std::integral_constant<int, 5>{}); break;
+                case 6: group(0, std::integral_constant<int, 6>{}); break;
+                case 7: group(0, std::integral_constant<int, 7>{}); break;
+                case 8: group(0, std::integral_constant<int, 8>{}); break;
+                default: break;
+            }
+            return;
         }
-        return;
     }
+    if constexpr (WALK == 1) return;
     int64_t it = 0;
     for (; it + UNROLL <= w.n_it; it += UNROLL) group(it, std::integral_constant<int, UNROLL>{});
     if constexpr (UNROLL >= 8) if (it + 4 <= w.n_it) { group(it, std::integral_constant<int, 4>{}); it += 4; }
@@ -115,7 +121,7 @@ __device__ __forceinline__ void seg_forward(const void* __restrict__ x, void* __
 
 // One channel segment of the backward (dx + the segment's d_scale / d_shift sums).  direct.ds != nullptr: the segment is
 // the whole channel, its sums are rounded and stored here; otherwise they go to partials[partial_index].
-template <typename IO, int V, bool SYM, bool INIT, bool EVAL, int UNROLL, bool NTL, bool NTS>
+template <typename IO, int V, bool SYM, bool INIT, bool EVAL, int UNROLL, bool NTL, bool NTS, int WALK = 0>
 __device__ __forceinline__ void seg_backward(const void* __restrict__ grad, const void* __restrict__ x, void* __restrict__ dx,
                                              const SegGeom& g, const SegWalk& w,
                                              const typename IO::arith* __restrict__ scale,
@@ -171,21 +177,25 @@ __device__ __forceinline__ void seg_backward(const void* __restrict__ grad, cons
         for (int u = 0; u < H; ++u) emit(e[u], gi[u], xi[u], ok[u]);
     };
     int64_t it = 0;
-    if (w.n_it <= kSegUpFrontBwd<IO>) {       // see seg_forward: the whole walk as one group
-        switch (static_cast<int>(w.n_it)) {
-            case 1: group(0, std::integral_constant<int, 1>{}); break;
-            case 2: group(0, std::integral_constant<int, 2>{}); break;
-            case 3: group(0, std::integral_constant<int, 3>{}); break;
-            case 4: if constexpr (kSegUpFrontBwd<IO> >= 4) group(0, std::integral_constant<int, 4>{}); break;
-            case 5: if constexpr (kSegUpFrontBwd<IO> >= 5) group(0, std::integral_constant<int, 5>{}); break;
-            default: break;
+    if constexpr (WALK != 2) {
+        if (WALK == 1 || w.n_it <= kSegUpFrontBwd<IO>) {       // see seg_forward: the whole walk as one group
+            switch (static_cast<int>(w.n_it)) {
+                case 1: group(0, std::integral_constant<int, 1>{}); break;
+                case 2: group(0, std::integral_constant<int, 2>{}); break;
+                case 3: group(0, std::integral_constant<int, 3>{}); break;
+                case 4: if constexpr (kSegUpFrontBwd<IO> >= 4) group(0, std::integral_constant<int, 4>{}); break;
+                case 5: if constexpr (kSegUpFrontBwd<IO> >= 5) group(0, std::integral_constant<int, 5>{}); break;
+                default: break;
+            }
+            it = w.n_it;
         }
-        it = w.n_it;
     }
-    for (; it + UNROLL <= w.n_it; it += UNROLL) group(it, std::integral_constant<int, UNROLL>{});
-    if constexpr (UNROLL >= 8) if (it + 4 <= w.n_it) { group(it, std::integral_constant<int, 4>{}); it += 4; }
-    if constexpr (UNROLL >= 4) if (it + 2 <= w.n_it) { group(it, std::integral_constant<int, 2>{}); it += 2; }
-    if constexpr (UNROLL >= 2) if (it < w.n_it) group(it, std::integral_constant<int, 1>{});
+    if constexpr (WALK != 1) {
+        for (; it + UNROLL <= w.n_it; it += UNROLL) group(it, std::integral_constant<int, UNROLL>{});
+        if constexpr (UNROLL >= 8) if (it + 4 <= w.n_it) { group(it, std::integral_constant<int, 4>{}); it += 4; }
+        if constexpr (UNROLL >= 4) if (it + 2 <= w.n_it) { group(it, std::integral_constant<int, 2>{}); it += 2; }
+        if constexpr (UNROLL >= 2) if (it < w.n_it) group(it, std::integral_constant<int, 1>{});
+    }
     if (EVAL) {
         if (direct.ds && threadIdx.x == 0) direct.write(w.c, g.C, 0.0, 0.0);   // d_scale = d_shift = 0 (lsq_kernel.h:142-144)
         return;
