@@ -293,6 +293,7 @@ void lsq_hip_debug_set_ring_nt(int v) { lsq::knob::set(lsq::knob::kRingNt, v); }
 void lsq_hip_debug_set_ww_max_log2(int v) { lsq::knob::set(lsq::knob::kWwMaxLog2, v < 0 || v > 40 ? 0 : v); }
 void lsq_hip_debug_set_seg_min_div(int v) { lsq::knob::set(lsq::knob::kSegMinDiv, v < 0 || v > 16 ? 0 : v); }
 void lsq_hip_debug_set_fwd_direct(int v) { lsq::knob::set(lsq::knob::kFwdDirect, v < 0 || v > 4 ? 0 : v); }
+void lsq_hip_debug_set_seg_no_up_front(int v) { lsq::knob::set(lsq::knob::kSegNoUpFront, v ? 1 : 0); }
 void lsq_hip_debug_set_fin_ch(int v) { lsq::knob::set(lsq::knob::kFinCh, v); }
 
 #ifdef LSQ_TIMELINE

@@ -42,6 +42,7 @@ void lsq_hip_debug_set_ww_big(int v);       /* 1024-lane row-group workgroups: 0
 void lsq_hip_debug_set_ww_max_log2(int v);  /* row-group windows for last-axis tensors below 2^v elements: 0 = policy */
 void lsq_hip_debug_set_seg_min_div(int v);  /* forward / backward: segment mode for channel rows of at least 1/v of a workgroup's span (1 = whole spans only): 0 = policy */
 void lsq_hip_debug_set_fwd_direct(int v);   /* last-axis forward: 0 / 3 = policy (lanes read their own scale / shift), 1 = the same on the usual grid, 2 = LDS table */
+void lsq_hip_debug_set_seg_no_up_front(int v); /* segment kernels: 1 = always the loop form, never the one-group short walk */
 void lsq_hip_debug_set_fin_ch(int v);
 /* tuning only: override the workgroups-per-CU of the observer-statistics kernels (0 = defaults) */
 void lsq_hip_debug_set_observe_wg_per_cu(int v);

@@ -57,7 +57,7 @@ constexpr int kDefaultPcSegNarrowVariant = encode_variant(1, true, true, 16);   
 // constant 0 ("no override"), the policy code that consults it folds away, no lsq_hip_debug_* symbol is exported, and the
 // library keeps no mutable global state (include/lsq_hip.h).
 namespace knob {
-enum Id { kForceRing, kWwMinRows, kWwSplit64, kWwBig, kRingNt, kFinCh, kObserveWgPerCu, kWwMaxLog2, kSegMinDiv, kFwdDirect, kCount };
+enum Id { kForceRing, kWwMinRows, kWwSplit64, kWwBig, kRingNt, kFinCh, kObserveWgPerCu, kWwMaxLog2, kSegMinDiv, kFwdDirect, kSegNoUpFront, kCount };
 #ifdef LSQ_TOOLS
 inline std::atomic<int>& slot(Id id) {
     static std::atomic<int> v[kCount];

@@ -1300,7 +1300,10 @@ static hipError_t launch_fwd_seg(const void* x, void* y, int8_t* levels, int bia
     const Range<T> r = make_range<T>(p);
     const dim3 grid(static_cast<unsigned>(g.C * g.segs), static_cast<unsigned>(g.osplits));
     // the most iterations a workgroup walks: short walks (a weight's channel) and long ones are two kernels (seg_forward)
-    const bool short_walk = g.sub_per_seg * g.o_per_split <= kSegUpFront;
+    // (not for a big grid whose iterations are rows 16 MB apart instead of neighbouring sub-rows: [4,8,1048576] bf16 forward
+    // 23.7 us with the loop, 26.4 us with the group -- profiles/r03_seg_up_front_ab.txt)
+    const bool short_walk = g.sub_per_seg * g.o_per_split <= kSegUpFront && knob::get(knob::kSegNoUpFront) == 0 &&
+                            (g.o_per_split == 1 || g.C * g.segs * g.osplits <= 8 * static_cast<int64_t>(device_info().cu_count));
 #define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                              \
     do {                                                                                                                       \
         if (short_walk)                                                                                                        \
@@ -1606,7 +1609,8 @@ static hipError_t launch_bwd_seg(const void* grad, const void* x, void* dx, cons
     using T = typename IO::arith;
     const Range<T> r = make_range<T>(p);
     const dim3 grid(static_cast<unsigned>(g.C * g.segs), static_cast<unsigned>(g.osplits));
-    const bool short_walk = g.sub_per_seg * g.o_per_split <= kSegUpFrontBwd<IO>;
+    const bool short_walk = g.sub_per_seg * g.o_per_split <= kSegUpFrontBwd<IO> && knob::get(knob::kSegNoUpFront) == 0 &&
+                            (g.o_per_split == 1 || g.C * g.segs * g.osplits <= 8 * static_cast<int64_t>(device_info().cu_count));
 #define LSQ_LAUNCH(U, NTLF, NTSF)                                                                                                 \
     do {                                                                                                                          \
         if (short_walk)                                                                                                           \
