@@ -43,6 +43,10 @@ int lsq_cpu_backward_per_channel(int dtype, const void* grad, const void* x, voi
                                  double* dsdb_wide, int64_t outer, int64_t channels, int64_t inner, const void* scale,
                                  const void* shift, const lsq_params* p);
 
+/* lsq_hip_sharded_finish for host memory: scaler from the all-reduced element count + one rounding (see lsq_hip.h). */
+int lsq_cpu_sharded_finish(int dtype, const double* packed, int64_t channels, int32_t per_channel, const lsq_params* p,
+                           void* ds, void* db);
+
 #ifdef __cplusplus
 }
 #endif

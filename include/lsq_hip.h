@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LSQ_HIP_ABI_VERSION 3
+#define LSQ_HIP_ABI_VERSION 4
 
 /* Storage type of x / grad / y / dx.  Arithmetic is fp32 for F32, BF16 and F16 storage and fp64
  * for F64 (reference CPU path: AT_DISPATCH_FLOATING_TYPES, lsq_cpu.cpp:37,92,182,243).
@@ -77,9 +77,14 @@ typedef struct lsq_params {
 
 /* Optional extra output of the forward: ONE auxiliary byte per element, laid out like y (NULL = not wanted).
  *  aux_kind 0 -- integer levels: q = rne(clamp(x/s + zp, quant_min, quant_max))  (lsq_kernel.h:13), stored
- *                as (int8_t)(q - level_bias); level_bias lets quint8 ranges (0..255) fit (use 128).
+ *                as the byte (q - level_bias) mod 256: an int8 when [quant_min, quant_max] - level_bias lies in
+ *                -128..127 (qint8 levels as they are; quint8 levels with level_bias 128), a uint8 when it lies in 0..255
+ *                (quint8 levels as they are, level_bias 0: the int_repr of a torch.quint8 tensor).
  *  aux_kind 1 -- inside mask: 1 where quant_min < clamp(..) < quant_max strictly, else 0: everything the
- *                eval-mode backward needs (lsq_kernel.h:126-145), see lsq_hip_backward_from_mask. */
+ *                eval-mode backward needs (lsq_kernel.h:126-145), see lsq_hip_backward_from_mask.
+ * With `levels` set the forward's `y` argument may be NULL: only the bytes are written (5 instead of 9 bytes of traffic per
+ * fp32 element) -- the conversion-time pass that turns a trained fake-quantizer's input into a real quantized tensor
+ * (reference quantized/modules/observers.py:378-422 supplies scale / zero_point for it) needs nothing else. */
 typedef struct lsq_fwd_extras {
     void* levels;
     int32_t level_bias;
@@ -163,6 +168,24 @@ int lsq_hip_backward_per_channel(int dtype, const void* grad, const void* x, voi
                                  int64_t inner, const void* scale, const void* shift,
                                  const lsq_params* p, const lsq_bwd_extras* extras, void* workspace,
                                  size_t workspace_bytes, void* stream);
+
+/* ---- batch-sharded backward: the epilogue after the all-reduce --------------------------------------- */
+
+/* One process per GPU, the batch (dim 0) split over the ranks: forward and dx need no communication, d_scale / d_shift are
+ * sums over ALL ranks' elements and their gradient scaler 1/sqrt(numel*quant_max[/C]) (lsq_cpu.cpp:103,250) wants the
+ * GLOBAL element count.  When every rank knows that count up front it goes into lsq_params.numel_for_scaler and the
+ * all-reduced dsdb_wide only has to be rounded.  When it does not (uneven shards, e.g. the last batch of an epoch), the
+ * count travels in the same collective:
+ *   1. each rank runs lsq_hip_backward_* with use_grad_scaling = 0, grad_scaler = 1 (unscaled terms) and dsdb_wide =
+ *      packed, a double[2*channels + 1] whose last slot the caller sets to the shard's element count;
+ *   2. ONE all-reduce(SUM) of `packed` (RCCL over xGMI; 24 bytes for a per-tensor quantizer);
+ *   3. lsq_hip_sharded_finish derives the scaler from packed[2*channels] ON THE DEVICE (no host round trip) with the
+ *      reference's precision chain for `dtype`'s arithmetic type, using p->quant_max, p->use_grad_scaling and
+ *      p->grad_scaler, multiplies the fp64 sums once and rounds once: ds[c] = T(packed[c] * gs), db[c] = T(packed[C+c] * gs).
+ * The result differs from the up-front route only in where the scaler's rounding happens (per term there, once per sum
+ * here): well inside the 1e-6 parity budget.  A global count of 0 stores zeros.  per_channel = 0 requires channels = 1. */
+int lsq_hip_sharded_finish(int dtype, const double* packed, int64_t channels, int32_t per_channel, const lsq_params* p,
+                           void* ds, void* db, void* stream);
 
 /* ---- many per-channel quantizers in one launch --------------------------------------------------- */
 

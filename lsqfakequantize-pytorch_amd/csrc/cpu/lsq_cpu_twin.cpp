@@ -229,6 +229,27 @@ int check(int dtype, const lsq_params* p) {
 
 }  // namespace
 
+// lsq_hip_sharded_finish for host memory: gradient scaler (lsq_cpu.cpp:103-104 / :250-251, same chain as this file's
+// backward) from the all-reduced element count, applied once to the fp64 sums, one rounding to the parameter type.
+template <typename T>
+static int sharded_finish(const double* packed, int64_t C, bool per_channel, const lsq_params& p, void* ds_, void* db_) {
+    T* ds = static_cast<T*>(ds_);
+    T* db = static_cast<T*>(db_);
+    const double count = packed[2 * C];
+    T gs = static_cast<T>(p.grad_scaler);
+    if (p.use_grad_scaling) {
+        T prod = static_cast<T>(count) * static_cast<T>(p.quant_max);
+        if (per_channel) prod = prod / static_cast<T>(C);
+        gs = static_cast<T>(p.grad_scaler / static_cast<double>(std::sqrt(prod)));
+    }
+    if (!(count > 0.0)) gs = static_cast<T>(0);
+    for (int64_t c = 0; c < C; ++c) {
+        ds[c] = static_cast<T>(packed[c] * static_cast<double>(gs));
+        db[c] = static_cast<T>(packed[C + c] * static_cast<double>(gs));
+    }
+    return LSQ_OK;
+}
+
 #define LSQ_CPU_DISPATCH(dtype, CALL)                 \
     switch (dtype) {                                  \
         case LSQ_F32: { using IO = F32; return CALL; }   \
@@ -276,6 +297,15 @@ int lsq_cpu_backward_per_channel(int dtype, const void* grad, const void* x, voi
     if (outer <= 0 || channels <= 0 || inner <= 0) return fail(LSQ_EINVAL, "backward_per_channel: empty or bad [outer, C, inner]");
     if (!grad || !x || !dx || !ds || !db || !scale || !shift) return fail(LSQ_EINVAL, "backward_per_channel: NULL buffer");
     LSQ_CPU_DISPATCH(dtype, backward_pc<IO>(grad, x, dx, ds, db, dsdb_wide, outer, channels, inner, scale, shift, *p));
+}
+
+int lsq_cpu_sharded_finish(int dtype, const double* packed, int64_t channels, int32_t per_channel, const lsq_params* p,
+                           void* ds, void* db) {
+    if (int rc = check(dtype, p)) return rc;
+    if (channels <= 0 || (!per_channel && channels != 1)) return fail(LSQ_EINVAL, "sharded_finish: bad channel count");
+    if (!packed || !ds || !db) return fail(LSQ_EINVAL, "sharded_finish: NULL buffer");
+    return dtype == LSQ_F64 ? sharded_finish<double>(packed, channels, per_channel != 0, *p, ds, db)
+                            : sharded_finish<float>(packed, channels, per_channel != 0, *p, ds, db);
 }
 
 }  // extern "C"

@@ -48,8 +48,8 @@ int check_common(int dtype, const lsq_params* p) {
 int check_levels(const lsq_params* p, const lsq_fwd_extras* ex) {
     if (ex && ex->levels && ex->aux_kind == 0) {
         const int lo = p->quant_min - ex->level_bias, hi = p->quant_max - ex->level_bias;
-        if (lo < -128 || hi > 127)
-            return fail(LSQ_EINVAL, "levels: [quant_min, quant_max] - level_bias = [%d, %d] does not fit int8", lo, hi);
+        if (!((lo >= -128 && hi <= 127) || (lo >= 0 && hi <= 255)))      // the byte is (q - level_bias) mod 256
+            return fail(LSQ_EINVAL, "levels: [quant_min, quant_max] - level_bias = [%d, %d] fits neither int8 nor uint8", lo, hi);
     }
     return LSQ_OK;
 }
@@ -136,7 +136,7 @@ LSQ_EX_LINKAGE int lsq_hip_forward_per_tensor_ex(int dtype, const void* x, void*
     if (int rc = check_common(dtype, p)) return rc;
     if (n < 0) return fail(LSQ_EINVAL, "negative element count %lld", static_cast<long long>(n));
     if (n == 0) return LSQ_OK;
-    if (!x || !y || !scale || !shift) return fail(LSQ_EINVAL, "forward_per_tensor: NULL buffer");
+    if (!x || !scale || !shift || (!y && !(extras && extras->levels))) return fail(LSQ_EINVAL, "forward_per_tensor: NULL buffer");
     if (int rc = check_levels(p, extras)) return rc;
     hipError_t e = hipSuccess;
     LSQ_DISPATCH_IO(dtype, e = lsq::forward_per_tensor<IO>(x, y, n, scale, shift, *p, extras, variant,
@@ -190,7 +190,7 @@ LSQ_EX_LINKAGE int lsq_hip_forward_per_channel_ex(int dtype, const void* x, void
     if (int rc = check_common(dtype, p)) return rc;
     if (int rc = check_ocl(outer, channels, inner)) return rc;
     if (outer == 0 || inner == 0) return LSQ_OK;
-    if (!x || !y || !scale || !shift) return fail(LSQ_EINVAL, "forward_per_channel: NULL buffer");
+    if (!x || !scale || !shift || (!y && !(extras && extras->levels))) return fail(LSQ_EINVAL, "forward_per_channel: NULL buffer");
     if (int rc = check_levels(p, extras)) return rc;
     hipError_t e = hipSuccess;
     LSQ_DISPATCH_IO(dtype, e = lsq::forward_per_channel<IO>(x, y, outer, channels, inner, scale, shift, *p, extras,
@@ -281,6 +281,19 @@ int lsq_hip_backward_from_mask(int dtype, const void* grad, const void* mask, vo
     hipError_t e = hipSuccess;
     LSQ_DISPATCH_IO(dtype, e = lsq::backward_from_mask<IO>(grad, mask, dx, n, static_cast<hipStream_t>(stream)));
     return hip_status(e, "lsq_hip_backward_from_mask");
+}
+
+int lsq_hip_sharded_finish(int dtype, const double* packed, int64_t channels, int32_t per_channel, const lsq_params* p,
+                           void* ds, void* db, void* stream) {
+    if (int rc = check_common(dtype, p)) return rc;
+    if (channels <= 0) return fail(LSQ_EINVAL, "sharded_finish: channel count must be positive");
+    if (!per_channel && channels != 1) return fail(LSQ_EINVAL, "sharded_finish: a per-tensor quantizer has one channel");
+    if (!packed || !ds || !db) return fail(LSQ_EINVAL, "sharded_finish: NULL buffer");
+    if (reinterpret_cast<uintptr_t>(packed) & 7u) return fail(LSQ_EINVAL, "sharded_finish: packed must be 8-byte aligned");
+    hipError_t e = dtype == LSQ_F64
+                       ? lsq::sharded_finish<double>(packed, channels, per_channel != 0, *p, ds, db, static_cast<hipStream_t>(stream))
+                       : lsq::sharded_finish<float>(packed, channels, per_channel != 0, *p, ds, db, static_cast<hipStream_t>(stream));
+    return hip_status(e, "lsq_hip_sharded_finish");
 }
 
 #ifdef LSQ_TOOLS

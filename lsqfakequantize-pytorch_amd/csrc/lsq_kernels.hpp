@@ -345,6 +345,11 @@ hipError_t forward_per_channel_multi(const lsq_pc_item* items, int32_t count, co
 template <typename IO>
 hipError_t backward_per_channel_multi(const lsq_pc_item* items, int32_t count, const lsq_params& p, hipStream_t stream);
 
+// batch-sharded backward: scaler from the global element count + rounding, after the all-reduce (lsq_per_tensor.hip)
+template <typename T>
+hipError_t sharded_finish(const double* packed, int64_t channels, bool per_channel, const lsq_params& p, void* ds, void* db,
+                          hipStream_t stream);
+
 template <typename IO>
 hipError_t backward_from_mask(const void* grad, const void* mask, void* dx, int64_t n, hipStream_t stream);
 

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
             }
         }
         if (valid) {
-            store_elems<IO, V, NTS>(y, e, out);
+            if (!LEVELS || y != nullptr) store_elems<IO, V, NTS>(y, e, out);     // y == NULL: the one-byte output only
             if (LEVELS) lv.store(levels + e);
         }
     };

@@ -71,7 +71,9 @@ __global__ __launch_bounds__(kBlock) void fwd_pt_kernel(const void* __restrict__
             out.v[j] = IO::to_elem(INIT ? xv : dequant<T>(rne(c), q));  // lsq_kernel.h:13
             if (LEVELS) lv.b[j] = aux_byte<T>(c, r, bias, aux_kind);
         }
-        if (NTS) store_packet_nt<IO>(y, p * VEC, out); else store_packet<IO>(y, p * VEC, out);
+        if (!LEVELS || y != nullptr) {     // y == NULL: only the one-byte output is wanted (include/lsq_hip.h, lsq_fwd_extras)
+            if (NTS) store_packet_nt<IO>(y, p * VEC, out); else store_packet<IO>(y, p * VEC, out);
+        }
         if (LEVELS) lv.store(levels + p * VEC);
     };
 
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void fwd_pt_kernel(const void* __restrict__
         if (i < n) {
             const T xv = IO::load1(x, i);
             const T c = clamped<T>(xv, q, r);
-            IO::store1(y, i, INIT ? xv : dequant<T>(rne(c), q));
+            if (!LEVELS || y != nullptr) IO::store1(y, i, INIT ? xv : dequant<T>(rne(c), q));
             if (LEVELS) levels[i] = aux_byte<T>(c, r, bias, aux_kind);
         }
     }
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void fwd_pt_scalar_kernel(const void* __res
          i += static_cast<int64_t>(gridDim.x) * kBlock) {
         const T xv = IO::load1(x, i);
         const T c = clamped<T>(xv, q, r);
-        IO::store1(y, i, INIT ? xv : dequant<T>(rne(c), q));
+        if (!LEVELS || y != nullptr) IO::store1(y, i, INIT ? xv : dequant<T>(rne(c), q));
         if (LEVELS) levels[i] = aux_byte<T>(c, r, bias, aux_kind);
     }
 }
@@ -491,6 +493,43 @@ hipError_t backward_from_mask(const void* grad, const void* mask, void* dx, int6
                        static_cast<const int8_t*>(mask), dx, n, aligned ? 1 : 0);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// batch-sharded backward, the epilogue after the all-reduce (lsq_hip_sharded_finish): packed = {sum ds terms [C],
+// sum db terms [C], element count}, every slot summed over the ranks; the terms are UNSCALED (the local backward ran with
+// use_grad_scaling = 0, grad_scaler = 1), so the scaler of lsq_cpu.cpp:103-104 / :250-251 -- same precision chain as
+// grad_scaler_per_tensor / _per_channel above, evaluated on the device because the global count only exists there --
+// multiplies the fp64 sums once, and the product is rounded once to the parameter type.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sharded_finish_kernel(const double* __restrict__ packed, int64_t channels,
+                                                                int per_channel, T qmax, int use_grad_scaling,
+                                                                double grad_scaler, T* __restrict__ ds, T* __restrict__ db) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (c >= channels) return;
+    const double count = packed[2 * channels];
+    T gs = static_cast<T>(grad_scaler);
+    if (use_grad_scaling) {
+        T prod = static_cast<T>(count) * qmax;                      // int64 numel -> scalar_t, times scalar_t(quant_max)
+        if (per_channel) prod = prod / static_cast<T>(channels);
+        gs = static_cast<T>(grad_scaler / static_cast<double>(sqrt(prod)));
+    }
+    if (!(count > 0.0)) gs = static_cast<T>(0);                      // every shard empty: nothing was summed
+    ds[c] = static_cast<T>(packed[c] * static_cast<double>(gs));
+    db[c] = static_cast<T>(packed[channels + c] * static_cast<double>(gs));
+}
+
+template <typename T>
+hipError_t sharded_finish(const double* packed, int64_t channels, bool per_channel, const lsq_params& p, void* ds, void* db,
+                          hipStream_t stream) {
+    const int grid = static_cast<int>((channels + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((sharded_finish_kernel<T>), dim3(grid), dim3(kBlock), 0, stream, packed, channels, per_channel ? 1 : 0,
+                       static_cast<T>(p.quant_max), p.use_grad_scaling ? 1 : 0, p.grad_scaler, static_cast<T*>(ds),
+                       static_cast<T*>(db));
+    return hipGetLastError();
+}
+template hipError_t sharded_finish<float>(const double*, int64_t, bool, const lsq_params&, void*, void*, hipStream_t);
+template hipError_t sharded_finish<double>(const double*, int64_t, bool, const lsq_params&, void*, void*, hipStream_t);
 
 // explicit instantiations used by the C ABI (lsq_capi.hip)
 #define LSQ_INSTANTIATE(IO)                                                                                        \

@@ -72,7 +72,7 @@ __device__ __forceinline__ void seg_forward(const void* __restrict__ x, void* __
             if (LEVELS) lv.b[j] = aux_byte<T>(c, r, bias, aux_kind);
         }
         if (valid) {
-            store_elems<IO, V, NTS>(y, e, out);
+            if (!LEVELS || y != nullptr) store_elems<IO, V, NTS>(y, e, out);     // y == NULL: the one-byte output only
             if (LEVELS) lv.store(levels + e);
         }
     };

@@ -56,7 +56,7 @@ class LsqPcItem(ctypes.Structure):
 
 
 LSQ_TICKET_BYTES = 4096
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
 _PP = ctypes.POINTER(LsqParams)
@@ -76,6 +76,7 @@ C_ABI = {
     "lsq_hip_forward_per_channel": (_int, [_int, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP, _EP, _vp]),
     "lsq_hip_backward_per_channel": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP, _BP,
                                             _vp, _sz, _vp]),
+    "lsq_hip_sharded_finish": (_int, [_int, _vp, _i64, ctypes.c_int32, _PP, _vp, _vp, _vp]),
     "lsq_hip_per_channel_multi_ok": (_int, [_int, _i64, _i64, _i64, _int]),
     "lsq_hip_forward_per_channel_multi": (_int, [_int, ctypes.POINTER(LsqPcItem), ctypes.c_int32, _PP, _vp]),
     "lsq_hip_backward_per_channel_multi": (_int, [_int, ctypes.POINTER(LsqPcItem), ctypes.c_int32, _PP, _vp]),
@@ -129,6 +130,7 @@ C_ABI_CPU = {
     "lsq_cpu_backward_per_tensor": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _PP]),
     "lsq_cpu_forward_per_channel": (_int, [_int, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP]),
     "lsq_cpu_backward_per_channel": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _PP]),
+    "lsq_cpu_sharded_finish": (_int, [_int, _vp, _i64, ctypes.c_int32, _PP, _vp, _vp]),
 }
 
 

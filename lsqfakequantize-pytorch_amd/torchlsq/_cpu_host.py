@@ -66,7 +66,7 @@ def cpu_forward(x, scale, shift, axis, per_channel, qmin, qmax, tmin, tmax, use_
 
 
 def cpu_backward(grad, x, scale, shift, axis, per_channel, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode,
-                 numel_for_scaler=0, want_wide=False):
+                 numel_for_scaler=0, want_wide=False, wide_out=None):
     what = "lsq_backward_per_channel" if per_channel else "lsq_backward_per_tensor"
     lib = _cpu_lib(what)
     code = _cpu_dtype(x, "lsq_backward")
@@ -76,6 +76,9 @@ def cpu_backward(grad, x, scale, shift, axis, per_channel, qmin, qmax, tmin, tma
     C = scale.numel() if per_channel else 1
     if x.numel() <= 0:  # lsq_cpu.cpp:76-78, :221-223 return (x, scale, shift) themselves
         if want_wide:
+            if wide_out is not None:
+                wide_out[:2 * C].zero_()
+                return x.clone(), wide_out
             return x.clone(), torch.zeros((2, C) if per_channel else (2,), dtype=torch.float64)
         return x.clone(), scale.clone(), shift.clone()
     _require_cpu(what, x, grad, scale, shift)
@@ -85,7 +88,13 @@ def cpu_backward(grad, x, scale, shift, axis, per_channel, qmin, qmax, tmin, tma
     dx = torch.empty_like(xd)
     pd = _param_dtype(x)
     ds, db = torch.empty(C, dtype=pd), torch.empty(C, dtype=pd)
-    wide = torch.empty((2, C) if per_channel else (2,), dtype=torch.float64) if want_wide else None
+    wide = None
+    if want_wide and wide_out is not None:      # the caller's buffer (the sharded path packs the element count behind the sums)
+        _check(wide_out.dtype == torch.float64 and wide_out.is_contiguous() and wide_out.numel() >= 2 * C and
+               wide_out.device.type == "cpu", "wide_out must be a contiguous float64 CPU tensor of at least 2 * channels elements")
+        wide = wide_out
+    elif want_wide:
+        wide = torch.empty((2, C) if per_channel else (2,), dtype=torch.float64)
     _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode, numel_for_scaler)
     sc, sh = scale.contiguous(), shift.contiguous()
     wptr = wide.data_ptr() if want_wide else None
@@ -100,6 +109,50 @@ def cpu_backward(grad, x, scale, shift, axis, per_channel, qmin, qmax, tmin, tma
     if want_wide:
         return dx, wide
     return dx, ds, db
+
+
+def cpu_levels(x, scale, shift, axis, per_channel, qmin, qmax, tmin, tmax, level_bias):
+    """The integer levels of lsq_kernel.h:13 for a tensor in host memory, as the byte (q - level_bias) mod 256: the formula of
+    the forward kernels operation by operation in torch's own (individually rounded) tensor arithmetic -- a conversion-time
+    helper on the CPU, not a hot path."""
+    _cpu_lib("lsq_levels")
+    check_forward_dtypes(x, scale, shift)
+    _require_cpu("lsq_levels", x, scale, shift)
+    if per_channel:
+        check_channel_args(x, scale, shift, axis, backward=False)
+    lo, hi = qmin - level_bias, qmax - level_bias
+    _check((lo >= -128 and hi <= 127) or (lo >= 0 and hi <= 255),
+           "levels: [quant_min, quant_max] - level_bias = [%d, %d] fits neither int8 nor uint8" % (lo, hi))
+    t = _param_dtype(x)
+    xf = x.detach().to(t)
+    eps = torch.finfo(t).eps
+    s = scale.detach().abs().clamp_min(eps)
+    inv_s = 1.0 / s
+    zp = torch.fmin(torch.full_like(s, tmax), torch.fmax(torch.full_like(s, tmin), -shift.detach() * inv_s)).round()
+    if per_channel:
+        view = [1] * x.dim()
+        view[axis] = -1
+        inv_s, zp = inv_s.view(view), zp.view(view)
+    q = xf * inv_s
+    q = q + zp
+    q = torch.fmin(torch.full_like(q, qmax), torch.fmax(torch.full_like(q, qmin), q)).round()      # NaN -> quant_min, like the kernels
+    return (q - level_bias).to(torch.int32).to(torch.int8)
+
+
+def cpu_sharded_finish(packed, channels, per_channel, x_dtype, qmax, use_gs, gs):
+    """lsq_cpu_sharded_finish: (d_scale, d_shift) from the all-reduced [sum ds (C), sum db (C), element count] (see
+    _hip_host.hip_sharded_finish)."""
+    lib = _cpu_lib("lsq_sharded_finish")
+    _require_cpu("lsq_sharded_finish", packed)
+    _check(packed.dtype == torch.float64 and packed.is_contiguous() and packed.numel() == 2 * channels + 1,
+           "lsq_sharded_finish: packed must be a contiguous float64 tensor of 2 * channels + 1 elements")
+    pd = torch.float64 if x_dtype == torch.float64 else torch.float32
+    ds, db = torch.empty(channels, dtype=pd), torch.empty(channels, dtype=pd)
+    _, pref = _params(0, qmax, 0, qmax, use_gs, gs, False, False, False)
+    rc = lib.lsq_cpu_sharded_finish(_DTYPE_CODE[x_dtype], packed.data_ptr(), channels, 1 if per_channel else 0, pref,
+                                    ds.data_ptr(), db.data_ptr())
+    _cpu_status(rc, "lsq_sharded_finish")
+    return ds, db
 
 
 def _cpu_minmax(x, axis=None):

@@ -275,15 +275,18 @@ def _aux_output(xd, levels_bias, want_mask):
 
 
 def hip_forward_per_tensor(x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode,
-                           levels_bias=None, variant=0, want_mask=False):
+                           levels_bias=None, variant=0, want_mask=False, levels_only=False):
+    """levels_only (with levels_bias): y is not written at all (NULL in the C ABI) and only the int8 levels are returned."""
     _assert_has_ops()
     check_forward_dtypes(x, scale, shift)
     _require_gpu("lsq_forward_per_tensor", x, scale, shift)
     xd, _ = _dense(x)
-    y = torch.empty_like(xd)
+    y = None if levels_only else torch.empty_like(xd)
     n = xd.numel()
     has_aux = levels_bias is not None or want_mask
     if n == 0:
+        if levels_only:
+            return torch.empty(x.shape, dtype=torch.int8, device=x.device)
         return (y, torch.empty(x.shape, dtype=torch.int8, device=x.device)) if has_aux else y
     _require_param("lsq_forward_per_tensor", scale, shift)
     lv, ex = _aux_output(xd, levels_bias, want_mask)
@@ -291,19 +294,33 @@ def hip_forward_per_tensor(x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, 
     scale_c, shift_c = scale.contiguous(), shift.contiguous()
     idx = x.device.index
     fn, tail = _entry("lsq_hip_forward_per_tensor", variant)
-    rc = _on_device(idx, fn, _DTYPE_CODE[x.dtype], xd.data_ptr(), y.data_ptr(), n,
+    rc = _on_device(idx, fn, _DTYPE_CODE[x.dtype], xd.data_ptr(), None if levels_only else y.data_ptr(), n,
                     scale_c.data_ptr(), shift_c.data_ptr(), pref, ex, _stream_of(idx), *tail)
     if rc:
         _status(rc, "lsq_hip_forward_per_tensor")
+    if levels_only:
+        return lv
     return (y, lv) if has_aux else y
 
 
+def _wide_buffer(wide_out, slots, dev):
+    """the caller's buffer for the un-rounded fp64 sums (the sharded path packs the element count behind them) or a new one"""
+    if wide_out is None:
+        return torch.empty(slots, dtype=torch.float64, device=dev)
+    _check(wide_out.dtype == torch.float64 and wide_out.is_contiguous() and wide_out.numel() >= slots and wide_out.device == dev,
+           "wide_out must be a contiguous float64 tensor of at least %d elements on %s" % (slots, dev))
+    return wide_out
+
+
 def hip_backward_per_tensor(grad, x, scale, shift, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode,
-                            numel_for_scaler=0, want_wide=False, variant=0, use_ticket=None):
+                            numel_for_scaler=0, want_wide=False, variant=0, use_ticket=None, wide_out=None):
     _assert_has_ops()
     check_backward_dtypes(grad, x, scale, shift)
     if x.numel() <= 0:  # lsq_cpu.cpp:76-78 returns (x, scale, shift) themselves
         if want_wide:
+            if wide_out is not None:
+                wide_out[:2].zero_()
+                return x.clone(), wide_out
             return x.clone(), torch.zeros(2, dtype=torch.float64, device=x.device)
         return x.clone(), scale.clone(), shift.clone()
     _require_gpu("lsq_backward_per_tensor", x, grad, scale, shift)
@@ -315,7 +332,7 @@ def hip_backward_per_tensor(grad, x, scale, shift, qmin, qmax, tmin, tmax, use_g
     dev = x.device
     ds = torch.empty(1, dtype=pd, device=dev)
     db = torch.empty(1, dtype=pd, device=dev)
-    wide = torch.empty(2, dtype=torch.float64, device=dev) if want_wide else None
+    wide = _wide_buffer(wide_out, 2, dev) if want_wide else None
     _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode, numel_for_scaler)
     code = _DTYPE_CODE[x.dtype]
     scale_c, shift_c = scale.contiguous(), shift.contiguous()
@@ -339,15 +356,17 @@ def hip_backward_per_tensor(grad, x, scale, shift, qmin, qmax, tmin, tmax, use_g
 
 
 def hip_forward_per_channel(x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode,
-                            levels_bias=None, variant=0, want_mask=False):
+                            levels_bias=None, variant=0, want_mask=False, levels_only=False):
     _assert_has_ops()
     check_forward_dtypes(x, scale, shift)
     check_channel_args(x, scale, shift, axis, backward=False)
     _require_gpu("lsq_forward_per_channel", x, scale, shift)
     xd, order = _dense(x)
-    y = torch.empty_like(xd)
+    y = None if levels_only else torch.empty_like(xd)
     has_aux = levels_bias is not None or want_mask
     if x.numel() == 0:
+        if levels_only:
+            return torch.empty(x.shape, dtype=torch.int8, device=x.device)
         return (y, torch.empty(x.shape, dtype=torch.int8, device=x.device)) if has_aux else y
     outer, C, inner = _ocl(xd, order, axis)
     lv, ex = _aux_output(xd, levels_bias, want_mask)
@@ -355,10 +374,12 @@ def hip_forward_per_channel(x, scale, shift, axis, qmin, qmax, tmin, tmax, use_g
     scale_c, shift_c = scale.contiguous(), shift.contiguous()
     idx = x.device.index
     fn, tail = _entry("lsq_hip_forward_per_channel", variant)
-    rc = _on_device(idx, fn, _DTYPE_CODE[x.dtype], xd.data_ptr(), y.data_ptr(), outer,
+    rc = _on_device(idx, fn, _DTYPE_CODE[x.dtype], xd.data_ptr(), None if levels_only else y.data_ptr(), outer,
                     C, inner, scale_c.data_ptr(), shift_c.data_ptr(), pref, ex, _stream_of(idx), *tail)
     if rc:
         _status(rc, "lsq_hip_forward_per_channel")
+    if levels_only:
+        return lv
     return (y, lv) if has_aux else y
 
 
@@ -393,12 +414,15 @@ _WS_BYTES_PC = {}
 
 
 def hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode,
-                             init_mode, numel_for_scaler=0, want_wide=False, variant=0, use_ticket=None):
+                             init_mode, numel_for_scaler=0, want_wide=False, variant=0, use_ticket=None, wide_out=None):
     _assert_has_ops()
     check_backward_dtypes(grad, x, scale, shift)
     check_channel_args(x, scale, shift, axis, backward=True)
     if x.numel() <= 0:  # lsq_cpu.cpp:221-223
         if want_wide:
+            if wide_out is not None:
+                wide_out[:2 * scale.numel()].zero_()
+                return x.clone(), wide_out
             return x.clone(), torch.zeros(2, scale.numel(), dtype=torch.float64, device=x.device)
         return x.clone(), scale.clone(), shift.clone()
     _require_gpu("lsq_backward_per_channel", x, grad, scale, shift)
@@ -411,7 +435,8 @@ def hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax
     idx = dev.index
     ds = torch.empty(C, dtype=pd, device=dev)
     db = torch.empty(C, dtype=pd, device=dev)
-    wide = torch.empty(2, C, dtype=torch.float64, device=dev) if want_wide else None
+    wide = (_wide_buffer(wide_out, 2 * C, dev) if wide_out is not None else
+            torch.empty(2, C, dtype=torch.float64, device=dev)) if want_wide else None
     _, pref = _params(qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode, numel_for_scaler)
     code = _DTYPE_CODE[x.dtype]
     scale_c, shift_c = scale.contiguous(), shift.contiguous()
@@ -435,6 +460,26 @@ def hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax
     if want_wide:
         return dx, wide
     return dx, ds, db
+
+
+def hip_sharded_finish(packed, channels, per_channel, x_dtype, qmax, use_gs, gs):
+    """(d_scale, d_shift) from the all-reduced `packed` = [sum ds terms (C), sum db terms (C), element count] of the
+    batch-sharded backward: the gradient scaler from the GLOBAL count, derived on the device (lsq_hip_sharded_finish)."""
+    _assert_has_ops()
+    _require_gpu("lsq_sharded_finish", packed)
+    _check(packed.dtype == torch.float64 and packed.is_contiguous() and packed.numel() == 2 * channels + 1,
+           "lsq_sharded_finish: packed must be a contiguous float64 tensor of 2 * channels + 1 elements")
+    pd = torch.float64 if x_dtype == torch.float64 else torch.float32
+    dev = packed.device
+    ds = torch.empty(channels, dtype=pd, device=dev)
+    db = torch.empty(channels, dtype=pd, device=dev)
+    _, pref = _params(0, qmax, 0, qmax, use_gs, gs, False, False, False)
+    idx = dev.index
+    rc = _on_device(idx, _abi._LIB.lsq_hip_sharded_finish, _DTYPE_CODE[x_dtype], packed.data_ptr(), channels,
+                    1 if per_channel else 0, pref, ds.data_ptr(), db.data_ptr(), _stream_of(idx))
+    if rc:
+        _status(rc, "lsq_hip_sharded_finish")
+    return ds, db
 
 
 # ---- many per-channel quantizers in one launch (lsq_hip_*_per_channel_multi) ----------------------------------------------

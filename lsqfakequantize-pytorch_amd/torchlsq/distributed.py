@@ -23,15 +23,53 @@ def _world(group):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+COLLECTIVE = "collective"      # global_numel=COLLECTIVE: the element count travels in the all-reduce (uneven shards)
+
+
+def _finish(packed, channels, per_channel, x_dtype, qmax, use_gs, gs):
+    fn = _E.hip_sharded_finish if packed.is_cuda else _E.cpu_sharded_finish
+    return fn(packed, channels, per_channel, x_dtype, qmax, use_gs, gs)
+
+
+def _backward_counted(grad, x, scale, shift, quant_min, quant_max, type_min, type_max, axis, use_grad_scaling, grad_scaler,
+                      sym, is_perchannel, init_mode, group, ws):
+    """The sharded backward when no rank knows the global element count (include/lsq_hip.h, lsq_hip_sharded_finish): the local
+    kernel leaves its terms unscaled, the count rides in the last slot of the ONE all-reduced buffer, and the scaler is
+    derived from the summed count on the device -- no extra collective, no host synchronisation."""
+    C = scale.numel() if is_perchannel else 1
+    n_local = x.numel()
+    packed = torch.full((2 * C + 1,), float(n_local), dtype=torch.float64, device=x.device)   # slot 2C = this shard's count
+    if x.is_cuda:
+        if is_perchannel:
+            dx, _ = _E.hip_backward_per_channel(grad, x, scale, shift, axis, quant_min, quant_max, type_min, type_max, False,
+                                                1.0, sym, False, init_mode, want_wide=True, wide_out=packed)
+        else:
+            dx, _ = _E.hip_backward_per_tensor(grad, x, scale, shift, quant_min, quant_max, type_min, type_max, False, 1.0,
+                                               sym, False, init_mode, want_wide=True, wide_out=packed)
+    else:
+        dx, _ = _E.cpu_backward(grad, x, scale, shift, axis, is_perchannel, quant_min, quant_max, type_min, type_max, False,
+                                1.0, sym, False, init_mode, want_wide=True, wide_out=packed)
+    if ws > 1:
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    ds, db = _finish(packed, C, is_perchannel, x.dtype, quant_max, use_grad_scaling, grad_scaler)
+    return dx, ds, db
+
+
 def sharded_backward(grad, x, scale, shift, quant_min, quant_max, type_min, type_max, axis=1,
                      use_grad_scaling=True, grad_scaler=1.0, is_affine=True, is_perchannel=False,
                      eval_mode=False, init_mode=False, group=None, global_numel=None, async_op=False):
     """Local fused backward + the one all-reduce.  Returns (dx, ds, db[, work]).
 
-    `global_numel` defaults to local numel * world size (equal shards)."""
+    `global_numel`: None = local numel * world size (equal shards); an int = the caller knows it; COLLECTIVE = nobody
+    does (uneven shards): the count is summed in the same collective and the scaler derived from it on the device.
+    eval_mode: d_scale = d_shift = 0 (lsq_kernel.h:142-144), so nothing is communicated."""
     ws = _world(group)
-    n4s = int(global_numel) if global_numel is not None else x.numel() * ws
     sym = not is_affine
+    if global_numel == COLLECTIVE and not eval_mode:
+        assert not async_op, "async_op is not available with global_numel=COLLECTIVE"
+        return _backward_counted(grad, x, scale, shift, quant_min, quant_max, type_min, type_max, axis, use_grad_scaling,
+                                 grad_scaler, sym, is_perchannel, init_mode, group, ws)
+    n4s = x.numel() * ws if global_numel is None or global_numel == COLLECTIVE else int(global_numel)
     # GPU tensors go through the C++ host binding when it is loaded (same C ABI, same kernels; ~4x less host time per
     # call than the Python-registered op, which matters when a rank's shard is only tens of microseconds of GPU work)
     ops = torch.ops.torchlsq_native if (x.is_cuda and _E._NATIVE_LSQ is not None) else torch.ops.torchlsq
@@ -43,7 +81,7 @@ def sharded_backward(grad, x, scale, shift, quant_min, quant_max, type_min, type
         dx, wide = ops.lsq_backward_per_tensor_wide(grad, x, scale, shift, quant_min, quant_max, type_min, type_max,
                                                     use_grad_scaling, grad_scaler, sym, eval_mode, init_mode, n4s)
     work = None
-    if ws > 1:
+    if ws > 1 and not eval_mode:
         work = dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     pd = _param_dtype(x)
     if async_op and work is not None:
@@ -84,6 +122,9 @@ def lsq_sharded(x, scale, shift, quant_min=0, quant_max=255, type_min=None, type
 
     scale/shift are replicated; their gradients come back already summed over all ranks and equal
     (to the 1e-6 parity budget) the gradients of the unsharded op on the concatenated tensor.
+    `global_numel`: the element count of the whole batch for the gradient scaler -- None: local numel x world size (equal
+    shards); an int; or `COLLECTIVE` ("collective"): shards may be uneven or empty and no rank knows the total, so the
+    count is summed in the same all-reduce (one collective per backward either way).
     Per-channel quantisation along the sharded dim itself (axis 0) needs no collective and is not
     handled here -- use the plain op on each shard."""
     _assert_has_ops()
@@ -103,3 +144,14 @@ def lsq_sharded(x, scale, shift, quant_min=0, quant_max=255, type_min=None, type
     cfg = (quant_min, quant_max, type_min, type_max, axis, use_grad_scaling, grad_scaler, is_affine, is_perchannel,
            eval_mode, init_mode, group, global_numel)
     return _ShardedLSQ.apply(x, scale, shift, cfg)
+
+
+def all_reduce_minmax(cur_min, cur_max, group=None):
+    """Batch min / max over all ranks in ONE collective: [min, -max] packed, all-reduce(MIN).  What the observer-driven
+    initialisation of a replicated quantizer needs so that every rank derives the same scale / shift from the whole batch
+    (reference quantized/modules/observers.py:446-449 sees the whole batch on its one device).  Returns new tensors."""
+    n = cur_min.numel()
+    packed = torch.cat([cur_min.reshape(-1), -cur_max.reshape(-1)])
+    if _world(group) > 1:
+        dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=group)
+    return packed[:n].reshape(cur_min.shape), (-packed[n:]).reshape(cur_max.shape)

@@ -28,8 +28,8 @@ from ._hip_host import (_SINGLE_LAUNCH_BWD, _TICKET_SLABS, _TICKETS, _WS_BYTES_P
                         _like_layout, _ocl, _param_dtype, _params, _physical_order, _ROW_MAJOR, hip_backward_from_mask,
                         hip_backward_per_channel, hip_backward_per_channel_multi, hip_backward_per_tensor,
                         hip_forward_per_channel, hip_forward_per_channel_multi, hip_forward_per_tensor, hip_meanstd,
-                        hip_minmax, hip_multi_eligible, hip_observer_update, set_single_launch_backward)
-from ._cpu_host import _cpu_meanstd, _cpu_minmax, cpu_backward, cpu_forward  # noqa: F401
+                        hip_minmax, hip_multi_eligible, hip_observer_update, hip_sharded_finish, set_single_launch_backward)
+from ._cpu_host import _cpu_meanstd, _cpu_minmax, cpu_backward, cpu_forward, cpu_levels, cpu_sharded_finish  # noqa: F401
 
 
 def __getattr__(name):
@@ -76,6 +76,13 @@ _lib_def.define("lsq_quantize_per_tensor(Tensor x, Tensor scale, Tensor shift, i
                 "int type_min, int type_max, int level_bias) -> (Tensor, Tensor)")
 _lib_def.define("lsq_quantize_per_channel(Tensor x, Tensor scale, Tensor shift, int axis, int quant_min, "
                 "int quant_max, int type_min, int type_max, int level_bias) -> (Tensor, Tensor)")
+#  * `lsq_levels_*`: ONLY the int8 levels (y is not written: 5 instead of 9 bytes of traffic per fp32 element) -- the
+#    conversion-time pass behind `torchlsq.functional.lsq_quantize` / `LSQFakeQuantizer.quantize`, which wraps them into real
+#    torch.quint8 / torch.qint8 tensors.  The byte is (q - level_bias) mod 256 (include/lsq_hip.h, lsq_fwd_extras).
+_lib_def.define("lsq_levels_per_tensor(Tensor x, Tensor scale, Tensor shift, int quant_min, int quant_max, "
+                "int type_min, int type_max, int level_bias) -> Tensor")
+_lib_def.define("lsq_levels_per_channel(Tensor x, Tensor scale, Tensor shift, int axis, int quant_min, "
+                "int quant_max, int type_min, int type_max, int level_bias) -> Tensor")
 
 
 
@@ -138,7 +145,19 @@ def _impl_quantize_pc(x, scale, shift, axis, qmin, qmax, tmin, tmax, level_bias)
                                    levels_bias=level_bias)
 
 
+def _impl_levels_pt(x, scale, shift, qmin, qmax, tmin, tmax, level_bias):
+    return hip_forward_per_tensor(x, scale, shift, qmin, qmax, tmin, tmax, True, 1.0, False, False, False,
+                                  levels_bias=level_bias, levels_only=True)
+
+
+def _impl_levels_pc(x, scale, shift, axis, qmin, qmax, tmin, tmax, level_bias):
+    return hip_forward_per_channel(x, scale, shift, axis, qmin, qmax, tmin, tmax, True, 1.0, False, False, False,
+                                   levels_bias=level_bias, levels_only=True)
+
+
 _lib_hip = torch.library.Library("torchlsq", "IMPL", "CUDA")
+_lib_hip.impl("lsq_levels_per_tensor", _impl_levels_pt)
+_lib_hip.impl("lsq_levels_per_channel", _impl_levels_pc)
 _lib_hip.impl("lsq_forward_per_tensor", _impl_fwd_pt)
 _lib_hip.impl("lsq_backward_per_tensor", _impl_bwd_pt)
 _lib_hip.impl("lsq_forward_per_channel", _impl_fwd_pc)
@@ -165,6 +184,8 @@ _lib_cpu.impl("lsq_backward_per_tensor_wide",
               lambda g, x, s, b, *a: cpu_backward(g, x, s, b, 0, False, *a[:-1], numel_for_scaler=a[-1], want_wide=True))
 _lib_cpu.impl("lsq_backward_per_channel_wide",
               lambda g, x, s, b, axis, *a: cpu_backward(g, x, s, b, axis, True, *a[:-1], numel_for_scaler=a[-1], want_wide=True))
+_lib_cpu.impl("lsq_levels_per_tensor", lambda x, s, b, *a: cpu_levels(x, s, b, 0, False, *a))
+_lib_cpu.impl("lsq_levels_per_channel", lambda x, s, b, axis, *a: cpu_levels(x, s, b, axis, True, *a))
 _lib_cpu.impl("lsq_minmax_per_tensor", lambda x: _cpu_minmax(x))
 _lib_cpu.impl("lsq_minmax_per_channel", lambda x, axis: _cpu_minmax(x, axis))
 _lib_cpu.impl("lsq_meanstd_per_tensor", lambda x: _cpu_meanstd(x))
@@ -216,6 +237,16 @@ def _fake_quantize_pt(x, scale, shift, *a):
 @torch.library.register_fake("torchlsq::lsq_quantize_per_channel", lib=_lib_def)
 def _fake_quantize_pc(x, scale, shift, axis, *a):
     return _meta_like(x), torch.empty_like(x, dtype=torch.int8)
+
+
+@torch.library.register_fake("torchlsq::lsq_levels_per_tensor", lib=_lib_def)
+def _fake_levels_pt(x, scale, shift, *a):
+    return torch.empty_like(x, dtype=torch.int8)
+
+
+@torch.library.register_fake("torchlsq::lsq_levels_per_channel", lib=_lib_def)
+def _fake_levels_pc(x, scale, shift, axis, *a):
+    return torch.empty_like(x, dtype=torch.int8)
 
 
 @torch.library.register_fake("torchlsq::lsq_backward_from_mask", lib=_lib_def)

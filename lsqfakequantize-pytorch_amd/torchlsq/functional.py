@@ -178,6 +178,48 @@ def lsq(x: Tensor, scale: Tensor, shift: Tensor,
                                   eval_mode, init_mode)
 
 
+def lsq_quantize(x: Tensor, scale: Tensor, shift: Tensor,
+                 quant_min: int = 0,
+                 quant_max: int = 255,
+                 type_min: int = None,
+                 type_max: int = None,
+                 axis: int = 1,
+                 is_perchannel: bool = False,
+                 dtype=torch.quint8) -> Tensor:
+    """The REAL quantized tensor behind `lsq`'s fake-quantized output (an addition of this build): a `torch.quint8` /
+    `torch.qint8` tensor whose integer representation holds the levels x_q of the forward (lsq_kernel.h:13) and whose
+    quantizer carries s = max(|scale|, eps) and the integer zero point zp = round(clamp(-shift / s, type_min, type_max)) the
+    kernels use -- so `lsq_quantize(...).dequantize()` equals `lsq(...)` bit for bit ((x_q - zp) * s, the same two
+    operations).  One pass that reads x and writes ONE byte per element (no fake-quantized output: 5 instead of 9 bytes per
+    fp32 element on the GPU).  The step after the path: reference quantized/modules/observers.py:378-422 hands scale and
+    zero_point to torch's converter, which quantizes again with its own rounding; here the trained quantizer emits them.
+    """
+    _assert_has_ops()
+    assert dtype in (torch.quint8, torch.qint8), "dtype must be torch.quint8 or torch.qint8"
+    type_min = quant_min if type_min is None else type_min
+    type_max = quant_max if type_max is None else type_max
+    lo, hi = (0, 255) if dtype == torch.quint8 else (-128, 127)
+    assert lo <= quant_min <= quant_max <= hi, "the quantized range must fit the quantized type"
+    if scale.dim() != 1 or shift.dim() != 1:
+        raise RuntimeError("scale and shift should be 1-D tensors, even in per tensor case(please, avoid torch.Scalar too)")
+    x, scale, shift = x.detach(), scale.detach(), shift.detach()
+    if is_perchannel:
+        size = max(scale.size(0), shift.size(0))
+        scale = scale if scale.size(0) == size else scale.repeat(size)
+        shift = shift if shift.size(0) == size else shift.repeat(size)
+        levels = torch.ops.torchlsq.lsq_levels_per_channel(x, scale, shift, axis, quant_min, quant_max, type_min, type_max, 0)
+    else:
+        levels = torch.ops.torchlsq.lsq_levels_per_tensor(x, scale, shift, quant_min, quant_max, type_min, type_max, 0)
+    # the quantizer's constants exactly as the kernels derive them (lsq_cpu.cpp:44-47 / lsq_kernel.h:157-158,12): |scale|
+    # floored at eps, the zero point from -shift * (1 / s), clamped to the type's range, rounded half to even
+    s = scale.abs().clamp_min(torch.finfo(scale.dtype).eps)
+    zp = torch.fmin(torch.full_like(s, type_max), torch.fmax(torch.full_like(s, type_min), -shift * (1.0 / s))).round()
+    int_repr = levels.view(torch.uint8) if dtype == torch.quint8 else levels        # the byte is q mod 256 either way
+    if is_perchannel:
+        return torch._make_per_channel_quantized_tensor(int_repr, s.to(torch.float64), zp.to(torch.int64), axis)
+    return torch._make_per_tensor_quantized_tensor(int_repr, float(s[0]), int(zp[0]))
+
+
 class _LSQForeach(torch.autograd.Function):
     """N per-channel quantizers as ONE autograd node over the multi-tensor kernels (lsq_hip_*_per_channel_multi): one launch
     per 32 tensors each way instead of N.  Same arithmetic and summation order as N `lsq` calls (bit-identical outputs and

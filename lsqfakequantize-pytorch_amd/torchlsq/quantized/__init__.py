@@ -41,4 +41,44 @@ for _name, _method, _dtype in _TABLE:
     globals()[_name] = _switch(_name, _method, _dtype)
 del _name, _method, _dtype
 
-__all__ = ["LSQFakeQuantizer", "LSQWeightGroup"] + [row[0] for row in _TABLE]
+
+
+def enable_rank_sync(model, process_group=None, grads="mean"):
+    """Data-parallel QAT: make every activation quantizer of `model` ONE quantizer over the batch that is sharded across the
+    ranks of `process_group` (`LSQFakeQuantizer.enable_rank_sync`: observer statistics all-reduced during the init batches,
+    one all-reduce of the scale / shift gradient sums per backward, replicas bit-identical).  Weight quantizers see replicated
+    tensors and are left alone.  Returns the quantizers that were switched."""
+    switched = []
+    for mod in model.modules():
+        if isinstance(mod, LSQFakeQuantizer) and mod.dtype == torch.quint8 and not mod.debug_mode:
+            mod.enable_rank_sync(process_group, grads=grads)
+            switched.append(mod)
+    return switched
+
+
+def prepare_ddp(model, process_group=None, grads="mean"):
+    """`enable_rank_sync(model)` + tell DistributedDataParallel what it need not touch.  Call it on the prepared QAT model
+    BEFORE wrapping it: `model = DDP(prepare_ddp(model), ...)`.
+
+    DDP broadcasts every buffer from rank 0 at each forward (broadcast_buffers=True); for this module that is four state
+    flags per quantizer, written in place -- which the module has to treat as an out-of-band write and re-read from the
+    device (a host synchronisation per quantizer and step).  The flags evolve identically on every rank by construction, the
+    synchronised observers' min / max too, and the synchronised quantizers' scale.grad / shift.grad arrive already reduced,
+    so all of them go on the model's `_ddp_params_and_buffers_to_ignore` list.  (Parameters the quantizers create at their
+    first call are only known to a DDP built AFTER that call -- as with the reference module, run one batch first.)"""
+    synced = set(id(m) for m in enable_rank_sync(model, process_group, grads))
+    ignore = list(getattr(model, "_ddp_params_and_buffers_to_ignore", []))
+    for name, mod in model.named_modules():
+        if not isinstance(mod, LSQFakeQuantizer):
+            continue
+        prefix = name + "." if name else ""
+        ignore += [prefix + b for b in ("fake_quant_enabled", "observer_enabled", "learning_enabled", "current_batch")]
+        if id(mod) in synced:
+            ignore += [prefix + "scale", prefix + "shift"]
+            if mod.activation_post_process is not None:
+                ignore += [prefix + "activation_post_process." + b for b, _ in mod.activation_post_process.named_buffers()]
+    model._ddp_params_and_buffers_to_ignore = sorted(set(ignore))
+    return model
+
+
+__all__ = ["LSQFakeQuantizer", "LSQWeightGroup", "enable_rank_sync", "prepare_ddp"] + [row[0] for row in _TABLE]

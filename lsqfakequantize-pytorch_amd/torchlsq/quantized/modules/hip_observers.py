@@ -33,26 +33,41 @@ def _fast(x, buf):
     return buf.dtype == want
 
 
-def _fused_step(obs, x, scale_param, shift_param, mode, per_channel):
-    """statistics pass + one update launch; False when the stock path must be taken instead"""
+def _fused_step(obs, x, scale_param, shift_param, mode, per_channel, group=None, synced=False):
+    """statistics pass + one update launch; False when the stock path must be taken instead.
+    synced: the batch is sharded over the ranks of `group` -- the batch min / max of all ranks are combined in ONE packed
+    collective between the two launches (torchlsq.distributed.all_reduce_minmax), so every rank writes the same scale / shift;
+    an empty local shard contributes (+inf, -inf)."""
     from torchlsq import extension as E
-    if not (_fast(x, obs.min_val) and obs.min_val.dtype == torch.float32 and scale_param.dtype == torch.float32
+    empty = synced and x.numel() == 0 and x.is_cuda and x.dtype in _FAST_DTYPES
+    if not ((empty or _fast(x, obs.min_val)) and obs.min_val.dtype == torch.float32 and scale_param.dtype == torch.float32
             and obs.qscheme in (torch.per_tensor_affine, torch.per_tensor_symmetric, torch.per_channel_affine,
                                 torch.per_channel_symmetric)):
         return False
     n = x.shape[obs.ch_axis] if per_channel else 1
     if scale_param.numel() != n or shift_param.numel() != n or not (scale_param.is_cuda and shift_param.is_cuda):
         return False
+    if empty:
+        cur_min = torch.full((n,), float("inf"), dtype=torch.float32, device=x.device)
+        cur_max = -cur_min
     if per_channel:
-        cur_min, cur_max = torch.ops.torchlsq.lsq_minmax_per_channel(x.detach(), obs.ch_axis)
+        if not empty:
+            cur_min, cur_max = torch.ops.torchlsq.lsq_minmax_per_channel(x.detach(), obs.ch_axis)
+        if synced:
+            from torchlsq.distributed import all_reduce_minmax
+            cur_min, cur_max = all_reduce_minmax(cur_min, cur_max, group)
         first = 0
         if obs.min_val.numel() == 0 or obs.max_val.numel() == 0:      # host-side fact: the buffers are still empty
             obs.min_val.resize_(cur_min.shape)
             obs.max_val.resize_(cur_max.shape)
             first = 1
     else:
-        cur_min, cur_max = torch.ops.torchlsq.lsq_minmax_per_tensor(x.detach())
-        cur_min, cur_max = cur_min.reshape(1), cur_max.reshape(1)
+        if not empty:
+            cur_min, cur_max = torch.ops.torchlsq.lsq_minmax_per_tensor(x.detach())
+            cur_min, cur_max = cur_min.reshape(1), cur_max.reshape(1)
+        if synced:
+            from torchlsq.distributed import all_reduce_minmax
+            cur_min, cur_max = all_reduce_minmax(cur_min, cur_max, group)
         first = -1                                                     # +inf / -inf state: decided on the device
     eps = getattr(obs, "_lsq_eps", None)
     if eps is None:                                                    # read the observer's eps buffer once
@@ -69,8 +84,8 @@ def _fused_step(obs, x, scale_param, shift_param, mode, per_channel):
 
 
 class HipMinMaxObserver(MinMaxObserver):
-    def lsq_fused_step(self, x, scale_param, shift_param):
-        return _fused_step(self, x, scale_param, shift_param, 1, False)
+    def lsq_fused_step(self, x, scale_param, shift_param, group=None, synced=False):
+        return _fused_step(self, x, scale_param, shift_param, 1, False, group, synced)
 
     def forward(self, x_orig):
         if not _fast(x_orig, self.min_val):
@@ -82,8 +97,8 @@ class HipMinMaxObserver(MinMaxObserver):
 
 
 class HipMovingAverageMinMaxObserver(MovingAverageMinMaxObserver):
-    def lsq_fused_step(self, x, scale_param, shift_param):
-        return _fused_step(self, x, scale_param, shift_param, 2, False)
+    def lsq_fused_step(self, x, scale_param, shift_param, group=None, synced=False):
+        return _fused_step(self, x, scale_param, shift_param, 2, False, group, synced)
 
     def forward(self, x_orig):
         if not _fast(x_orig, self.min_val):
@@ -101,8 +116,8 @@ class HipMovingAverageMinMaxObserver(MovingAverageMinMaxObserver):
 
 
 class HipPerChannelMinMaxObserver(PerChannelMinMaxObserver):
-    def lsq_fused_step(self, x, scale_param, shift_param):
-        return _fused_step(self, x, scale_param, shift_param, 1, True)
+    def lsq_fused_step(self, x, scale_param, shift_param, group=None, synced=False):
+        return _fused_step(self, x, scale_param, shift_param, 1, True, group, synced)
 
     def _forward(self, x_orig):
         if not _fast(x_orig, self.min_val):
@@ -122,8 +137,8 @@ class HipPerChannelMinMaxObserver(PerChannelMinMaxObserver):
 
 
 class HipMovingAveragePerChannelMinMaxObserver(MovingAveragePerChannelMinMaxObserver):
-    def lsq_fused_step(self, x, scale_param, shift_param):
-        return _fused_step(self, x, scale_param, shift_param, 2, True)
+    def lsq_fused_step(self, x, scale_param, shift_param, group=None, synced=False):
+        return _fused_step(self, x, scale_param, shift_param, 2, True, group, synced)
 
     def forward(self, x_orig):
         if not _fast(x_orig, self.min_val):

@@ -18,6 +18,10 @@ module's back (`m.fake_quant_enabled[0] = 0`, `.fill_()`, `.copy_()`, a broadcas
 what it last saw, so such writes are honoured at the next call like in the reference, at the price of one
 re-read (a synchronisation) per out-of-band write, never in the steady state.
 
+Multi-GPU (an addition of this build; the reference has no distributed code): with `sync=True` (or `process_group=`, or
+`enable_rank_sync()`) a quantizer whose input is the rank's shard of the batch -- every activation quantizer of a
+data-parallel model -- behaves as ONE quantizer over the whole batch: see `enable_rank_sync`.
+
 Two deliberate differences from the reference, both turning a crash into the documented behaviour:
   * `LSQFakeQuantizer.with_args(...)` works (the reference calls `partial` without importing it,
     observers.py:64);
@@ -99,6 +103,25 @@ def _flag(value):
     return torch.tensor([int(value)], dtype=torch.uint8)
 
 
+class _GroupRef(object):
+    """Holds the process group of a rank-synchronised quantizer.  A ProcessGroup can neither be deep-copied nor pickled, and
+    nn.Module does both with its attributes (copy.deepcopy(model), torch.save(model)): a copy shares the group, a pickle
+    comes back meaning the default group."""
+    def __init__(self, group=None):
+        self.group = group
+
+    def __deepcopy__(self, memo):
+        return self
+
+    def __reduce__(self):
+        return (_GroupRef, ())
+
+
+def _dist_world(group):
+    import torch.distributed as dist
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
 class LSQFakeQuantizer(ObserverBase):
     """Fake quantizer with Learned Step Size Quantization (LSQ+, arXiv:2004.09576).
 
@@ -133,6 +156,7 @@ class LSQFakeQuantizer(ObserverBase):
         use_grad_scaling, grad_scaler: gradient scaling of the parameters.
         avoid_torch_overflow: use 7-bit default ranges / reduce_range in the observer.
         debug_mode: forward is the identity.
+        sync, process_group, sync_grads (this build): see `enable_rank_sync`; `process_group` alone implies sync=True.
     """
     init_modes = ('learnable', 'observer')
     fuse_observer_tail = True     # observer-driven init batches on the GPU: one launch after the statistics pass
@@ -149,7 +173,8 @@ class LSQFakeQuantizer(ObserverBase):
                  ch_axis=None, learn_params=True,
                  init_batches=1000, init_mode='observer',
                  use_grad_scaling=True, grad_scaler=1.,
-                 avoid_torch_overflow=True, debug_mode=False, **observer_kwargs):
+                 avoid_torch_overflow=True, debug_mode=False, sync=False, process_group=None, sync_grads='sum',
+                 **observer_kwargs):
         super().__init__(dtype)
         assert init_mode in self.init_modes, f'only following modes available: {("learnable", "observer")}'
         assert otype in OTYPES, f'otype must be on of {tuple(OTYPES.keys())}, but {otype} is given'
@@ -189,6 +214,84 @@ class LSQFakeQuantizer(ObserverBase):
         self.init_shift = init_shift
         self.quant_min, self.quant_max = self._verify_qmin_qmax(quant_min, quant_max, lowbit=avoid_torch_overflow)
         self.reset(learn_params=learn_params)
+        self._sync = False
+        self._sync_grads = 'sum'
+        self._group_ref = _GroupRef(None)
+        if sync or process_group is not None:
+            self.enable_rank_sync(process_group, grads=sync_grads)
+
+    # ---- one quantizer over a batch that is sharded across ranks (this build) ---------------------------------------
+    def enable_rank_sync(self, process_group=None, grads='sum'):
+        """Treat the input as this rank's shard (dim 0) of a batch spread over the ranks of `process_group` (None = the
+        default group) and behave like the reference module on the WHOLE batch (quantized/modules/observers.py:424-462 on
+        the concatenation of the shards), with replicated `scale` / `shift` that stay bit-identical on every rank:
+          * observer-driven init batches: the batch min / max are all-reduced in ONE packed collective ([min, -max], MIN)
+            before the observer's running state, the qparams and scale / shift are updated -- without it every rank
+            overwrites its replica from rank-local statistics and the replicas diverge for good (DDP never re-synchronises
+            parameters, only gradients);
+          * LSQ steps ('learnable' init batches included): `torchlsq.distributed.lsq_sharded` -- ONE all-reduce of the fp64
+            [sum d_scale terms, sum d_shift terms, element count] per backward, the gradient scaler from the global element
+            count (lsq_cpu.cpp:103,250), so shards may be uneven or empty; scale.grad / shift.grad arrive already reduced
+            and identical on every rank.
+        `grads`: 'sum' = the gradients of the reference on the concatenated batch for the same upstream gradients;
+        'mean' = that divided by the world size, DistributedDataParallel's convention (it averages every other parameter's
+        gradient; DDP may average these again -- they are equal on all ranks, so that changes nothing -- or skip them:
+        `torchlsq.quantized.prepare_ddp`).  Weight quantizers see replicated tensors and need none of this: on them the
+        switch is accepted and does nothing.  No-op while torch.distributed is not initialised or the group has one rank."""
+        assert grads in ('sum', 'mean'), "grads must be 'sum' or 'mean'"
+        if self.otype != OTYPES['weight']:
+            assert not (self.is_perchannel and self.ch_axis == 0), \
+                'rank sync shards dim 0 (the batch): a per-channel quantizer along dim 0 has nothing to synchronise'
+            obs = self.activation_post_process
+            if obs is not None:
+                from torch.ao.quantization.observer import MinMaxObserver, PerChannelMinMaxObserver
+                assert isinstance(obs, (MinMaxObserver, PerChannelMinMaxObserver)), \
+                    'rank sync needs an observer of the MinMax family (its state is a function of the batch min / max)'
+        self._sync = True
+        self._sync_grads = grads
+        self._group_ref = _GroupRef(process_group)
+
+    def disable_rank_sync(self):
+        self._sync = False
+
+    def _sync_world(self):
+        """ranks this call synchronises with (1 = none): only quantizers of batch-sharded inputs, only inside a job"""
+        if not self._sync or self.otype == OTYPES['weight']:
+            return 1
+        return _dist_world(self._group_ref.group)
+
+    def _observe_synced(self, x, obs):
+        """One observer step on the batch statistics of ALL ranks (see enable_rank_sync)."""
+        group = self._group_ref.group
+        fused = getattr(obs, 'lsq_fused_step', None) if self.fuse_observer_tail else None
+        if fused is not None and fused(x, self.scale, self.shift, group=group, synced=True):
+            return
+        from torchlsq.distributed import all_reduce_minmax
+        from torch.ao.quantization.observer import PerChannelMinMaxObserver
+        per_channel = isinstance(obs, PerChannelMinMaxObserver)
+        stat_dtype = obs.min_val.dtype
+        if per_channel:
+            n = x.shape[obs.ch_axis]
+            if x.numel() > 0:
+                cur_min, cur_max = torch.ops.torchlsq.lsq_minmax_per_channel(x, obs.ch_axis)
+            else:
+                cur_min = torch.full((n,), float('inf'), dtype=stat_dtype, device=x.device)
+                cur_max = -cur_min
+        elif x.numel() > 0:
+            cur_min, cur_max = (t.reshape(1) for t in torch.ops.torchlsq.lsq_minmax_per_tensor(x))
+        else:
+            cur_min = torch.full((1,), float('inf'), dtype=stat_dtype, device=x.device)
+            cur_max = -cur_min
+        gmin, gmax = all_reduce_minmax(cur_min.to(stat_dtype), cur_max.to(stat_dtype), group)
+        # the stock observer only ever looks at its input through aminmax: a two-element-per-channel stand-in with the
+        # global extremes drives its own update rule (running / moving average) exactly as the whole batch would
+        if per_channel:
+            stand_in = torch.stack([gmin, gmax]).reshape([2] + [1] * (obs.ch_axis - 1) + [gmin.numel()])
+        else:
+            stand_in = torch.cat([gmin, gmax])
+        obs(stand_in)
+        scale, zero_point = obs.calculate_qparams()
+        self._set_weights(scale=scale, zero_point=zero_point)
 
     # ---- range bookkeeping ---------------------------------------------------------------------
     def _verify_qmin_qmax(self, quant_min: int, quant_max: int, lowbit=True) -> Tuple[int, int]:
@@ -383,6 +486,19 @@ class LSQFakeQuantizer(ObserverBase):
         zero_point = self.convert_shift_to_zp(shift, scale, self.dtype)
         return (scale, shift, zero_point) if need_shift else (scale, zero_point)
 
+    def quantize(self, x):
+        """`x` as a REAL quantized tensor (torch.quint8 / torch.qint8, per tensor or per channel) with this trained
+        quantizer's levels and constants: `m.quantize(x).dequantize()` is `m(x)` in its steady state, bit for bit
+        (`torchlsq.functional.lsq_quantize`; one pass writing one byte per element).  Note `calculate_qparams()` keeps the
+        reference's formulas (max(scale, eps), round(-shift / scale)); the kernels -- and therefore this method -- use
+        max(|scale|, eps) and round(clamp(-shift * (1 / s))), which differ from them only for a negative scale or when
+        -shift / s sits within an ulp of a rounding tie."""
+        from torchlsq.functional import lsq_quantize
+        assert self._initialized and self.scale is not None, "run the module on at least one batch before quantize()"
+        tmin, tmax = TYPES_RANGE_MAPPING[self.dtype]['range']
+        return lsq_quantize(x, self.scale, self.shift, quant_min=self.quant_min, quant_max=self.quant_max, type_min=tmin,
+                            type_max=tmax, axis=self.ch_axis, is_perchannel=self.is_perchannel, dtype=self.dtype)
+
     # ---- the caller of the hot path ------------------------------------------------------------
     _prefetched = None      # (weight tensor, its fake-quantized value) stashed by LSQWeightGroup.prequantize()
 
@@ -416,12 +532,15 @@ class LSQFakeQuantizer(ObserverBase):
             h['batch'] += 1
             self._stamp = self._buffer_stamp()
 
+        sync_ws = self._sync_world()
         if h['observer'] == 1:
             obs = self.activation_post_process
             fused = getattr(obs, 'lsq_fused_step', None) if self.fuse_observer_tail else None
             # GPU fast path: statistics pass + ONE launch that updates the observer state, derives the qparams and
             # writes scale / shift, nothing read back to the host (hip_observers.py); otherwise the reference sequence
-            if fused is None or not fused(x.detach(), self.scale, self.shift):
+            if sync_ws > 1:
+                self._observe_synced(x.detach(), obs)
+            elif fused is None or not fused(x.detach(), self.scale, self.shift):
                 obs(x.detach())
                 scale, zero_point = obs.calculate_qparams()
                 self._set_weights(scale=scale, zero_point=zero_point)
@@ -435,6 +554,15 @@ class LSQFakeQuantizer(ObserverBase):
             # before the first one's backward changes what the reference's eval backward sees (it recomputes the mask
             # from the saved x and the then-current parameters, lsq_autograd.cpp:46-73): keep that behaviour there
             # (save x); once the parameters are only changed by the optimizer, the one-byte saved mask is equivalent.
+            if sync_ws > 1 and full_lsq:
+                # the input is this rank's shard of the batch: one all-reduce per backward, scaler from the global count
+                from torchlsq.distributed import COLLECTIVE, lsq_sharded
+                gs = self.grad_scaler / sync_ws if self._sync_grads == 'mean' else self.grad_scaler
+                return lsq_sharded(x, self.scale, self.shift, quant_min=self.quant_min, quant_max=self.quant_max,
+                                   type_min=tmin, type_max=tmax, axis=self.ch_axis, use_grad_scaling=self.use_grad_scaling,
+                                   grad_scaler=gs, is_affine=self.is_affine, is_perchannel=self.is_perchannel,
+                                   eval_mode=False, init_mode=backprop_init, group=self._group_ref.group,
+                                   global_numel=COLLECTIVE)
             return lsq(x, self.scale, self.shift, quant_min=self.quant_min, quant_max=self.quant_max,
                        type_min=tmin, type_max=tmax, axis=self.ch_axis, use_grad_scaling=self.use_grad_scaling,
                        grad_scaler=self.grad_scaler, is_affine=self.is_affine, is_perchannel=self.is_perchannel,

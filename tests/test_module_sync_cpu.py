@@ -1,0 +1,96 @@
+"""CPU, gloo: `LSQFakeQuantizer(sync=True)` -- one quantizer over a batch that is sharded across ranks.
+
+The reference module (quantized/modules/observers.py:424-462) sees the whole batch on one device.  With rank sync every rank
+feeds its shard and must end up exactly where the reference's trace of the WHOLE batch does: identical scale / shift on all
+ranks after every call (observer-driven init, 'learnable' init and LSQ steps), gradients within the parity budget, one
+collective per observer step and one per backward.  World 2 (equal shards) and world 4 with UNEVEN shards, one of them empty.
+Also: a small QAT model under DistributedDataParallel (`torchlsq.quantized.prepare_ddp`) against single-process training.
+"""
+import socket
+
+import pytest
+import torch.multiprocessing as mp
+
+import sync_workers
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(target, world, *args, timeout=300):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    problems = [msg for _, msgs in sorted(res) for msg in msgs]
+    assert not problems, "\n".join(problems[:12])
+
+
+def test_shard_bounds_helper():
+    assert sync_workers.shard_bounds(4, 2, False) == [0, 2, 4]
+    assert sync_workers.shard_bounds(4, 4, True) == [0, 2, 2, 3, 4]          # an empty shard
+    assert sync_workers.shard_bounds(3, 4, True) == [0, 2, 2, 2, 3]
+    assert sync_workers.shard_bounds(16, 4, True)[-1] == 16
+
+
+def test_synced_module_replays_the_reference_traces_world2():
+    _run(sync_workers.replay, 2, False, "cpu")
+
+
+def test_synced_module_replays_the_reference_traces_world4_uneven_shards():
+    _run(sync_workers.replay, 4, True, "cpu", timeout=420)
+
+
+def test_negative_control_without_sync_the_replicas_leave_the_reference_trace():
+    """the same replay with sync off must FAIL its checks (rank-local statistics and scalers): the test above has teeth"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=sync_workers.replay, args=(r, 2, port, False, "cpu", q, ("act_observer_pt", "act_learnable_pt"), False))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    problems = [msg for _, msgs in res for msg in msgs]
+    assert any("scale/shift differ from the reference trace" in m for m in problems)
+    assert any("grad" in m for m in problems)
+
+
+def test_ddp_replicas_stay_identical_and_follow_single_process_training():
+    _run(sync_workers.ddp_train, 2, "cpu")
+
+
+def test_sync_is_a_noop_outside_a_job_and_on_weights():
+    import torch
+    from torch.ao.quantization.observer import MovingAverageMinMaxObserver as Obs, HistogramObserver
+    from torchlsq.quantized import LSQFakeQuantizer as Q
+    a, b = Q(Obs, "activation", init_batches=1, sync=True), Q(Obs, "activation", init_batches=1)
+    x = torch.rand(4, 8) + 0.5
+    for _ in range(3):
+        ya, yb = a(x), b(x)
+    assert torch.equal(ya, yb) and a._sync_world() == 1
+    w = Q(None, "weight", dtype=torch.qint8, qscheme=torch.per_tensor_symmetric, init_mode="learnable", sync=True)
+    assert w._sync_world() == 1
+    with pytest.raises(AssertionError, match="MinMax family"):
+        Q(HistogramObserver, "activation", sync=True)
+    with pytest.raises(AssertionError, match="nothing to synchronise"):
+        Q(None, "activation", qscheme=torch.per_channel_affine, ch_axis=0, init_mode="learnable", sync=True)
+    import copy
+    import pickle
+    c = copy.deepcopy(a)
+    assert c._sync and c._group_ref is a._group_ref
+    assert pickle.loads(pickle.dumps(a._group_ref)).group is None
