@@ -59,6 +59,7 @@ WORKLOADS = {
     "cfg2": ("cfg2", "float32", None),
     "cfg3": ("cfg3", "float32", None),
     "cfg4": ("cfg4", "float32", None),
+    "cfg4_shard": ("cfg4", "float32", None),           # [128,1024,14,14]: one rank's share of config 4 at 8 GPUs
     "cfg5": ("cfg5", "float32", None),
     "cfg5_bf16": ("cfg5", "bfloat16", None),
     "cfg5_axis0": ("cfg5", "float32", 0),
@@ -69,6 +70,17 @@ WORKLOADS = {
 
 
 SECONDARY = ("cfg1", "cfg3", "cfg5", "cfg5_bf16")    # timed after the headline region of the default run
+# ... as (workload, how): eager single calls first, then what the small / sharded configs look like in the forms a model runs them
+SECONDARY_RUNS = tuple((w, {}) for w in SECONDARY) + (
+    ("cfg4_shard", {"shard_of": 8, "note": "BASELINE config 4's per-GPU shard [128,1024,14,14]: the step ONE rank of the 8-GPU job runs "
+                                           "(lsq_backward_per_tensor_wide with the global element count, fp64 sums rounded; no collective) -- "
+                                           "the 1-GPU denominator of the 8-GPU efficiency target"}),
+    ("cfg3", {"name": "cfg3_x50_foreach", "multi": 50,
+              "note": "50 x BASELINE config 3 ([512,512,3,3] qint8 weights) per step through the multi-tensor ops "
+                      "(lsq_hip_*_per_channel_multi: one launch per 32 tensors each way) -- a model's weight quantizers together"}),
+    ("cfg1", {"name": "cfg1_graph", "graph": True, "note": "BASELINE config 1 replayed from a HIP graph: the GPU-side rate of a host-bound size"}),
+    ("cfg3", {"name": "cfg3_graph", "graph": True, "note": "BASELINE config 3 replayed from a HIP graph"}),
+)
 
 
 def parse_args(argv=None):
@@ -96,6 +108,7 @@ def parse_args(argv=None):
                     help="replay the step from a HIP graph (GPU-side rate of latency-bound workloads; N = 1 only)")
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)            # "gloo" + --single-device: smoke-test
     ap.add_argument("--single-device", action="store_true", help=argparse.SUPPRESS)  # the N>1 control flow on a 1-GPU box
+    ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)     # tests: this rank raises before the timed region
     ap.add_argument("--variant-fwd", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--variant-bwd", type=int, default=0, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
@@ -124,19 +137,24 @@ def spawn_ranks(a):
                          % (a.gpus, visible))
         return 2
     port = _free_port()
-    procs = []
+    procs, errs = [], []
     for r in range(a.gpus):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this pool
         env.setdefault("OMP_NUM_THREADS", "1")
+        # every rank's stderr goes to its own scratch file (a pipe nobody drains would block a chatty rank): the tail of a
+        # failing rank's is shown below -- a traceback on rank 5 must not vanish
+        errs.append(tempfile.TemporaryFile(mode="w+", prefix="lsq_bench_rank%d_" % r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True if r == 0 else None))
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[r],
+                                      text=True if r == 0 else None))
     # a rank that dies early would leave the others waiting in the rendezvous: watch them all, stop the rest on a failure
     while all(p.poll() is None for p in procs):
         time.sleep(0.2)
-    if any(p.poll() not in (None, 0) for p in procs):
+    first_bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+    if first_bad:
         time.sleep(2.0)
         for p in procs:
             if p.poll() is None:
@@ -146,6 +164,14 @@ def spawn_ranks(a):
     sys.stdout.write(out0)
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    for r, f in enumerate(errs):
+        f.seek(0)
+        text = f.read()
+        f.close()
+        if r in first_bad:        # the rank(s) that failed on their own, not the ones stopped because of them
+            sys.stderr.write("bench.py: ---- rank %d exited with code %d; the end of its stderr ----\n%s\n" % (r, codes[r], text[-3000:]))
+        elif r == 0 and not bad and text.strip():
+            sys.stderr.write(text)
     if bad:
         sys.stderr.write("bench.py: rank exit codes %s\n" % bad)
         return 1
@@ -263,6 +289,8 @@ def run_rank(a):
         else:
             dist.init_process_group(backend=a.backend)
 
+    if a.fail_rank == rank:
+        raise RuntimeError("deliberate failure of rank %d (--fail-rank)" % rank)
     if a.variant_fwd or a.variant_bwd:      # launch variants: tools build of the library (tools/lsq_tools.py), ctypes host layer
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import lsq_tools
@@ -278,9 +306,12 @@ def run_rank(a):
     ops = torch.ops.torchlsq_native if binding == "native" else torch.ops.torchlsq
     ops_of = {"native": getattr(torch.ops, "torchlsq_native", None), "ctypes": torch.ops.torchlsq}
 
-    def measure(workload, steps, warmup, graph=False, buffers=0, ops=ops, warm_ms=0.0, extra_blocks=0):
+    def measure(workload, steps, warmup, graph=False, buffers=0, ops=ops, warm_ms=0.0, extra_blocks=0, shard_of=0, multi=0):
         """Time `steps` steps (forward op + backward op) of one workload after `warmup` untimed ones; returns the raw
-        measurements (K-step wall time bracketed by barrier + synchronize, max over ranks; per-op HIP-event times)."""
+        measurements (K-step wall time bracketed by barrier + synchronize, max over ranks; per-op HIP-event times).
+        shard_of = R (single rank only): the step ONE rank of an R-rank job runs on this shape -- the `*_wide` backward with
+        the global element count (R x local) in the gradient scaler and the rounding of the fp64 sums, no collective.
+        multi = M (per-channel weights): M tensors of the shape per step through the multi-tensor ops (one launch per 32)."""
         cfg_name, dtype_name, axis_override = WORKLOADS[workload]
         c = dict(synth.CONFIGS[cfg_name])
         if axis_override is not None:
@@ -294,6 +325,8 @@ def run_rank(a):
             assert shape[0] % world == 0
             shape[0] //= world
             scaling = "strong"
+        if workload == "cfg4_shard":     # one rank's share of config 4 at 8 GPUs, whatever this job's size
+            shape[0] //= 8
         if world > 1 and per_channel and c["axis"] == 0:
             raise SystemExit("workload %s quantises along dim 0, the sharded dim: a weight is replicated under data "
                              "parallelism, there is nothing to shard -- run it with --gpus 1" % workload)
@@ -306,15 +339,25 @@ def run_rank(a):
         # copies of (x, grad), more than 1 GiB of inputs in total.  Config 2 (2.4 GB per step) needs one set.
         set_bytes = 2 * n_local * esz
         n_sets = buffers if buffers > 0 else max(1, min(16, -(-(1 << 30) // set_bytes)))
-        xs, gs = [x], [g]
-        for _ in range(n_sets - 1):
-            xs.append(x.clone())
-            gs.append(g.clone())
+        if multi:
+            assert per_channel and world == 1 and not shard_of
+            set_bytes *= multi
+            n_sets = buffers if buffers > 0 else max(1, min(16, -(-(1 << 30) // set_bytes)))
+            xs = [[x] + [x.clone() for _ in range(multi - 1)] for _ in range(n_sets)]
+            gs = [[g] + [g.clone() for _ in range(multi - 1)] for _ in range(n_sets)]
+            scales, shifts, axes = [scale.clone() for _ in range(multi)], [shift.clone() for _ in range(multi)], [c["axis"]] * multi
+            n_local *= multi
+        else:
+            xs, gs = [x], [g]
+            for _ in range(n_sets - 1):
+                xs.append(x.clone())
+                gs.append(g.clone())
         cur = [0]
 
         def bset():       # the backward works on a set the forward touched n_sets / 2 steps ago: not on lines the forward just read
             return (cur[0] + n_sets // 2) % n_sets
         n_global = n_local * world
+        n_scaler = n_local * shard_of if shard_of else 0
         q = (c["qmin"], c["qmax"], c["tmin"], c["tmax"])
         sym = not c["affine"]
         axis = c["axis"]
@@ -324,7 +367,13 @@ def run_rank(a):
         op_fwd_pc, op_fwd_pt = ops.lsq_forward_per_channel.default, ops.lsq_forward_per_tensor.default
         op_bwd_pc, op_bwd_pt = ops.lsq_backward_per_channel.default, ops.lsq_backward_per_tensor.default
 
+        native_multi = multi and ops is getattr(torch.ops, "torchlsq_native", None)
+
         def fwd():
+            if multi:
+                if native_multi:
+                    return ops.lsq_forward_per_channel_multi(xs[cur[0]], scales, shifts, axes, *tail)
+                return extension.hip_forward_per_channel_multi(xs[cur[0]], scales, shifts, axes, *tail)
             if a.variant_fwd:
                 if per_channel:
                     return extension.hip_forward_per_channel(xs[cur[0]], scale, shift, axis, *tail, variant=a.variant_fwd)
@@ -336,6 +385,16 @@ def run_rank(a):
         pending = []   # N > 1: the previous step's in-flight all-reduce (RCCL runs it on its own stream)
 
         def bwd():
+            if multi:
+                if native_multi:
+                    return ops.lsq_backward_per_channel_multi(gs[bset()], xs[bset()], scales, shifts, axes, *tail)
+                return extension.hip_backward_per_channel_multi(gs[bset()], xs[bset()], scales, shifts, axes, *tail)
+            if shard_of:        # one rank's step of a shard_of-rank job: everything but the collective itself
+                if per_channel:
+                    dx, wide = ops.lsq_backward_per_channel_wide(gs[bset()], xs[bset()], scale, shift, axis, *tail, n_scaler)
+                else:
+                    dx, wide = ops.lsq_backward_per_tensor_wide(gs[bset()], xs[bset()], scale, shift, *tail, n_scaler)
+                return dx, wide.to(torch.float32)
             if world == 1:
                 if a.variant_bwd:
                     if per_channel:
@@ -485,7 +544,7 @@ def run_rank(a):
         return dict(workload=workload, c=c, dtype_name=dtype_name, esz=esz, per_channel=per_channel, shape=shape, axis=axis,
                     scaling=scaling, n_local=n_local, n_global=n_global, n_sets=n_sets, set_bytes=set_bytes, steps=steps,
                     warmup=warmup, elapsed_max=elapsed_max, fwd_ms=fwd_ms, bwd_ms=bwd_ms, fwd_avg=fwd_avg, bwd_avg=bwd_avg,
-                    xs=xs, gs=gs, x=x, solo_ms=solo_ms, block_times=block_times)
+                    xs=xs, gs=gs, x=x, solo_ms=solo_ms, block_times=block_times, graph=bool(graph))
 
     # the non-headline workloads are small (20-100 us per step): W warm-up steps are over before the GPU's clocks have come up,
     # so they warm up for at least 60 ms of wall time (the headline workload, cfg2, does exactly its W steps)
@@ -608,11 +667,14 @@ def run_rank(a):
             torch.cuda.empty_cache()
             t_sec = time.perf_counter()
             sec = []
-            for w in SECONDARY:
+            for w, extra in SECONDARY_RUNS:
                 try:
-                    sm = measure(w, a.secondary_steps, 20, warm_ms=60.0, extra_blocks=2)
+                    name = extra.get("name", w)
+                    mkw = {k: v for k, v in extra.items() if k in ("graph", "shard_of", "multi")}
+                    sm = measure(w, a.secondary_steps if not extra.get("multi") else max(20, a.secondary_steps // 4), 20,
+                                 warm_ms=60.0, extra_blocks=0 if mkw.get("graph") else 2, **mkw)
                     sb_f, sb_b = 2 * sm["esz"], 3 * sm["esz"]
-                    rec = {"workload": w, "shape": sm["shape"], "storage": sm["dtype_name"],
+                    rec = {"workload": name, "shape": sm["shape"], "storage": sm["dtype_name"],
                            "value": round(sm["n_global"] * sm["steps"] / sm["elapsed_max"] / 1e9, 3), "unit": "GElem/s",
                            "steps": sm["steps"], "ms_per_step": round(sm["elapsed_max"] / sm["steps"] * 1e3, 5),
                            "fwd_ms": round(sm["fwd_avg"], 5), "bwd_ms": round(sm["bwd_avg"], 5),
@@ -620,10 +682,14 @@ def run_rank(a):
                            "fwd_frac": round(sb_f * sm["n_local"] / (sm["fwd_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                            "step_frac": round((sb_f + sb_b) * sm["n_local"] / ((sm["fwd_avg"] + sm["bwd_avg"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                            "step_frac_wall": round((sb_f + sb_b) * sm["n_local"] / (sm["elapsed_max"] / sm["steps"]) / 1e9 / HBM_PEAK_GBS, 4),
-                           "launch": "eager", "host_binding": binding, "input_buffer_sets": sm["n_sets"],
+                           "launch": "graph" if sm["graph"] else "eager", "host_binding": binding, "input_buffer_sets": sm["n_sets"],
                            "blocks_ms_per_step": [round(tb / sm["steps"] * 1e3, 5) for tb in sm["block_times"]],
                            "value_is": "median of %d blocks of %d steps" % (len(sm["block_times"]), sm["steps"])}
-                    n_small = sm["n_local"] < (1 << 23)
+                    if extra.get("note"):
+                        rec["what"] = extra["note"]
+                    if sm["graph"]:
+                        rec["per_op_ms_from"] = "a second, un-timed pass of eager launches (the ops are nodes of one graph launch)"
+                    n_small = sm["n_local"] < (1 << 23) and not mkw
                     del sm
                     if n_small and binding == "native":
                         # launch-bound sizes: the Python / ctypes host layer next to the C++ binding (same kernels)
@@ -633,7 +699,7 @@ def run_rank(a):
                     torch.cuda.empty_cache()
                     sec.append(rec)
                 except Exception as e:      # never let a secondary record break the headline line
-                    sec.append({"workload": w, "error": repr(e)})
+                    sec.append({"workload": extra.get("name", w), "error": repr(e)})
             line["secondary"] = sec
             line["secondary_wall_s"] = round(time.perf_counter() - t_sec, 2)
     strong = None

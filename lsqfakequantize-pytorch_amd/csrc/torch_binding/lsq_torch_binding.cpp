@@ -17,6 +17,7 @@
 // forward+backward of a small layer: see DESIGN.md section 7).
 #include <ATen/ATen.h>
 #include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPCachingAllocator.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
@@ -192,12 +193,21 @@ void* ticket_for(const Tensor& x, void* stream, bool per_channel) {
     if (hit != g_tickets.end()) return hit->second;
     TicketSlab& slab = g_ticket_slabs[dev];
     if (!slab.base) {
-        void* p = nullptr;
+        // From PyTorch's caching allocator (raw_alloc: normally a cached block, no hipMalloc) and zeroed on the CALLING stream,
+        // which was just seen not to be capturing, with a stream-level wait: a hipMalloc / device-wide synchronisation here
+        // would be illegal -- and would invalidate the capture -- while ANOTHER stream captures in global mode.  Never
+        // returned to the allocator (a raw pointer, not a Tensor: nothing to destroy after the runtime at process exit).
         const size_t bytes = static_cast<size_t>(kTicketSlots) * LSQ_TICKET_BYTES;
-        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {   // zeroed before any stream uses a slot (one-off)
+        void* p = nullptr;
+        try {
+            c10::DeviceGuard guard(x.device());
+            p = c10::hip::HIPCachingAllocator::raw_alloc(bytes);
+        } catch (...) {
+            return nullptr;                                   // two-launch route; asked again at the next backward
+        }
+        if (hipMemsetAsync(p, 0, bytes, static_cast<hipStream_t>(stream)) != hipSuccess ||
+            hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) {   // zeroed before any other stream uses a slot (one-off)
             (void)hipGetLastError();
-            (void)hipFree(p);
             return nullptr;
         }
         slab.base = static_cast<char*>(p);
@@ -536,13 +546,29 @@ class LsqForeachNode : public torch::autograd::Function<LsqForeachNode> {
         const int64_t flags = cfg[4];
         const Scalars s{cfg[0], cfg[1], cfg[2], cfg[3], (flags & 1) != 0, ctx->saved_data["gs"].toDouble(), (flags & 2) != 0,
                         (flags & 8) != 0, (flags & 16) != 0};
-        const at::TensorList all(saved);
-        std::vector<Tensor> gl(n);
-        for (size_t i = 0; i < n; ++i) gl[i] = grads[i].defined() ? grads[i] : at::zeros_like(saved[i]);
-        const std::vector<Tensor> r = backward_per_channel_multi(gl, all.slice(0, n), all.slice(n, n), all.slice(2 * n, n), axes, s.qmin,
-                                                                 s.qmax, s.tmin, s.tmax, s.use_gs, s.gs, s.sym, s.eval_mode, s.init_mode);
+        // An output nobody used has no gradient: its tensor takes no part in the launch and gets NO gradients -- what N separate
+        // lsq calls give it (with init_mode the parameter gradients ignore the upstream one, lsq_kernel.h:116, so a zero-filled
+        // stand-in would invent d_scale / d_shift for it; and it would cost a fill plus the tensor's share of the kernel).
         torch::autograd::variable_list out(3 * n + 10);
-        for (size_t i = 0; i < 3 * n; ++i) out[i] = r[i];
+        std::vector<size_t> live;
+        live.reserve(n);
+        for (size_t i = 0; i < n; ++i)
+            if (grads[i].defined()) live.push_back(i);
+        if (live.empty()) return out;
+        const size_t m = live.size();
+        std::vector<Tensor> gl(m), xl(m), sl(m), bl(m);
+        std::vector<int64_t> al(m);
+        for (size_t k = 0; k < m; ++k) {
+            const size_t i = live[k];
+            gl[k] = grads[i]; xl[k] = saved[i]; sl[k] = saved[n + i]; bl[k] = saved[2 * n + i]; al[k] = axes[i];
+        }
+        const std::vector<Tensor> r = backward_per_channel_multi(gl, xl, sl, bl, al, s.qmin, s.qmax, s.tmin, s.tmax, s.use_gs, s.gs, s.sym,
+                                                                 s.eval_mode, s.init_mode);
+        for (size_t k = 0; k < m; ++k) {
+            out[live[k]] = r[k];
+            out[n + live[k]] = r[m + k];
+            out[2 * n + live[k]] = r[2 * m + k];
+        }
         return out;
     }
 };

@@ -221,7 +221,13 @@ def _ticket(idx, stream):
     # A launch that is being CAPTURED into a HIP graph gets no ticket (two-launch route): the graph may later be replayed on
     # any stream, next to eager work or another replay on the capture stream, and two concurrent launches must never share
     # an arrival counter.
-    if torch.cuda.is_current_stream_capturing():
+    # (asked about THE device the kernel is launched on: the query looks at the current device's current stream)
+    if torch.cuda.current_device() == idx:
+        capturing = torch.cuda.is_current_stream_capturing()
+    else:
+        with torch.cuda.device(idx):
+            capturing = torch.cuda.is_current_stream_capturing()
+    if capturing:
         return None
     key = (idx, stream)
     hit = _TICKETS.get(key)          # (a dict read is atomic under the GIL; entries are never removed or changed)

@@ -242,10 +242,18 @@ class _LSQForeach(torch.autograd.Function):
         tensors = ctx.saved_tensors
         xs, scales, shifts = tensors[:n], tensors[n:2 * n], tensors[2 * n:]
         (qmin, qmax, tmin, tmax, axes, use_gs, gs, sym, eval_mode, init_mode) = ctx.cfg
-        grads = [g if g is not None else torch.zeros_like(x) for g, x in zip(grad_outs, xs)]
-        outs = _E.hip_backward_per_channel_multi(grads, xs, scales, shifts, axes, qmin, qmax, tmin, tmax, use_gs, gs, sym,
-                                                 eval_mode, init_mode)
-        return (None, None) + tuple(o[0] for o in outs) + tuple(o[1] for o in outs) + tuple(o[2] for o in outs)
+        # an output nobody used has no gradient: its tensor takes no part in the launch and gets NO gradients, exactly what N
+        # separate lsq calls give it (with init_mode the parameter gradients ignore the upstream gradient, lsq_kernel.h:116: a
+        # zero-filled stand-in would invent d_scale / d_shift for it)
+        live = [i for i in range(n) if grad_outs[i] is not None]
+        dxs, dss, dbs = [None] * n, [None] * n, [None] * n
+        if live:
+            outs = _E.hip_backward_per_channel_multi([grad_outs[i] for i in live], [xs[i] for i in live], [scales[i] for i in live],
+                                                     [shifts[i] for i in live], [axes[i] for i in live], qmin, qmax, tmin, tmax,
+                                                     use_gs, gs, sym, eval_mode, init_mode)
+            for i, o in zip(live, outs):
+                dxs[i], dss[i], dbs[i] = o
+        return (None, None) + tuple(dxs) + tuple(dss) + tuple(dbs)
 
 
 def lsq_foreach(xs, scales, shifts,
@@ -278,7 +286,8 @@ def lsq_foreach(xs, scales, shifts,
     axes = [int(axis)] * n if isinstance(axis, int) else [int(a) for a in axis]
     assert len(axes) == n
     fusable = not torch.jit.is_tracing() and not torch.compiler.is_compiling()
-    if fusable and n > 1 and _E._NATIVE_LSQ is not None and xs[0].is_cuda:
+    all_gpu = all(x.is_cuda and sc.is_cuda and sh.is_cuda for x, sc, sh in zip(xs, scales, shifts))
+    if fusable and n > 1 and _E._NATIVE_LSQ is not None and all_gpu:     # (a list with CPU entries: the Python partition below)
         # C++ host layer: the partition into fused / single tensors, the checks and the one autograd node all happen there
         # (a table row and an output allocation of host time per tensor instead of a Python call chain)
         return list(torch.ops.torchlsq_native.lsq_foreach(list(xs), list(scales), list(shifts), axes, quant_min, quant_max,

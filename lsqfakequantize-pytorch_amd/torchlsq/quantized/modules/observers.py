@@ -500,14 +500,15 @@ class LSQFakeQuantizer(ObserverBase):
                             type_max=tmax, axis=self.ch_axis, is_perchannel=self.is_perchannel, dtype=self.dtype)
 
     # ---- the caller of the hot path ------------------------------------------------------------
-    _prefetched = None      # (weight tensor, its fake-quantized value) stashed by LSQWeightGroup.prequantize()
+    _prefetched = None      # (weight, its version, scale's, shift's, fake-quantized value) stashed by LSQWeightGroup.prequantize()
 
     def forward(self, x):
         pre = self._prefetched
         if pre is not None:         # this call's result was computed with the other weight quantizers, in one launch
             self._prefetched = None
-            if pre[0] is x:
-                return pre[1]
+            # ... for THIS tensor object and the values it and the parameters had then (Tensor._version: host-side counters)
+            if pre[0] is x and pre[1] == x._version and pre[2] == self.scale._version and pre[3] == self.shift._version:
+                return pre[4]
         if self.debug_mode:
             return x
         if not self._initialized:

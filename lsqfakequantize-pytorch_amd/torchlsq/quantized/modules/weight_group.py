@@ -37,15 +37,29 @@ class LSQWeightGroup:
     def __init__(self, model, register_hook=True):
         self.pairs = _qat_weight_layers(model)
         self.handle = model.register_forward_pre_hook(self._pre_hook) if register_hook else None
+        # results a layer did not pick up (a branch that did not run, an exception mid-forward) are dropped when the model's
+        # forward ends, whatever way it ends: a stashed non-leaf tensor would otherwise keep the whole fused graph alive, make
+        # copy.deepcopy(model) raise and travel with torch.save(model)
+        self.post_handle = model.register_forward_hook(self._post_hook, always_call=True) if register_hook else None
         self.last_fused = 0          # tensors that went through the fused call at the last prequantize()
 
+    def clear(self):
+        for _, q in self.pairs:
+            q._prefetched = None
+
     def remove(self):
-        if self.handle is not None:
-            self.handle.remove()
-            self.handle = None
+        self.clear()
+        for name in ("handle", "post_handle"):
+            h = getattr(self, name)
+            if h is not None:
+                h.remove()
+                setattr(self, name, None)
 
     def _pre_hook(self, module, args):
         self.prequantize()
+
+    def _post_hook(self, module, args, output):
+        self.clear()
 
     @staticmethod
     def _steady(q, w):
@@ -84,6 +98,8 @@ class LSQWeightGroup:
                              quant_max=qmax, type_min=tmin, type_max=tmax, axis=[q.ch_axis for q, _ in items],
                              use_grad_scaling=use_gs, grad_scaler=gs, is_affine=affine, eval_mode=(not full_lsq), init_mode=False)
             for (q, w), y in zip(items, ys):
-                q._prefetched = (w, y)
+                # valid for exactly this weight and these parameter values: the version counters catch an in-place update
+                # (optimizer.step(), w.mul_(), ...) between prequantize() and the layer's own call
+                q._prefetched = (w, w._version, q.scale._version, q.shift._version, y)
             self.last_fused += len(items)
         return self.last_fused

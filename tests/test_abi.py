@@ -105,7 +105,7 @@ def test_cpu_library_exports_its_header_and_devices_never_substitute():
     from torchlsq import extension as E
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "lsq_cpu.h")).read(), flags=re.S)
     declared = sorted(set(re.findall(r"\b(lsq_cpu_\w+)\s*\(", text)))
-    assert declared == sorted(E.C_ABI_CPU) and len(declared) == 7
+    assert declared == sorted(E.C_ABI_CPU) and len(declared) == 8
     cpu_lib = os.path.join(os.path.dirname(LIB), "liblsq_cpu.so")
     nm = subprocess.run(["nm", "-D", "--defined-only", cpu_lib], capture_output=True, text=True, check=True).stdout
     exported = set(l.split()[-1] for l in nm.splitlines() if " T " in l)

@@ -69,10 +69,41 @@ def test_default_line_carries_the_per_channel_half():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     sec = {s["workload"]: s for s in out["secondary"]}
-    assert sorted(sec) == ["cfg1", "cfg3", "cfg5", "cfg5_bf16"]
-    for s in sec.values():
-        assert "error" not in s and s["value"] > 0 and s["launch"] == "eager" and 0 < s["step_frac"] < 1, s
+    assert sorted(sec) == ["cfg1", "cfg1_graph", "cfg3", "cfg3_graph", "cfg3_x50_foreach", "cfg4_shard", "cfg5", "cfg5_bf16"]
+    for name, s in sec.items():
+        assert "error" not in s and s["value"] > 0 and 0 < s["step_frac"] < 1, s
+        assert s["launch"] == ("graph" if name.endswith("_graph") else "eager")
     assert "ms_per_step_ctypes_binding" in sec["cfg1"] and sec["cfg5_bf16"]["storage"] == "bfloat16"
+    # BASELINE config 4's per-GPU shard: the step one rank of the 8-GPU job runs, the denominator of the 0.9x target
+    assert sec["cfg4_shard"]["shape"] == [128, 1024, 14, 14] and "what" in sec["cfg4_shard"]
+    # 50 weight quantizers in one launch each way stream far better than 50 latency-bound single calls
+    assert sec["cfg3_x50_foreach"]["step_frac"] > sec["cfg3"]["step_frac"]
+    assert sec["cfg1_graph"]["ms_per_step"] < sec["cfg1"]["ms_per_step"]
+
+
+@pytest.mark.gpu
+def test_eight_ranks_control_flow_on_one_device():
+    """`--gpus 8` end to end without an 8-GPU node: eight self-spawned ranks share the one GPU, collectives over gloo -- rank
+    0 alone prints, the weak line and the strong-scaled config 4 ([1024,1024,14,14] / 8 = [128,1024,14,14] per rank) both
+    come out.  cfg1-sized weak shards keep eight processes within the box's memory; config 4's shards are the real size."""
+    r = _run(["--gpus", "8", "--backend", "gloo", "--single-device", "--workload", "cfg4", "--steps", "3", "--warmup", "1",
+              "--no-cpu-baseline"], timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = lines[0]
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["config"]["parallelism"] == "dp8"
+    assert out["config"]["elements_per_gpu"] == 128 * 1024 * 14 * 14 and out["config"]["global_elements"] == 1024 * 1024 * 14 * 14
+    assert out["value"] > 0 and 0 < out["per_gpu_efficiency"]
+
+
+@pytest.mark.gpu
+def test_a_failing_rank_shows_its_traceback():
+    r = _run(["--gpus", "2", "--backend", "gloo", "--single-device", "--workload", "cfg1", "--steps", "2", "--warmup", "1",
+              "--no-cpu-baseline", "--fail-rank", "1"])
+    assert r.returncode != 0
+    assert "rank 1 exited with code" in r.stderr and "deliberate failure of rank 1" in r.stderr and "Traceback" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
 @pytest.mark.gpu
