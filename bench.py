@@ -327,6 +327,8 @@ def run_rank(a):
             scaling = "strong"
         if workload == "cfg4_shard":     # one rank's share of config 4 at 8 GPUs, whatever this job's size
             shape[0] //= 8
+            if world == 1 and not shard_of:
+                shard_of = 8             # ... run as that rank runs it: global element count in the scaler, fp64 sums rounded
         if world > 1 and per_channel and c["axis"] == 0:
             raise SystemExit("workload %s quantises along dim 0, the sharded dim: a weight is replicated under data "
                              "parallelism, there is nothing to shard -- run it with --gpus 1" % workload)
@@ -421,18 +423,25 @@ def run_rank(a):
             return None
 
         step_graphs = None
+        graph_steps = 1
         if graph:
+            # ONE graph holding `graph_steps` consecutive steps (the buffer sets in rotation): a replay is one launch of the
+            # whole chain, so what is timed is the GPU-side rate -- a graph per step would still pay a graph launch (~10 us of
+            # host time on this stack) per 10 us step.  The step count is rounded up to whole replays.
+            graph_steps = n_sets if (n_sets >= 8 or set_bytes >= (64 << 20)) else 8
+            steps = -(-steps // graph_steps) * graph_steps
             st = torch.cuda.Stream()
-            step_graphs = []
             with torch.cuda.stream(st):
-                for k in range(n_sets):          # one captured step per buffer set
+                for k in range(n_sets):
                     cur[0] = k
                     fwd(); bwd()
-                    gr = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gr, stream=st):
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=st):
+                    for k in range(graph_steps):
+                        cur[0] = k % n_sets
                         y = fwd()
                         r = bwd()
-                    step_graphs.append(gr)
+                step_graphs = [gr]
             torch.cuda.synchronize()
 
         # `warmup` untimed steps -- and, for the secondary records, as many more as it takes to fill `warm_ms` of wall time:
@@ -443,7 +452,8 @@ def run_rank(a):
         while i < warmup or (warm_ms > 0 and world == 1 and (time.perf_counter() - t_warm) * 1e3 < warm_ms):
             cur[0] = i % n_sets
             if step_graphs is not None:
-                step_graphs[cur[0]].replay()
+                step_graphs[0].replay()
+                i += graph_steps - 1
             else:
                 y = fwd()
                 r = bwd()
@@ -486,8 +496,8 @@ def run_rank(a):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if step_graphs is not None:
-            for i in range(steps):
-                step_graphs[i % n_sets].replay()
+            for i in range(steps // graph_steps):
+                step_graphs[0].replay()
         else:
             for i in range(steps):
                 cur[0] = i % n_sets
@@ -544,7 +554,7 @@ def run_rank(a):
         return dict(workload=workload, c=c, dtype_name=dtype_name, esz=esz, per_channel=per_channel, shape=shape, axis=axis,
                     scaling=scaling, n_local=n_local, n_global=n_global, n_sets=n_sets, set_bytes=set_bytes, steps=steps,
                     warmup=warmup, elapsed_max=elapsed_max, fwd_ms=fwd_ms, bwd_ms=bwd_ms, fwd_avg=fwd_avg, bwd_avg=bwd_avg,
-                    xs=xs, gs=gs, x=x, solo_ms=solo_ms, block_times=block_times, graph=bool(graph))
+                    xs=xs, gs=gs, x=x, solo_ms=solo_ms, block_times=block_times, graph=bool(graph), graph_steps=graph_steps)
 
     # the non-headline workloads are small (20-100 us per step): W warm-up steps are over before the GPU's clocks have come up,
     # so they warm up for at least 60 ms of wall time (the headline workload, cfg2, does exactly its W steps)
@@ -558,7 +568,7 @@ def run_rank(a):
     xs, gs, x = m["xs"], m["gs"], m["x"]
     if rank == 0:
         bytes_fwd, bytes_bwd = 2 * esz, 3 * esz   # algorithmic bytes per element: R x + W y; R grad + R x + W dx
-        value = n_global * a.steps / elapsed_max / 1e9
+        value = n_global * m["steps"] / elapsed_max / 1e9
         bwd_gbs = bytes_bwd * n_local / (bwd_avg * 1e-3) / 1e9
         fwd_gbs = bytes_fwd * n_local / (fwd_avg * 1e-3) / 1e9
         step_gbs = (bytes_fwd + bytes_bwd) * n_local / ((fwd_avg + bwd_avg) * 1e-3) / 1e9
@@ -597,16 +607,16 @@ def run_rank(a):
         metric = METRIC if not per_channel else METRIC.replace("per-tensor int8", "per-channel (%s workload, not the BASELINE headline)" % a.workload)
         line = {
             "metric": metric,
-            "value": round(value, 3), "unit": "GElem/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(elapsed_max / a.steps * 1e3, 5), "higher_is_better": True, "scaling": scaling,
+            "value": round(value, 3), "unit": "GElem/s", "n_gpus": world, "steps": m["steps"], "warmup": a.warmup,
+            "ms_per_step": round(elapsed_max / m["steps"] * 1e3, 5), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "warmup_wall_floor_ms": warm_floor_ms,
-            "timed_blocks_ms_per_step": [round(tb / a.steps * 1e3, 5) for tb in m["block_times"]],
+            "timed_blocks_ms_per_step": [round(tb / m["steps"] * 1e3, 5) for tb in m["block_times"]],
             "config": {"workload": "%s: %s %s %s per GPU, %s%s" % (a.workload, what, dtype_name, shape, opnames,
                                                                     "" if world == 1 else ", batch-sharded, 1 RCCL all-reduce of fp64 [ds,db] per step"),
                        "storage": dtype_name, "arithmetic": "float32",
                        "elements_per_gpu": n_local, "global_elements": n_global,
                        "parallelism": "dp%d" % world, "host_binding": binding,
-                       "launch": "hip-graph replay" if a.graph else "eager",
+                       "launch": ("hip-graph replay (%d steps per graph launch)" % m["graph_steps"]) if a.graph else "eager",
                        "input_buffer_sets": n_sets,
                        "input_buffers_note": (("the steps rotate through %d copies of (x, grad), %.2f GB of inputs: reads come from HBM, "
                                                "not from the 256 MB Infinity Cache" % (n_sets, n_sets * set_bytes / 1e9))
@@ -688,6 +698,7 @@ def run_rank(a):
                     if extra.get("note"):
                         rec["what"] = extra["note"]
                     if sm["graph"]:
+                        rec["steps_per_graph_launch"] = sm["graph_steps"]
                         rec["per_op_ms_from"] = "a second, un-timed pass of eager launches (the ops are nodes of one graph launch)"
                     n_small = sm["n_local"] < (1 << 23) and not mkw
                     del sm

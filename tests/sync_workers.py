@@ -236,6 +236,8 @@ def ddp_train(rank, world, port, device, out_q, steps=6):
             flat = torch.cat([p.detach().reshape(-1).double() for p in repl.parameters()])
             gathered = [torch.empty_like(flat) for _ in range(world)]
             dist.all_gather(gathered, flat)
+            if i == 1:
+                refresh["n"] = 0        # (the first call after .to(device) re-reads the moved buffers once: not DDP's doing)
             if any(not torch.equal(g, gathered[0]) for g in gathered):
                 problems.append("step %d: replicas differ across ranks" % i)
             for (n1, p1), (_, p2) in zip(single.named_parameters(), repl.named_parameters()):

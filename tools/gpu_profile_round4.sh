@@ -1,0 +1,42 @@
+#!/bin/bash
+# Round-4 evidence run on one MI355X box (via gpurun).  Summaries into gpurun_out/summ4/ (tools/collect_round_profiles.py 4
+# copies them into profiles/).  Part 1: the default bench line + rocprofv3 kernel stats of the same command + the single-workload
+# lines; part 2 (arg "exp"): the round's experiments.
+export TMPDIR=/tmp
+O=gpurun_out/summ4
+mkdir -p $O
+if [ "$1" != "exp" ]; then
+python3 bench.py --steps 100 --warmup 20 > $O/r04_bench_cfg2_n1.json 2> $O/r04_bench_cfg2_n1.err
+tail -1 $O/r04_bench_cfg2_n1.json | cut -c1-300
+rocprofv3 --kernel-trace --stats -d $O/prof_cfg2 -o bench -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-measure-traffic --no-yardstick --no-secondary > $O/r04_bench_cfg2_under_rocprof.json 2>/dev/null
+python3 tools/rocprof_summary.py $O/prof_cfg2 > $O/r04_bench_cfg2_kernel_stats.txt; rm -rf $O/prof_cfg2
+grep "lsq::" $O/r04_bench_cfg2_kernel_stats.txt | cut -c1-200
+for W in cfg1 cfg3 cfg4_shard cfg5 cfg5_bf16; do
+  python3 bench.py --workload $W --steps 200 --warmup 20 > $O/r04_bench_${W}_n1.json 2> $O/r04_bench_${W}_n1.err
+  tail -1 $O/r04_bench_${W}_n1.json | cut -c1-220
+done
+for W in cfg1 cfg3 cfg4_shard; do
+  python3 bench.py --workload $W --steps 200 --warmup 20 --graph --no-cpu-baseline > $O/r04_bench_${W}_graph.json 2>/dev/null
+  tail -1 $O/r04_bench_${W}_graph.json | cut -c1-220
+done
+for W in cfg4_shard cfg5_bf16; do
+  rocprofv3 --kernel-trace --stats -d $O/prof_$W -o bench -- python3 bench.py --workload $W --steps 100 --warmup 20 --no-cpu-baseline --no-measure-traffic --no-yardstick > /dev/null 2>&1
+  python3 tools/rocprof_summary.py $O/prof_$W > $O/r04_bench_${W}_kernel_stats.txt; rm -rf $O/prof_$W
+  grep "lsq::" $O/r04_bench_${W}_kernel_stats.txt | cut -c1-200
+done
+python3 bench.py --gpus 8 --backend gloo --single-device --workload cfg4 --steps 5 --warmup 2 --no-cpu-baseline > $O/r04_bench_cfg4_8ranks_one_device_gloo.json 2> $O/r04_bench_8ranks.err
+tail -1 $O/r04_bench_cfg4_8ranks_one_device_gloo.json | cut -c1-400
+else
+# ---- experiments -------------------------------------------------------------------------------------------------------
+python3 tools/exp_levels_only.py > $O/r04_levels_only.txt 2>/dev/null; cat $O/r04_levels_only.txt
+for CTR in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $CTR --kernel-trace -d $O/pmc_lv_$CTR -o lv -- python3 tools/exp_levels_only.py one cfg2 > /dev/null 2>&1
+  python3 tools/rocprof_summary.py $O/pmc_lv_$CTR --pmc | grep -E "^$CTR" | grep "lsq::" | cut -c1-220 >> $O/r04_levels_only_pmc.txt
+  rm -rf $O/pmc_lv_$CTR
+done
+cat $O/r04_levels_only_pmc.txt
+python3 tools/exp_owner_probe.py > $O/r04_owner_pattern_probe.txt 2>/dev/null; cat $O/r04_owner_pattern_probe.txt
+python3 tools/exp_knob_ab.py set_fin_ch 64 0 bf16 256x2048x7x7@1 128x512x28x28@1 > $O/r04_finalize_lean_ab.txt 2>/dev/null
+python3 tools/exp_knob_ab.py set_fin_ch 64 0 f32 256x2048x7x7@1 >> $O/r04_finalize_lean_ab.txt 2>/dev/null
+cat $O/r04_finalize_lean_ab.txt
+fi
