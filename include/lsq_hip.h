@@ -127,6 +127,23 @@ const char* lsq_hip_last_error(void);
 double lsq_hip_grad_scaler(int dtype, int per_channel, int64_t numel, int32_t quant_max,
                            int64_t channels, int32_t use_grad_scaling, double grad_scaler);
 
+/* ---- host-side launch policy shared by every host layer ------------------------------------------------ */
+
+/* Two host layers sit on this ABI (the Python / ctypes one and the C++ torch binding); the decisions they
+ * must make IDENTICALLY live here, as pure functions (no GPU, no state), so that they cannot drift apart:
+ *
+ * lsq_hip_policy_ticket: should this backward be given a ticket (one launch instead of kernel + finalize launch)?
+ *   mode 0 never, 1 always, 2 "auto": per-tensor tensors of at most 8 MB -- host-bound in eager mode, where one launch less is
+ *   11-15 % of a forward + backward step, while on the GPU the one-launch route is never faster.  The
+ *   per-channel entry point ignores tickets, so auto never asks for one there.  Captured launches take none whatever the
+ *   answer (the caller knows whether its stream is capturing).
+ * lsq_hip_policy_saves_mask: does the forward of an autograd node save the one-byte inside mask (aux_kind 1) instead of x?
+ *   Only the eval-mode backward can run from it (lsq_kernel.h:126-145), only when an input gradient will be asked for, and
+ *   only if the caller did not ask for the reference's behaviour to the letter (mask from the parameters at BACKWARD time,
+ *   lsq_autograd.cpp:46-73: what LSQFakeQuantizer needs while its observer rewrites them). */
+int lsq_hip_policy_ticket(int32_t mode, int32_t per_channel, int64_t tensor_bytes);
+int lsq_hip_policy_saves_mask(int32_t eval_mode, int32_t init_mode, int32_t input_requires_grad, int32_t mask_backward);
+
 /* ---- per-tensor ------------------------------------------------------------------------- */
 
 /* Bytes of scratch the backward needs (block partial sums); 256-byte aligned buffer expected.

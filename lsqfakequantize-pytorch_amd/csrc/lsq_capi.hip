@@ -91,6 +91,17 @@ double lsq_hip_grad_scaler(int dtype, int per_channel, int64_t numel, int32_t qu
                : static_cast<double>(lsq::grad_scaler_per_tensor<float>(numel, quant_max, use, grad_scaler));
 }
 
+int lsq_hip_policy_ticket(int32_t mode, int32_t per_channel, int64_t tensor_bytes) {
+    constexpr int64_t kTicketAutoBytes = int64_t{8} << 20;      // profiles/r03_ticket_sizes.txt
+    if (mode == 1) return 1;
+    if (mode == 2) return (!per_channel && tensor_bytes <= kTicketAutoBytes) ? 1 : 0;
+    return 0;
+}
+
+int lsq_hip_policy_saves_mask(int32_t eval_mode, int32_t init_mode, int32_t input_requires_grad, int32_t mask_backward) {
+    return (eval_mode && !init_mode && input_requires_grad && mask_backward) ? 1 : 0;
+}
+
 size_t lsq_hip_backward_per_tensor_workspace(int dtype, int64_t n) {
     (void)dtype;
     (void)n;
@@ -308,6 +319,7 @@ void lsq_hip_debug_set_seg_min_div(int v) { lsq::knob::set(lsq::knob::kSegMinDiv
 void lsq_hip_debug_set_fwd_direct(int v) { lsq::knob::set(lsq::knob::kFwdDirect, v < 0 || v > 4 ? 0 : v); }
 void lsq_hip_debug_set_seg_no_up_front(int v) { lsq::knob::set(lsq::knob::kSegNoUpFront, v ? 1 : 0); }
 void lsq_hip_debug_set_fin_ch(int v) { lsq::knob::set(lsq::knob::kFinCh, v); }
+void lsq_hip_debug_set_own(int v) { lsq::knob::set(lsq::knob::kOwn, v < 0 || v > 2 ? 0 : v); }
 
 #ifdef LSQ_TIMELINE
 void lsq_hip_debug_set_timeline(void* device_buffer) { lsq::knob::timeline_buffer().store(static_cast<unsigned long long*>(device_buffer)); }

@@ -57,7 +57,7 @@ constexpr int kDefaultPcSegNarrowVariant = encode_variant(1, true, true, 16);   
 // constant 0 ("no override"), the policy code that consults it folds away, no lsq_hip_debug_* symbol is exported, and the
 // library keeps no mutable global state (include/lsq_hip.h).
 namespace knob {
-enum Id { kForceRing, kWwMinRows, kWwSplit64, kWwBig, kRingNt, kFinCh, kObserveWgPerCu, kWwMaxLog2, kSegMinDiv, kFwdDirect, kSegNoUpFront, kCount };
+enum Id { kForceRing, kWwMinRows, kWwSplit64, kWwBig, kRingNt, kFinCh, kObserveWgPerCu, kWwMaxLog2, kSegMinDiv, kFwdDirect, kSegNoUpFront, kOwn, kCount };
 #ifdef LSQ_TOOLS
 inline std::atomic<int>& slot(Id id) {
     static std::atomic<int> v[kCount];
@@ -77,7 +77,7 @@ inline std::atomic<unsigned long long*>& timeline_buffer() {     // lsq_hip_debu
 // all geometry knobs as one key (the workspace memo of lsq_capi.hip)
 inline int geometry_key() {
     int k = 0;
-    for (Id id : {kWwMinRows, kWwSplit64, kWwBig, kRingNt, kWwMaxLog2, kSegMinDiv}) k = k * 41 + get(id);
+    for (Id id : {kWwMinRows, kWwSplit64, kWwBig, kRingNt, kWwMaxLog2, kSegMinDiv, kOwn}) k = k * 41 + get(id);
     return k;
 }
 }  // namespace knob
@@ -204,7 +204,7 @@ inline int resident_blocks_per_cu(const void* kernel, size_t lds_bytes) {
 // what the last window-mode backward launch of this thread looked like (lsq_hip_debug_last_launch; tools build only)
 struct LaunchNote {
     int grid_x, grid_y, resident_per_cu, vgprs_hint;
-    int kind;        // 1 = 256-lane windows, 2 = row-group windows, 3 = segment mode
+    int kind;        // 1 = 256-lane windows, 2 = row-group windows, 3 = segment mode, 4 = owner windows
     int dma_depth;   // 0 = register loops, else the LDS-DMA ring depth
     int block;       // workgroup size
     int ring_nt;

@@ -135,6 +135,7 @@ struct PcGeom {
     int32_t block_threads;   // workgroup size to launch (kBlock except for row-group windows)
     int32_t ring_nt;         // LDS-DMA ring: issue its copies with the streaming hint (global_load_lds ... nt)
     int32_t direct;          // forward, a lane's components are different channels: no LDS table, the lane reads its own scale / shift
+    int32_t own;             // OWNER windows (make_geom_own): lanes per row of the owner's run; 0 otherwise
 #ifdef LSQ_TIMELINE
     unsigned long long* timeline;   // experiment build (tools/exp_timeline.py): 8 x u64 per wave of the window backward
 #endif
@@ -194,6 +195,7 @@ static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec,
     g.block_threads = kBlock;
     g.ring_nt = 0;
     g.direct = 0;
+    g.own = 0;
 #ifdef LSQ_TIMELINE
     g.timeline = nullptr;
 #endif
@@ -233,6 +235,7 @@ static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_
     PcGeom g;
     g.ring_nt = 0;
     g.direct = 0;
+    g.own = 0;
 #ifdef LSQ_TIMELINE
     g.timeline = nullptr;
 #endif
@@ -267,6 +270,85 @@ static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_
     return g;
 }
 
+// OWNER windows (backward, round 4): a workgroup OWNS k whole channels -- a run of k * inner contiguous positions of every
+// row -- for ALL rows, so its channel sums are final: no partials, no finalize launch (on a 25 M-element activation that
+// launch was 5-6 us of a 36 us backward).  k is the smallest channel count whose run is whole 16-byte packets; the workgroup
+// is R row slots of run / V lanes each (lane t: row slot t / lanes, packet t % lanes of the run), row slot r takes row r of
+// every tile of R rows -- the lane keeps its packet column, hence its channel(s), for its whole life like in every other
+// window mode.  Neighbouring owners share a 128-byte line at each end of their runs (784-byte runs at BASELINE config 5),
+// so the owner index is dealt XCD-major (own_window): consecutive runs meet in one XCD's L2 instead of being fetched twice
+// (tools/exp_owner_probe.py, profiles/r04_owner_pattern_probe.txt: 28.1 us against 31.4 without, 29-31 for 4 KiB windows).
+struct OwnPlan {
+    int k;                // channels per owner (0: the shape does not take owner windows)
+    int lanes_per_row;    // run / V
+    int R;                // row slots per workgroup
+    int block_threads;    // R * lanes_per_row rounded up to whole waves
+    int per_cu;           // owners resident per CU the plan was sized for
+};
+static inline OwnPlan plan_own(int64_t outer, int64_t C, int64_t inner, int vec, int elem_bytes, int dma_depth, int cus,
+                               int block_limit = 512) {
+    OwnPlan o{0, 0, 0, 0, 0};
+    if (vec <= 1 || inner < vec) return o;                         // (inner < V: the row-group / last-axis kernels' ground)
+    int k = 0;
+    for (int kk = 1; kk <= vec; ++kk)
+        if ((kk * inner) % vec == 0 && C % kk == 0) { k = kk; break; }
+    if (k == 0) return o;
+    const int64_t lanes = k * inner / vec;
+    if (lanes > 256) return o;                                     // long channel rows: the 256-lane windows / segment walk
+    const int64_t owners = C / k;
+    const int per_cu = static_cast<int>((owners + cus - 1) / cus);
+    if (owners < (3 * static_cast<int64_t>(cus)) / 4 || per_cu > 4) return o;   // idle CUs / more than one round of fat workgroups
+    // waves a CU can hold per owner: 16 of the 1024-lane launch bound, and the ring's LDS (dma_depth stages of 2 KiB per wave)
+    const int lds_waves = static_cast<int>(((160 * 1024) / per_cu - 2048) / (dma_depth * kDmaStageBytes));
+    const int max_lanes = std::min(block_limit, std::min(1024 / per_cu, lds_waves * 64)) / 64 * 64;
+    int r_max = static_cast<int>(std::min<int64_t>(max_lanes / lanes, outer));
+    if (r_max < 2) return o;
+    int R = r_max;
+    for (int d = r_max; d * 5 >= r_max * 3; --d)                   // a divisor of the row count close to the maximum: every
+        if (outer % d == 0) { R = d; break; }                      // lane then walks the same number of rows (the loop's fast form)
+    // the ring wants 2 x its depth of row tiles per lane: few rows -> fewer row slots (a thinner workgroup), down to two
+    while (R > 2 && (outer + R - 1) / R < 2 * dma_depth) {
+        int next = R - 1;
+        for (int d = R - 1; d >= 2; --d)
+            if (outer % d == 0) { next = d; break; }
+        R = next;
+    }
+    if ((outer + R - 1) / R < 2 * dma_depth) return o;              // too few rows per lane to run the ring
+    o.k = k; o.lanes_per_row = static_cast<int>(lanes); o.R = R; o.per_cu = per_cu;
+    o.block_threads = static_cast<int>((R * lanes + 63) / 64 * 64);
+    (void)elem_bytes;
+    return o;
+}
+static inline PcGeom make_geom_own(int64_t outer, int64_t C, int64_t inner, int vec, const OwnPlan& o) {
+    PcGeom g;
+    g.outer = outer; g.C = C; g.inner = inner; g.L = C * inner; g.vec = vec;
+    g.fits32 = (g.L + static_cast<int64_t>(1024) * vec) < 0x7fffffffLL ? 1 : 0;
+    g.wpos = static_cast<int64_t>(o.k) * inner;
+    g.n_windows = C / o.k;
+    g.R = o.R;
+    g.k_slots = o.k;
+    g.n_tiles = (outer + o.R - 1) / o.R;
+    g.splits = 1;
+    g.rows_per_split = g.n_tiles * o.R;
+    g.ww_lanes = 0;
+    g.block_threads = o.block_threads;
+    g.ring_nt = 0;
+    g.direct = 0;
+    g.own = o.lanes_per_row;
+#ifdef LSQ_TIMELINE
+    g.timeline = nullptr;
+#endif
+    return g;
+}
+// the owner a workgroup serves: blockIdx.x dealt XCD-major (workgroups go to the 8 XCDs round-robin: blockIdx.x % 8 is the
+// XCD), so that owners j and j + 1 -- whose runs share a cache line -- sit on the same XCD
+__device__ __forceinline__ int64_t own_window(const PcGeom& g) {
+    (void)g;
+    const uint32_t n = gridDim.x, x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+    const uint32_t per = n >> 3, rem = n & 7u;
+    return static_cast<int64_t>(x * per + (x < rem ? x : rem) + i);
+}
+
 // Dynamic LDS of the window-mode backward in front of the LDS-DMA ring: the channel table + fp64 slots of the 256-lane
 // windows (the ring starts at the next 1 KiB boundary).  Row-group windows have nothing in front: their combine buffer
 // is only used after the last row has been consumed and takes the ring's place (one barrier in between).
@@ -299,6 +381,19 @@ __device__ __forceinline__ LaneSite lane_site(const PcGeom& g, int V) {
         s.live = s.row_in_tile < g.R;
         s.c_lo = 0;
     }
+    return s;
+}
+
+// owner windows: thread t = packet (t % lanes) of row slot (t / lanes) of owner own_window()'s run
+__device__ __forceinline__ LaneSite lane_site_own(const PcGeom& g, int V) {
+    LaneSite s;
+    const uint32_t lanes = static_cast<uint32_t>(g.own);
+    const uint32_t slot = threadIdx.x / lanes;
+    const int64_t j = own_window(g);
+    s.p0 = j * g.wpos + static_cast<int64_t>(threadIdx.x - slot * lanes) * V;
+    s.row_in_tile = static_cast<int32_t>(slot);
+    s.live = static_cast<int32_t>(slot) < g.R;
+    s.c_lo = j * g.k_slots;
     return s;
 }
 

@@ -106,8 +106,19 @@ __device__ __forceinline__ void finish_channel_table(QSlot<T>* table, int k_coun
 }
 // first channel of workgroup blockIdx.x's window (LaneSite::c_lo without the per-lane part)
 __device__ __forceinline__ int64_t window_first_channel(const PcGeom& g) {
+    if (g.own) return own_window(g) * g.k_slots;
     return g.R == 1 ? udiv(static_cast<int64_t>(blockIdx.x) * g.wpos, g.inner, g.fits32 != 0) : 0;
 }
+
+// Where an OWNER-window backward stores its channels' finished sums (d_scale / d_shift, rounded once; wide: un-rounded).
+template <typename T>
+struct PcDirect {
+    T* ds;
+    T* db;
+    double* wide;
+    T sym_term;         // the constant per-element d_shift term of the symmetric case, 0 * grad_scaler (lsq_kernel.h:118,122)
+    int32_t sym;
+};
 
 // CPL = channels a lane can touch: 1 (inner % V == 0), 2 (inner >= V), V (anything).
 template <typename T, int V, int CPL>
@@ -428,10 +439,13 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
                                                         const typename IO::arith* __restrict__ scale,
                                                         const typename IO::arith* __restrict__ shift,
                                                         Range<typename IO::arith> r, typename IO::arith grad_scaler,
-                                                        double2* __restrict__ partials) {
+                                                        double2* __restrict__ partials, PcDirect<typename IO::arith> direct) {
     using T = typename IO::arith;
     using E = typename IO::elem;
     using LC = LaneChannels<T, V, CPL>;
+    // OWN: owner windows (make_geom_own) -- a fat workgroup of R row slots over the run of k whole channels, all rows: the
+    // LDS slots end up holding FINAL sums, stored straight to d_scale / d_shift (`direct`); no partials, no finalize launch
+    constexpr bool OWN = !WW && BLOCK > kBlock;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef LSQ_TIMELINE     // experiment build: shader-clock stamps per wave (tools/exp_timeline.py)
     const unsigned long long tl0 = __builtin_readcyclecounter();
@@ -441,7 +455,8 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
 #define LSQ_TL_WAIT(stmt) stmt
 #endif
     static_assert(!WW || (CPL == V && V > 1), "row-group windows: one channel per packet component");
-    static_assert(BLOCK == kBlock || (WW && DMA > 0), "768/1024-lane workgroups: row-group windows on the ring only");
+    static_assert(BLOCK == kBlock || DMA > 0, "768/1024-lane workgroups: row-group and owner windows, on the ring only");
+    static_assert(!OWN || (!EVAL && V > 1 && CPL <= 2), "owner windows: whole packets of one or two channels, training modes");
     QSlot<T>* table = reinterpret_cast<QSlot<T>*>(smem);
     double* lds_s = reinterpret_cast<double*>(smem + static_cast<size_t>(g.k_slots) * sizeof(QSlot<T>));
     double* lds_b = lds_s + g.k_slots;
@@ -473,7 +488,7 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
         raw = load_channel_raw<T>(g.k_slots, window_first_channel(g), g.C, scale, shift);
     }
     int32_t lane_in_group = 0;
-    const LaneSite site = WW ? lane_site_ww(g, V, lane_in_group) : lane_site(g, V);
+    const LaneSite site = WW ? lane_site_ww(g, V, lane_in_group) : (OWN ? lane_site_own(g, V) : lane_site(g, V));
     const RowWalk walk(g, site);
     // A group = UNROLL rows.  load_group never predicates: rows past the lane's last one re-read the last row.
     auto load_group = [&](E (&gb)[UNROLL][V], E (&xb)[UNROLL][V], int64_t i0) {
@@ -945,6 +960,26 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
             segmented_wave_accumulate<SYM>(site.live ? ch.key[j] : -1, acc_s[j], acc_b[j], lds_s, lds_b);
     }
     __syncthreads();
+    if constexpr (OWN) {
+        // every element of these channels went through this workgroup: the slots are the channels' totals
+        for (int k = threadIdx.x; k < g.k_slots; k += BLOCK) {
+            const int64_t c = site.c_lo + k;
+            if (c < g.C) {
+                const double ts = lds_s[k];
+                const double tb = direct.sym ? 0.0 + static_cast<double>(direct.sym_term) : lds_b[k];
+                direct.ds[c] = static_cast<T>(ts);
+                direct.db[c] = static_cast<T>(tb);
+                if (direct.wide) {
+                    direct.wide[c] = ts;
+                    direct.wide[g.C + c] = tb;
+                }
+            }
+        }
+#ifdef LSQ_TIMELINE
+        tl_record();
+#endif
+        return;
+    }
     const int64_t block_linear = static_cast<int64_t>(blockIdx.y) * g.n_windows + blockIdx.x;
     double2* out = partials + block_linear * g.k_slots;
     for (int k = threadIdx.x; k < g.k_slots; k += kBlock) out[k] = make_double2(lds_s[k], lds_b[k]);
@@ -1222,6 +1257,16 @@ static inline int ring_nt_for(int64_t tensor_bytes, bool backward, bool row_grou
 // (16-bit storage: 768 lanes -- its kernel needs ~140 registers, 1024 lanes would cap it at 128 and spill)
 template <int ELEM_BYTES>
 constexpr int kBigBlockOf = ELEM_BYTES < 4 ? 768 : 1024;
+// Owner windows (plan_own): launch bound of their kernels (the workgroup is R x lanes-per-row threads, at most this: eight
+// waves, so the 16-bit kernel keeps its ~120 registers without spilling) and the tensor size up to which the policy takes
+// them.  Measured (profiles/r04_owner_windows_ab.txt, backward op, cold): they win where the finalize launch is a large
+// share of the op -- [64,2048,7,7] bf16 15.8 -> 12.8 us, fp32 22.7 -> 18.8 us -- are level at 12.8 M elements and LOSE 15-30 %
+// from 25 M elements on (config 5: bf16 34.0 -> 39.5 us, fp32 59.1 -> 75.5 us; without the ring's streaming hint 38.8 / 69.7):
+// every owner walks the same rows at the same time and the kernel streams at 3.9-4.4 TB/s where the 256-lane windows,
+// whose row slabs spread the chip over the whole tensor, reach 5 TB/s -- although a no-arithmetic probe of the owner pattern
+// streams at 5.5 (profiles/r04_owner_pattern_probe.txt).
+constexpr int kOwnBlock = 512;
+constexpr int64_t kOwnMaxElems = int64_t{1} << 23;
 constexpr int kWwBwdBlocksPerCU = 4;     // row-group windows: one full round for every storage type (3-4 resident per CU)
 // Rows a forward workgroup walks at least, per unit of its per-workgroup overhead (make_geom): that overhead is only
 // the channel-table build -- VEC channels per lane when the quantized axis is the last one, so twice as heavy per
@@ -1565,7 +1610,7 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
                                         WW ? 2 : 1, dma_depth, g.block_threads, g.ring_nt};
 #endif
         hipLaunchKernelGGL(kern, grid, dim3(g.block_threads), lds, c.stream, c.grad, c.x, c.dx, g, static_cast<const T*>(c.scale),
-                           static_cast<const T*>(c.shift), r, c.gs, c.partials);
+                           static_cast<const T*>(c.shift), r, c.gs, c.partials, PcDirect<T>{nullptr, nullptr, nullptr, c.sym_term, 0});
         result = hipGetLastError();
         if (result != hipSuccess) return true;
         const int fin_ch = fin_channels(c.C);
@@ -1596,6 +1641,39 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
 #define LSQ_BWD_DMA_DEPTH 4
 #endif
     constexpr int kDmaDepth = LSQ_BWD_DMA_DEPTH;
+    // OWNER windows first (lsq_pc_geom.hpp, plan_own): activations whose channel rows are short (NCHW with small H x W) and
+    // whose tensor is small enough for the finalize launch to matter -- one launch, no workspace.
+    if constexpr (kDmaAble && !WW && !EVAL && V > 1 && CPL <= 2) {
+        const int own = knob::get(knob::kOwn);          // tools builds: 1 = wherever the shape allows, 2 = never
+        const int64_t bytes = c.outer * c.C * c.inner * static_cast<int64_t>(sizeof(typename IO::elem));
+        if (own != 2 && (own == 1 || (c.default_variant && c.outer * c.C * c.inner <= kOwnMaxElems))) {
+            auto launch_own = [&](auto block_c) -> bool {
+                constexpr int OB = decltype(block_c)::value;
+                const OwnPlan op = plan_own(c.outer, c.C, c.inner, V, static_cast<int>(sizeof(typename IO::elem)), kDmaDepth,
+                                            device_info().cu_count, OB);
+                if (op.k == 0) return false;
+                if (c.plan_need) return true;            // no workspace
+                PcGeom g = make_geom_own(c.outer, c.C, c.inner, V, op);
+                g.ring_nt = ring_nt_for(bytes, true, false);
+#if defined(LSQ_TOOLS) && defined(LSQ_TIMELINE)
+                g.timeline = knob::timeline_buffer().load();
+#endif
+                const size_t lds = bwd_lds_front_bytes(g, sizeof(QSlot<T>)) +
+                                   static_cast<size_t>(g.block_threads / 64) * kDmaDepth * kDmaStageBytes;
+                constexpr auto kern = bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, 1, true, true, false, false, kDmaDepth, OB>;
+#ifdef LSQ_TOOLS
+                last_launch_note() = LaunchNote{static_cast<int>(g.n_windows), 1, op.per_cu, registers_of(reinterpret_cast<const void*>(kern)),
+                                                4, kDmaDepth, g.block_threads, g.ring_nt};
+#endif
+                hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(g.n_windows)), dim3(g.block_threads), lds, c.stream, c.grad, c.x,
+                                   c.dx, g, static_cast<const T*>(c.scale), static_cast<const T*>(c.shift), r, c.gs, c.partials,
+                                   PcDirect<T>{c.ds, c.db, c.wide, c.sym_term, p.sym ? 1 : 0});
+                result = hipGetLastError();
+                return true;
+            };
+            if (launch_own(std::integral_constant<int, kOwnBlock>{})) return result;
+        }
+    }
     if constexpr (kDmaAble) {
         // (4- and 8-byte storage with one channel per lane, CPL == 1, keeps its register loop: it already has eight loads
         // in flight per lane and few registers, the ring only adds its LDS round trip -- measured 3-6 % slower)

@@ -165,7 +165,6 @@ Tensor byte_workspace(const Tensor& like, size_t nbytes) {
 // Mode 2 ("auto", the default): per-tensor tensors of at most 8 MB -- host-bound in eager mode, where one launch less is
 // 11-15 % of the forward + backward wall time; on the GPU the single-launch route is not faster, and 2-3 us slower where the
 // kernel is busy (profiles/r03_ticket_sizes.txt).  TORCHLSQ_SINGLE_LAUNCH_BACKWARD=1: always, =0: never.
-constexpr int64_t kTicketAutoBytes = int64_t{8} << 20;
 std::atomic<int> g_ticket_mode{[] {
     const char* e = std::getenv("TORCHLSQ_SINGLE_LAUNCH_BACKWARD");
     return !e ? 2 : (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2));
@@ -180,8 +179,9 @@ std::map<int, TicketSlab> g_ticket_slabs;                    // device index -> 
 std::map<std::pair<int, void*>, void*> g_tickets;            // (device index, stream) -> ticket
 
 void* ticket_for(const Tensor& x, void* stream, bool per_channel) {
-    const int mode = g_ticket_mode.load(std::memory_order_relaxed);
-    if (mode == 0 || (mode == 2 && (per_channel || x.numel() * static_cast<int64_t>(x.element_size()) > kTicketAutoBytes)))
+    // the decision is the library's (include/lsq_hip.h: one rule for both host layers); the mode is this layer's state
+    if (!lsq_hip_policy_ticket(g_ticket_mode.load(std::memory_order_relaxed), per_channel ? 1 : 0,
+                               x.numel() * static_cast<int64_t>(x.element_size())))
         return nullptr;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &st) != hipSuccess || st != hipStreamCaptureStatusNone)
@@ -380,7 +380,7 @@ class LsqNode : public torch::autograd::Function<LsqNode> {
         at::AutoDispatchBelowADInplaceOrView below;
         // mask_backward == false: the reference's eval backward, from x and the parameters as they are at backward time
         // (lsq_autograd.cpp:46-73) -- what LSQFakeQuantizer asks for while its observer rewrites them on every call
-        const bool masked = eval_mode && !init_mode && x.requires_grad() && mask_backward;
+        const bool masked = lsq_hip_policy_saves_mask(eval_mode, init_mode, x.requires_grad(), mask_backward) != 0;
         const Scalars s{qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode};
         auto [y, mask] = forward_impl(x, scale, shift, per_channel, axis, s, masked);
         ctx->save_for_backward({masked ? mask : x, scale, shift});
@@ -681,6 +681,12 @@ TORCH_LIBRARY(torchlsq_native, m) {
     m.def("lsq_backward_per_channel_multi(Tensor[] grads, Tensor[] xs, Tensor[] scales, Tensor[] shifts, int[] axes, " LSQ_TAIL
           ") -> Tensor[]");
     m.def("_abi_version() -> int", []() -> int64_t { return lsq_hip_abi_version(); });
+    // what this layer would decide (tests/test_host_policy.py holds it against the Python layer's decisions)
+    m.def("_policy_probe(int per_channel, int tensor_bytes, bool eval_mode, bool init_mode, bool requires_grad, bool mask_backward) -> int[]",
+          [](int64_t per_channel, int64_t bytes, bool eval_mode, bool init_mode, bool rg, bool mb) -> std::vector<int64_t> {
+              return {lsq_hip_policy_ticket(g_ticket_mode.load(), per_channel ? 1 : 0, bytes),
+                      lsq_hip_policy_saves_mask(eval_mode, init_mode, rg, mb), g_ticket_mode.load()};
+          });
     m.def("_set_single_launch_backward(int mode) -> ()", [](int64_t mode) { g_ticket_mode.store(mode < 0 || mode > 2 ? 2 : static_cast<int>(mode)); });
 }
 

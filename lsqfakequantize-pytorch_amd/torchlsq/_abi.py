@@ -69,6 +69,8 @@ C_ABI = {
     "lsq_hip_runtime_version": (_i64, []),
     "lsq_hip_last_error": (ctypes.c_char_p, []),
     "lsq_hip_grad_scaler": (ctypes.c_double, [_int, _int, _i64, ctypes.c_int32, _i64, ctypes.c_int32, ctypes.c_double]),
+    "lsq_hip_policy_ticket": (_int, [ctypes.c_int32, ctypes.c_int32, _i64]),
+    "lsq_hip_policy_saves_mask": (_int, [ctypes.c_int32] * 4),
     "lsq_hip_backward_per_tensor_workspace": (_sz, [_int, _i64]),
     "lsq_hip_forward_per_tensor": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _PP, _EP, _vp]),
     "lsq_hip_backward_per_tensor": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _PP, _BP, _vp, _sz, _vp]),

@@ -189,9 +189,8 @@ def _workspace(device, nbytes):
 # (profiles/r02_ticket_single_launch.txt) and 2-3 us more where the kernel is busy -- but tensors of up to 8 MB are HOST-bound
 # in eager mode, and there one launch less is 11-15 % of the forward + backward wall time (profiles/r03_ticket_sizes.txt:
 # fp32 up to 2^21 elements, bf16 up to 2^22; +14 % at the next size up).  So the default is "auto": per-tensor backward of at
-# most _TICKET_AUTO_BYTES through a ticket, everything else through kernel + finalize.  TORCHLSQ_SINGLE_LAUNCH_BACKWARD=1 /
+# most 8 MB (lsq_hip_policy_ticket) through a ticket, everything else through kernel + finalize.  TORCHLSQ_SINGLE_LAUNCH_BACKWARD=1 /
 # set_single_launch_backward(True): always; =0 / False: never.
-_TICKET_AUTO_BYTES = 8 << 20
 _TICKET_MODES = {"0": 0, "1": 1, "auto": 2}
 _SINGLE_LAUNCH_BWD = [_TICKET_MODES.get(os.environ.get("TORCHLSQ_SINGLE_LAUNCH_BACKWARD", "auto").lower(), 2)]    # 0 never, 1 always, 2 auto
 
@@ -205,9 +204,15 @@ def set_single_launch_backward(on):
         torch.ops.torchlsq_native._set_single_launch_backward(mode)
 
 
-def _wants_ticket(nbytes):
-    mode = _SINGLE_LAUNCH_BWD[0]
-    return mode == 1 or (mode == 2 and nbytes <= _TICKET_AUTO_BYTES)
+def _wants_ticket(nbytes, per_channel=False):
+    """the decision itself is the library's (lsq_hip_policy_ticket: one rule for both host layers); the mode is this layer's state"""
+    return bool(_abi._LIB.lsq_hip_policy_ticket(_SINGLE_LAUNCH_BWD[0], 1 if per_channel else 0, nbytes))
+
+
+def saves_mask(eval_mode, init_mode, input_requires_grad, mask_backward):
+    """does an autograd node's forward save the one-byte inside mask instead of x?  (lsq_hip_policy_saves_mask)"""
+    return bool(_abi._LIB.lsq_hip_policy_saves_mask(int(bool(eval_mode)), int(bool(init_mode)), int(bool(input_requires_grad)),
+                                                    int(bool(mask_backward))))
 
 
 _TICKET_SLOTS = 64
@@ -455,7 +460,7 @@ def hip_backward_per_channel(grad, x, scale, shift, axis, qmin, qmax, tmin, tmax
     ws = _workspace(dev, nbytes)
     stream = _stream_of(idx)
     if use_ticket is None:
-        use_ticket = _SINGLE_LAUNCH_BWD[0] == 1      # (the per-channel entry point takes a ticket and ignores it)
+        use_ticket = _wants_ticket(xd.numel() * xd.element_size(), per_channel=True)   # (mode "always" only: the entry point ignores it)
     fn, tail = _entry("lsq_hip_backward_per_channel", variant)
     rc = _on_device(idx, fn, code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(),
                     ds.data_ptr(), db.data_ptr(), wide.data_ptr() if want_wide else None, outer, C, inner,

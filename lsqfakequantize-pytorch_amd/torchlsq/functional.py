@@ -36,7 +36,7 @@ class _LSQOnDevice(torch.autograd.Function):
         # LSQFakeQuantizer does on every call (observers.py:417-420).  `mask_backward=False` (what the module passes
         # while its observer is enabled) keeps the reference's behaviour: x is saved and the eval backward runs on the
         # current parameters.  (The C++ host binding's LsqNode has the same switch.)
-        masked = eval_mode and not init_mode and x.requires_grad and mask_backward
+        masked = _E.saves_mask(eval_mode, init_mode, x.requires_grad, mask_backward)
         if per_channel:
             y = _E.hip_forward_per_channel(x, scale, shift, axis, qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode,
                                            init_mode, want_mask=masked)

@@ -88,8 +88,32 @@ def test_streaming_hint_above_32_mb(T, dtype):
     esz = 4 if dtype == torch.float32 else 2
     lo, hi = _rows(32 * MB // esz + 1, 2048 * 7)        # NCHW-style windows: [rows, 2048, 7] quantized on axis 1
     (_, b_lo), (_, b_hi) = _case(T, (lo, 2048, 7), 1, dtype, (-8, 7, -128, 127)), _case(T, (hi, 2048, 7), 1, dtype, (-8, 7, -128, 127))
-    assert b_lo["kind"] == b_hi["kind"] == "windows" and b_lo["ring_depth"] == b_hi["ring_depth"] == 4
+    # (fp32: 32 MB is also the 2^23 elements up to which such a tensor takes owner windows -- test_owner_windows_band)
+    assert b_lo["kind"] in ("windows", "owners") and b_hi["kind"] == "windows" and b_lo["ring_depth"] == b_hi["ring_depth"] == 4
     assert (b_lo["ring_nt"], b_hi["ring_nt"]) == (0, 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_owner_windows_band(T, dtype):
+    """NCHW activations with short channel rows, up to 2^23 elements: OWNER windows -- a fat workgroup owns k whole channels
+    (the smallest count whose run is whole 16-byte packets) for ALL rows, stores d_scale / d_shift itself, one launch, no
+    workspace (profiles/r04_owner_windows_ab.txt: -7 .. -45 % there); above 2^23 elements, with too few owners for the chip,
+    or with channel rows longer than 256 lanes: the 256-lane windows + finalize launch as before"""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    k = 8 if dtype == torch.bfloat16 else 4                          # 7 x 7 = 49 elements per channel row
+    lo, hi = _rows((1 << 23) + 1, 2048 * 49)
+    (_, a), (_, b) = _case(T, (lo, 2048, 7, 7), 1, dtype, (-8, 7, -128, 127)), _case(T, (hi, 2048, 7, 7), 1, dtype, (-8, 7, -128, 127))
+    assert a["kind"] == "owners" and b["kind"] == "windows", (a, b)
+    assert a["grid_x"] == 2048 // k and a["grid_y"] == 1 and a["block"] <= 512 and a["ring_depth"] == 4, a
+    # few rows: thinner workgroups (fewer row slots), still one launch
+    (_, c) = _case(T, (16, 2048, 7, 7), 1, dtype, (-8, 7, -128, 127))
+    assert c["kind"] == "owners" and c["block"] < a["block"], (a, c)
+    # too few owners to cover the chip (512 channels / k): windows
+    (_, d) = _case(T, (64, 512, 7, 7), 1, dtype, (-8, 7, -128, 127))
+    assert d["kind"] == "windows" and (512 // k) * 4 < 3 * cus, d
+    # long channel rows (56 x 56): windows
+    (_, e) = _case(T, (8, 256, 56, 56), 1, dtype)
+    assert e["kind"] == "windows", e
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -128,7 +152,8 @@ def test_row_groups_give_way_to_windows_at_512_mb(T, dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_ring_needs_as_many_row_tiles_as_stages(T, dtype):
     """a workgroup that would walk fewer row tiles than the ring is deep runs the register loops"""
-    (_, a), (_, b) = _case(T, (32, 2048, 7, 7), 1, dtype, (-8, 7, -128, 127)), _case(T, (256, 2048, 7, 7), 1, dtype, (-8, 7, -128, 127))
+    # ((32, 512, 7, 7): too few channels for owner windows, test_owner_windows_band)
+    (_, a), (_, b) = _case(T, (32, 512, 7, 7), 1, dtype, (-8, 7, -128, 127)), _case(T, (256, 2048, 7, 7), 1, dtype, (-8, 7, -128, 127))
     assert a["kind"] == b["kind"] == "windows"
     assert a["ring_depth"] == 0 and b["ring_depth"] == 4, (a, b)
     assert 32 / a["grid_y"] < 4 <= 256 / b["grid_y"]

@@ -33,7 +33,7 @@ def internal_abi():
            ("lsq_hip_forward_per_tensor", "lsq_hip_backward_per_tensor", "lsq_hip_forward_per_channel",
             "lsq_hip_backward_per_channel")}
     for n in ("force_ring", "set_ww_min_rows", "set_ww_split64", "set_ww_big", "set_ring_nt", "set_fin_ch",
-              "set_observe_wg_per_cu", "set_ww_max_log2", "set_seg_min_div", "set_fwd_direct", "set_seg_no_up_front"):
+              "set_observe_wg_per_cu", "set_ww_max_log2", "set_seg_min_div", "set_fwd_direct", "set_seg_no_up_front", "set_own"):
         tab["lsq_hip_debug_" + n] = (None, [_int])
     tab["lsq_hip_debug_last_launch"] = (None, [ctypes.POINTER(ctypes.c_int * 8)])
     return tab
@@ -60,9 +60,23 @@ def activate(path=TOOLS_LIB):
     if _state["saved"] is None:
         _state["saved"] = (E.library(), E.host_binding())
     E.set_library(_state["lib"])
-    E._WS_BYTES_PC.clear()           # the tools build sizes the scratch for every variant: do not reuse production answers
+    _drop_memos()                    # the tools build sizes the scratch for every variant: do not reuse production answers
     E.set_host_binding("ctypes")
     return _state["lib"]
+
+
+def _drop_memos():
+    """per-shape answers the Python host layer keeps (workspace sizes, multi-tensor eligibility) depend on the library and on
+    its policy knobs (set_seg_min_div, ...): forget them whenever either changes"""
+    from torchlsq import _hip_host
+    _hip_host._WS_BYTES_PC.clear()
+    _hip_host._MULTI_OK.clear()
+
+
+def set_knob(name, value):
+    """lsq_hip_debug_<name>(value) on the active tools library + forget the host layer's memoised policy answers"""
+    getattr(_state["lib"], "lsq_hip_debug_" + name)(int(value))
+    _drop_memos()
 
 
 def deactivate():
@@ -70,7 +84,7 @@ def deactivate():
     if _state["saved"] is not None:
         reset_knobs()
         E.set_library(_state["saved"][0])
-        E._WS_BYTES_PC.clear()
+        _drop_memos()
         if _state["saved"][1] == "native":
             E.set_host_binding("native")
         _state["saved"] = None
@@ -80,11 +94,12 @@ def reset_knobs():
     lib = _state["lib"]
     if lib is not None:
         for n in ("force_ring", "set_ww_min_rows", "set_ww_split64", "set_ww_big", "set_ring_nt", "set_fin_ch",
-                  "set_observe_wg_per_cu", "set_ww_max_log2", "set_seg_min_div", "set_fwd_direct", "set_seg_no_up_front"):
+                  "set_observe_wg_per_cu", "set_ww_max_log2", "set_seg_min_div", "set_fwd_direct", "set_seg_no_up_front", "set_own"):
             getattr(lib, "lsq_hip_debug_" + n)(0)
+        _drop_memos()
 
 
-KINDS = {0: "none", 1: "windows", 2: "row-groups", 3: "segment"}
+KINDS = {0: "none", 1: "windows", 2: "row-groups", 3: "segment", 4: "owners"}
 
 
 def last_launch():
