@@ -364,6 +364,7 @@ struct LaneSite {
     int32_t row_in_tile;
     bool live;
     int64_t c_lo;  // first channel of the window
+    bool counts;   // the lane's sums count (== live, except the stand-in lanes of owner windows: they walk, store duplicates, add nothing)
 };
 __device__ __forceinline__ LaneSite lane_site(const PcGeom& g, int V) {
     LaneSite s;
@@ -381,6 +382,7 @@ __device__ __forceinline__ LaneSite lane_site(const PcGeom& g, int V) {
         s.live = s.row_in_tile < g.R;
         s.c_lo = 0;
     }
+    s.counts = s.live;
     return s;
 }
 
@@ -391,8 +393,13 @@ __device__ __forceinline__ LaneSite lane_site_own(const PcGeom& g, int V) {
     const uint32_t slot = threadIdx.x / lanes;
     const int64_t j = own_window(g);
     s.p0 = j * g.wpos + static_cast<int64_t>(threadIdx.x - slot * lanes) * V;
-    s.row_in_tile = static_cast<int32_t>(slot);
-    s.live = static_cast<int32_t>(slot) < g.R;
+    // The lanes past the last row slot (the workgroup is whole waves) are STAND-INS of the last row slot's lanes: they walk its
+    // rows, compute and store the very same bytes a second time, and their sums are dropped.  Every wave so runs the loop's fast
+    // form (all lanes valid for all rows); with idle lanes the last wave took the generic row-at-a-time loop, whose waits are
+    // longer -- and an owner workgroup, alone on its CU for the whole launch, is as slow as its slowest wave.
+    s.counts = static_cast<int32_t>(slot) < g.R;
+    s.row_in_tile = s.counts ? static_cast<int32_t>(slot) : g.R - 1;
+    s.live = true;
     s.c_lo = j * g.k_slots;
     return s;
 }
@@ -407,6 +414,7 @@ __device__ __forceinline__ LaneSite lane_site_ww(const PcGeom& g, int V, int32_t
     s.p0 = base + static_cast<int64_t>(lane_in_group) * V;
     s.row_in_tile = static_cast<int32_t>(rg);
     s.live = static_cast<int32_t>(rg) < g.R && s.p0 < g.L;
+    s.counts = s.live;
     s.c_lo = base;     // inner == 1: position == channel
     return s;
 }

@@ -932,7 +932,7 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
         // travel one lane up and join that lane's run: ONE segmented reduction instead of two.  Only
         // the last lane of a wave / of a row has no neighbour and adds its second channel itself.
         const int lane = threadIdx.x & 63;
-        const bool has_hi = site.live && ch.split < V;
+        const bool has_hi = site.counts && ch.split < V;
         double lo_s = 0.0, lo_b = 0.0, hi_s = 0.0, hi_b = 0.0;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
@@ -943,7 +943,7 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
             hi_b += hi ? acc_b[j] : 0.0;
         }
         const int key_hi = has_hi ? ch.key[LC::N - 1] : -1;
-        const int next_key0 = __shfl_down(site.live ? ch.key[0] : -2, 1, 64);
+        const int next_key0 = __shfl_down(site.counts ? ch.key[0] : -2, 1, 64);
         const bool handoff = has_hi && lane < 63 && next_key0 == key_hi;
         const double give_s = handoff ? hi_s : 0.0, give_b = handoff ? hi_b : 0.0;
         const double got_s = shfl_up_f64(give_s, 1), got_b = shfl_up_f64(give_b, 1);
@@ -952,12 +952,12 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
             __hip_atomic_fetch_add(&lds_s[key_hi], hi_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (!SYM) __hip_atomic_fetch_add(&lds_b[key_hi], hi_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        segmented_wave_accumulate<SYM>(site.live ? ch.key[0] : -1, lo_s, lo_b, lds_s, lds_b);
+        segmented_wave_accumulate<SYM>(site.counts ? ch.key[0] : -1, lo_s, lo_b, lds_s, lds_b);
     } else {
         // lanes -> window slots.  Dead lanes carry key -1 (never written).
 #pragma unroll
         for (int j = 0; j < LC::N; ++j)
-            segmented_wave_accumulate<SYM>(site.live ? ch.key[j] : -1, acc_s[j], acc_b[j], lds_s, lds_b);
+            segmented_wave_accumulate<SYM>(site.counts ? ch.key[j] : -1, acc_s[j], acc_b[j], lds_s, lds_b);
     }
     __syncthreads();
     if constexpr (OWN) {

@@ -41,6 +41,7 @@ def build():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--build", action="store_true")
+    ap.add_argument("--own", action="store_true", help="config 5 (bf16, fp32) and a small tensor as OWNER windows (lsq_hip_debug_set_own(1)) next to the 256-lane windows")
     a = ap.parse_args()
     if a.build:
         build()
@@ -59,8 +60,19 @@ def main():
              ("[32,256,56,56] bf16 axis 1", (32, 256, 56, 56), 1, torch.bfloat16, (-8, 7, -128, 127)),
              ("vit bf16 [64,197,768] axis 2", (64, 197, 768), 2, torch.bfloat16, (0, 127, 0, 255)),
              ("vit fp32 [64,197,768] axis 2", (64, 197, 768), 2, torch.float32, (0, 127, 0, 255))]
+    if a.own:
+        base_cases = [("cfg5 bf16 [256,2048,7,7] axis 1", (256, 2048, 7, 7), 1, torch.bfloat16, (-8, 7, -128, 127)),
+                      ("cfg5 fp32 [256,2048,7,7] axis 1", (256, 2048, 7, 7), 1, torch.float32, (-8, 7, -128, 127)),
+                      ("[64,2048,7,7] bf16 axis 1", (64, 2048, 7, 7), 1, torch.bfloat16, (-8, 7, -128, 127))]
+        cases = []
+        for c_ in base_cases:
+            cases.append(("WINDOWS " + c_[0],) + c_[1:] + (2,))
+            cases.append(("OWNERS  " + c_[0],) + c_[1:] + (1,))
+    else:
+        cases = [c_ + (0,) for c_ in cases]
     print("# tools/exp_timeline.py: per-wave shader-clock stamps of the window-mode backward (one launch, cold inputs); us")
-    for name, shape, axis, dtype, q in cases:
+    for name, shape, axis, dtype, q, own in cases:
+        lsq_tools.set_knob("set_own", own)
         n = int(np.prod(shape))
         esz = 2 if dtype == torch.bfloat16 else 4
         K = max(2, -(-(600 << 20) // (2 * n * esz)))

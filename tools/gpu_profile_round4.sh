@@ -46,4 +46,6 @@ for CTR in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc_own_$CTR
 done
 cat $O/r04_owner_pattern_probe_pmc.txt
+python3 tools/exp_timeline.py --build > /dev/null 2>&1      # the -DLSQ_TIMELINE experiment build is not shipped: made here (~1 min)
+python3 tools/exp_timeline.py --own 2>/dev/null > $O/r04_owner_timeline.txt; grep -E "^##|busy span|per row|epilogue" $O/r04_owner_timeline.txt | cut -c1-220
 fi
