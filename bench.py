@@ -667,6 +667,18 @@ def run_rank(a):
                 del scratch
             except Exception as e:      # context only: never let it break the bench line
                 line["roofline"]["same_box_reference_kernels"] = {"error": repr(e)}
+        if world == 1 and binding == "native" and not a.graph and not a.no_secondary:
+            # north_star describes Python host code over the thin C ABI; the timed region above ran the C++ host binding (same C
+            # entry points, less host time per call).  The same workload through the Python / ctypes host layer, 20 steps:
+            try:
+                pm = measure(a.workload, 20, 5, buffers=1 if set_bytes * 2 > (1 << 30) else a.buffers, ops=ops_of["ctypes"])
+                line["config"]["python_ctypes_host_layer"] = {
+                    "ms_per_step": round(pm["elapsed_max"] / pm["steps"] * 1e3, 5),
+                    "value": round(pm["n_global"] * pm["steps"] / pm["elapsed_max"] / 1e9, 3), "steps": pm["steps"],
+                    "note": "torch.ops.torchlsq.* (torch.library registration in Python -> ctypes -> the same C ABI and kernels)"}
+                del pm
+            except Exception as e:      # context only
+                line["config"]["python_ctypes_host_layer"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(shape, a.workload)
         if world == 1 and a.workload == "cfg2" and not a.graph and not a.no_secondary:

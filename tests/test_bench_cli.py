@@ -74,6 +74,9 @@ def test_default_line_carries_the_per_channel_half():
         assert "error" not in s and s["value"] > 0 and 0 < s["step_frac"] < 1, s
         assert s["launch"] == ("graph" if name.endswith("_graph") else "eager")
     assert "ms_per_step_ctypes_binding" in sec["cfg1"] and sec["cfg5_bf16"]["storage"] == "bfloat16"
+    # the headline workload through the Python / ctypes host layer north_star describes, next to the C++ binding's figure
+    py = out["config"]["python_ctypes_host_layer"]
+    assert out["config"]["host_binding"] == "native" and py["value"] > 0.9 * out["value"], (py, out["value"])
     # BASELINE config 4's per-GPU shard: the step one rank of the 8-GPU job runs, the denominator of the 0.9x target
     assert sec["cfg4_shard"]["shape"] == [128, 1024, 14, 14] and "what" in sec["cfg4_shard"]
     # 50 weight quantizers in one launch each way stream far better than 50 latency-bound single calls
