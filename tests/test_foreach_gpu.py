@@ -189,3 +189,93 @@ def test_foreach_random_weight_lists(seed):
                         what, i, shapes[i], dtype, mode, binding)
     finally:
         E.set_host_binding(saved)
+
+
+@pytest.mark.parametrize("binding", ["native", "ctypes"])
+@pytest.mark.parametrize("init_mode", [False, True])
+def test_unused_outputs_of_a_fused_call_get_no_gradients(binding, init_mode):
+    """an output nobody used has no upstream gradient: its tensor takes no part in the backward launch and gets NO gradients,
+    exactly what N separate lsq calls give it -- with init_mode the parameter gradients ignore the upstream gradient
+    (lsq_kernel.h:116), so a zero-filled stand-in would have invented d_scale / d_shift for it"""
+    from torchlsq import extension as E
+    from torchlsq.functional import lsq, lsq_foreach
+    if binding == "native" and E.native_lsq() is None:
+        pytest.skip("the C++ binding is not built")
+    dev = torch.device("cuda:0")
+    saved = E.host_binding()
+    E.set_host_binding(binding)
+    try:
+        shapes = [(64, 64, 3, 3), (128, 64, 3, 3), (96, 256)]
+        xs, gs, ss, bs = _weights(shapes, torch.float32, dev, 77)
+        kw = dict(quant_min=-128, quant_max=127, type_min=-128, type_max=127, is_affine=True, init_mode=init_mode)
+
+        def run(fused):
+            xl = [x.clone().requires_grad_(True) for x in xs]
+            sl = [s.clone().requires_grad_(True) for s in ss]
+            bl = [b.clone().requires_grad_(True) for b in bs]
+            ys = lsq_foreach(xl, sl, bl, axis=0, **kw) if fused else [lsq(x, s, b, axis=0, is_perchannel=True, **kw) for x, s, b in zip(xl, sl, bl)]
+            torch.autograd.backward([ys[0], ys[2]], [gs[0], gs[2]])         # output 1 is never used
+            torch.cuda.synchronize()
+            return xl, sl, bl
+        fx, fs, fb = run(True)
+        ex, es, eb = run(False)
+        assert fx[1].grad is None and fs[1].grad is None and fb[1].grad is None
+        assert ex[1].grad is None and es[1].grad is None
+        for i in (0, 2):
+            assert _bits(fx[i].grad) == _bits(ex[i].grad) and _bits(fs[i].grad) == _bits(es[i].grad) and _bits(fb[i].grad) == _bits(eb[i].grad)
+    finally:
+        E.set_host_binding(saved)
+
+
+def test_foreach_with_cpu_entries_takes_the_python_partition():
+    """a list with tensors in host memory: those go through `lsq` (liblsq_cpu.so), the GPU ones still fuse -- on either host layer"""
+    from torchlsq.functional import lsq, lsq_foreach
+    dev = torch.device("cuda:0")
+    xs, gs, ss, bs = _weights([(64, 64, 3, 3), (128, 64, 3, 3), (32, 16, 3, 3)], torch.float32, dev, 91)
+    xs[2], ss[2], bs[2] = xs[2].cpu(), ss[2].cpu(), bs[2].cpu()
+    kw = dict(quant_min=-128, quant_max=127, type_min=-128, type_max=127, is_affine=False)
+    ys = lsq_foreach(xs, ss, bs, axis=0, **kw)
+    assert ys[2].device.type == "cpu" and ys[0].is_cuda
+    for x, s, b, y in zip(xs, ss, bs, ys):
+        assert _bits(y) == _bits(lsq(x, s, b, axis=0, is_perchannel=True, **kw))
+
+
+def test_weight_group_results_are_dropped_when_stale_or_unused():
+    """LSQWeightGroup's stash is valid for exactly the weight and parameter VALUES it was computed from (Tensor._version): an
+    in-place update between prequantize() and the layer's call recomputes; whatever the layers did not pick up is dropped when
+    the model's forward ends, so the model stays deep-copyable and picklable"""
+    import copy
+    from torch.ao.quantization import QConfig
+    from torch.ao.quantization.observer import MovingAverageMinMaxObserver, MovingAveragePerChannelMinMaxObserver
+    from torchlsq.quantized import LSQFakeQuantizer, LSQWeightGroup
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    model = torch.nn.Sequential(torch.nn.Conv2d(16, 64, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(64, 64, 3, padding=1))
+    model.qconfig = QConfig(activation=LSQFakeQuantizer.with_args(observer=MovingAverageMinMaxObserver, otype="activation", init_batches=1),
+                            weight=LSQFakeQuantizer.with_args(observer=MovingAveragePerChannelMinMaxObserver, otype="weight", dtype=torch.qint8,
+                                                              qscheme=torch.per_channel_symmetric))
+    torch.ao.quantization.prepare_qat(model.train(), inplace=True)
+    model.to(dev)
+    x = torch.randn(4, 16, 12, 12, device=dev)
+    for _ in range(3):
+        model(x)
+    group = LSQWeightGroup(model, register_hook=False)
+    assert group.prequantize() == 2
+    wq = model[0].weight_fake_quant
+    stale = wq._prefetched[-1].detach().clone()
+    with torch.no_grad():
+        model[0].weight.mul_(1.5)                       # what optimizer.step() does: in place, bumps the version
+    fresh = wq(model[0].weight)
+    assert wq._prefetched is None and not torch.equal(fresh, stale)
+    plain = LSQFakeQuantizer.forward(wq, model[0].weight)
+    assert torch.equal(fresh, plain)
+    # with the hooks: a forward that leaves a result unused (here: we never call layer 2) must not leave it behind
+    group2 = LSQWeightGroup(model)
+    group2.prequantize()
+    assert model[2].weight_fake_quant._prefetched is not None
+    model(x)                                            # pre-hook stashes, layers consume, post-hook clears
+    assert all(q._prefetched is None for _, q in group2.pairs)
+    group2.prequantize()
+    group2.remove()
+    assert all(q._prefetched is None for _, q in group2.pairs)
+    copy.deepcopy(model)                                # no stashed non-leaf tensor in the way

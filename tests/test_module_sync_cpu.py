@@ -94,3 +94,30 @@ def test_sync_is_a_noop_outside_a_job_and_on_weights():
     c = copy.deepcopy(a)
     assert c._sync and c._group_ref is a._group_ref
     assert pickle.loads(pickle.dumps(a._group_ref)).group is None
+
+
+def test_prepare_ddp_lists_what_ddp_need_not_touch(oracle_cpu_backend):
+    import torch
+    from torch.ao.quantization import QConfig
+    from torch.ao.quantization.observer import MovingAverageMinMaxObserver, MovingAveragePerChannelMinMaxObserver
+    from torchlsq.quantized import LSQFakeQuantizer, prepare_ddp
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.ReLU())
+    model.qconfig = QConfig(activation=LSQFakeQuantizer.with_args(observer=MovingAverageMinMaxObserver, otype="activation"),
+                            weight=LSQFakeQuantizer.with_args(observer=MovingAveragePerChannelMinMaxObserver, otype="weight", dtype=torch.qint8,
+                                                              qscheme=torch.per_channel_symmetric))
+    torch.ao.quantization.prepare_qat(model.train(), inplace=True)
+    model(torch.randn(2, 3, 8, 8))
+    out = prepare_ddp(model)
+    assert out is model
+    ig = set(model._ddp_params_and_buffers_to_ignore)
+    names = dict(model.named_parameters())
+    names.update(dict(model.named_buffers()))
+    assert ig <= set(names), sorted(ig - set(names))                      # every entry is a real parameter / buffer name
+    act = [n for n, m in model.named_modules() if isinstance(m, LSQFakeQuantizer) and m.dtype == torch.quint8]
+    wgt = [n for n, m in model.named_modules() if isinstance(m, LSQFakeQuantizer) and m.dtype == torch.qint8]
+    assert act and wgt
+    for n in act:
+        assert {n + ".scale", n + ".shift", n + ".current_batch", n + ".activation_post_process.min_val"} <= ig
+        assert dict(model.named_modules())[n]._sync and dict(model.named_modules())[n]._sync_grads == "mean"
+    for n in wgt:            # weights: replicated input, DDP averages their gradients like any parameter's; only the flags are skipped
+        assert n + ".scale" not in ig and n + ".fake_quant_enabled" in ig and not dict(model.named_modules())[n]._sync

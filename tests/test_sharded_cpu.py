@@ -25,7 +25,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, per_channel, out_q, bounds=None):
+def _worker(rank, world, port, per_channel, out_q, bounds=None, collective=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -70,7 +70,7 @@ def _worker(rank, world, port, per_channel, out_q, bounds=None):
             extra = {}
         else:                    # UNEVEN shards (one of them may be empty): the caller states the global element count
             sl = slice(bounds[rank], bounds[rank + 1])
-            extra = dict(global_numel=n)
+            extra = dict(global_numel="collective" if collective else n)     # COLLECTIVE: the count rides in the all-reduce
         xs = x[sl].clone().requires_grad_(True)
         ss = scale.clone().requires_grad_(True)
         bs = shift.clone().requires_grad_(True)
@@ -117,5 +117,24 @@ def test_uneven_shards_explicit_global_numel_gloo_world4(per_channel):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1, 2, 3]
+    for rank, ok, ncalls, err in res:
+        assert ok, "rank %d: sharded != unsharded (all_reduce calls %d, max |ds err| %g)" % (rank, ncalls, err)
+
+
+@pytest.mark.parametrize("per_channel", [False, True])
+def test_uneven_shards_count_in_the_collective_gloo_world4(per_channel):
+    """the same 5 / 1 / 3 / 2 rows with global_numel=COLLECTIVE: no rank is told the total; the element count is summed in the
+    ONE all-reduce and the scaler derived from it (lsq_cpu_sharded_finish) -- still one collective per backward, same result"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    bounds = (0, 5, 6, 9, 11)
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, per_channel, q, bounds, True)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
     for rank, ok, ncalls, err in res:
         assert ok, "rank %d: sharded != unsharded (all_reduce calls %d, max |ds err| %g)" % (rank, ncalls, err)
