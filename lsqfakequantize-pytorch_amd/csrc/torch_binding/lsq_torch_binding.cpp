@@ -531,6 +531,7 @@ class LsqForeachNode : public torch::autograd::Function<LsqForeachNode> {
         torch::autograd::variable_list ys = forward_per_channel_multi(tensors.slice(0, n), tensors.slice(n, n), tensors.slice(2 * n, n), axes,
                                                                       qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode);
         ctx->save_for_backward(tensors.vec());
+        ctx->set_materialize_grads(false);      // an unused output arrives undefined in backward, not as a zero tensor
         const int64_t flags = (use_gs ? 1 : 0) | (sym ? 2 : 0) | (eval_mode ? 8 : 0) | (init_mode ? 16 : 0);
         ctx->saved_data["cfg"] = c10::IValue(std::vector<int64_t>{qmin, qmax, tmin, tmax, flags});
         ctx->saved_data["axes"] = c10::IValue(axes);

@@ -233,6 +233,7 @@ class _LSQForeach(torch.autograd.Function):
                                               init_mode)
         ctx.save_for_backward(*tensors)
         ctx.cfg, ctx.n = cfg, n
+        ctx.set_materialize_grads(False)        # an unused output arrives as None in backward, not as a zero tensor
         return tuple(ys)
 
     @staticmethod
