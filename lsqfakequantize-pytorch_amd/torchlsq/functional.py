@@ -217,7 +217,8 @@ def lsq_quantize(x: Tensor, scale: Tensor, shift: Tensor,
     int_repr = levels.view(torch.uint8) if dtype == torch.quint8 else levels        # the byte is q mod 256 either way
     if is_perchannel:
         return torch._make_per_channel_quantized_tensor(int_repr, s.to(torch.float64), zp.to(torch.int64), axis)
-    return torch._make_per_tensor_quantized_tensor(int_repr, float(s[0]), int(zp[0]))
+    s0, zp0 = torch.stack([s[0].double(), zp[0].double()]).tolist()          # the quantizer wants host numbers: ONE read-back
+    return torch._make_per_tensor_quantized_tensor(int_repr, s0, int(zp0))
 
 
 class _LSQForeach(torch.autograd.Function):

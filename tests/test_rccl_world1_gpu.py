@@ -1,0 +1,84 @@
+"""GPU: the collectives of the sharded path executed by RCCL itself (backend "nccl" on ROCm) -- with the ONE rank a 1-GPU box
+can give it.  A world of one makes every all-reduce an identity, which is exactly what lets the result be checked: with
+torchlsq.distributed told to communicate as if there were peers, the sharded op must equal the plain op on the same tensor.
+What this pins that the gloo tests cannot: ProcessGroupNCCL accepts the buffers this code hands it (fp64 SUM of 2C+1 slots,
+fp32 MIN of the packed [min, -max]), on the stream the kernels run on, with async_op handles consumed a step later as bench.py
+does -- the call sequence the 8-GPU job makes on every rank."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+CODE = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%(root)r, "lsqfakequantize-pytorch_amd"))
+import torch, torch.distributed as dist
+import torchlsq
+from torchlsq import distributed as D, synth
+from torchlsq.functional import lsq
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+calls = {"n": 0}
+real = dist.all_reduce
+def counting(*a, **k):
+    calls["n"] += 1
+    return real(*a, **k)
+dist.all_reduce = counting
+D._world = lambda group: 2 if os.environ.get("PRETEND_PEERS") == "1" else 1     # communicate as if there were peers
+os.environ["PRETEND_PEERS"] = "1"
+ok = True
+for per_channel in (False, True):
+    for dtype in (torch.float32, torch.bfloat16):
+        shape = (32, 256, 14, 14)
+        n = 32 * 256 * 14 * 14
+        x = synth.normal_like(n, 3, 0.3, 1.0, dtype=dtype, device=dev).view(shape)
+        g = synth.normal_like(n, 4, 0.0, 1e-2, dtype=dtype, device=dev).view(shape).abs()
+        if per_channel:
+            scale, shift = synth.uniform_like(256, 5, 0.05, 0.3, device=dev), synth.normal_like(256, 6, 0.0, 0.1, device=dev)
+            kw = dict(quant_min=-8, quant_max=7, type_min=-128, type_max=127, axis=1, is_perchannel=True)
+        else:
+            scale, shift = torch.tensor([0.03], device=dev), torch.tensor([0.05], device=dev)
+            kw = dict(quant_min=0, quant_max=127, type_min=0, type_max=255)
+        xf, sf, bf = x.clone().requires_grad_(True), scale.clone().requires_grad_(True), shift.clone().requires_grad_(True)
+        lsq(xf, sf, bf, **kw).backward(g)
+        for mode in (D.COLLECTIVE, n):          # the count in the collective / known up front
+            xs, ss, bs = x.clone().requires_grad_(True), scale.clone().requires_grad_(True), shift.clone().requires_grad_(True)
+            before = calls["n"]
+            D.lsq_sharded(xs, ss, bs, global_numel=mode, **kw).backward(g)
+            torch.cuda.synchronize()
+            good = (torch.equal(xs.grad, xf.grad) and torch.allclose(ss.grad, sf.grad, rtol=2e-6, atol=0) and
+                    torch.allclose(bs.grad, bf.grad, rtol=2e-6, atol=1e-12) and calls["n"] - before == 1)
+            ok = ok and good
+            print(per_channel, dtype, mode if mode == D.COLLECTIVE else "int", good, calls["n"] - before, flush=True)
+# bench.py's pattern: the collective issued async, consumed one step later
+pending = None
+for step in range(4):
+    dx, wide, work = D.sharded_backward(g, x, scale, shift, -8, 7, -128, 127, 1, True, 1.0, True, True, False, False, None, n, async_op=True)
+    if pending is not None:
+        pending[1].wait()
+        _ = pending[0].to(torch.float32)
+    pending = (wide, work)
+pending[1].wait()
+torch.cuda.synchronize()
+ok = ok and torch.isfinite(pending[0]).all().item()
+# the observer statistics' packed MIN all-reduce
+lo, hi = torch.tensor([-1.5, 0.25], device=dev), torch.tensor([2.0, 0.75], device=dev)
+a, b = D.all_reduce_minmax(lo, hi, None)
+torch.cuda.synchronize()
+ok = ok and torch.equal(a, lo) and torch.equal(b, hi)
+dist.destroy_process_group()
+print("RESULT", "ok" if ok else "FAILED", flush=True)
+'''
+
+
+def test_sharded_path_over_rccl_world_of_one():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", CODE % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "RESULT ok" in r.stdout, r.stdout[-3000:]
