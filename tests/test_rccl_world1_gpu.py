@@ -71,6 +71,33 @@ lo, hi = torch.tensor([-1.5, 0.25], device=dev), torch.tensor([2.0, 0.75], devic
 a, b = D.all_reduce_minmax(lo, hi, None)
 torch.cuda.synchronize()
 ok = ok and torch.equal(a, lo) and torch.equal(b, hi)
+# the drop-in module with rank sync, told it has a peer: observer-driven init batches (fused statistics -> packed MIN all-reduce
+# -> one-launch observer tail) and LSQ steps (count in the collective) must reproduce the plain module call for call
+from torch.ao.quantization.observer import MovingAverageMinMaxObserver, MovingAveragePerChannelMinMaxObserver
+from torchlsq.quantized import LSQFakeQuantizer
+from torchlsq.quantized.modules import observers as OBS
+OBS._dist_world = lambda group: 2
+for obs_cls, extra in ((MovingAverageMinMaxObserver, {}), (MovingAveragePerChannelMinMaxObserver, dict(qscheme=torch.per_channel_affine, ch_axis=1))):
+    a = LSQFakeQuantizer(obs_cls, "activation", init_batches=2, sync=True, **extra).train()
+    p = LSQFakeQuantizer(obs_cls, "activation", init_batches=2, **extra).train()
+    for i in range(6):
+        xi = synth.normal_like(8 * 16 * 6 * 6, 50 + i, 0.8, 1.0, device=dev).view(8, 16, 6, 6)
+        wi = synth.normal_like(8 * 16 * 6 * 6, 70 + i, 0.0, 1.0, device=dev).view(8, 16, 6, 6)
+        xa, xp = xi.clone().requires_grad_(True), xi.clone().requires_grad_(True)
+        before = calls["n"]
+        ya, yp = a(xa), p(xp)
+        if i == 0:
+            a.to(dev); p.to(dev)
+        if ya.requires_grad:
+            for m in (a, p):
+                m.scale.grad = None; m.shift.grad = None
+            (ya * wi).sum().backward(); (yp * wi).sum().backward()
+        torch.cuda.synchronize()
+        good = torch.equal(ya.detach(), yp.detach()) and torch.equal(a.scale, p.scale) and torch.equal(a.shift, p.shift)
+        if a.scale.grad is not None and p.scale.grad is not None:
+            good = good and torch.allclose(a.scale.grad, p.scale.grad, rtol=2e-5, atol=1e-12) and torch.allclose(a.shift.grad, p.shift.grad, rtol=2e-5, atol=1e-10)
+        ok = ok and good
+        print("module", obs_cls.__name__, "call", i, good, "collectives", calls["n"] - before, flush=True)
 dist.destroy_process_group()
 print("RESULT", "ok" if ok else "FAILED", flush=True)
 '''
