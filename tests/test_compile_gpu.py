@@ -132,3 +132,21 @@ def test_inductor_compiled_block_with_fake_quantizers_in_steady_state():
     assert len(g) == len(g_ref) and len(g) >= 5        # x, conv weight + bias, activation scale/shift, weight scale
     for a, c in zip(g, g_ref):
         assert torch.allclose(a, c, rtol=1e-5, atol=1e-6)   # conv backward algorithms may differ between graphs
+
+
+def test_inductor_compiled_levels_only_op_equals_eager():
+    """the conversion-time op (int8 levels alone, y == NULL underneath) as an extern call inside a compiled graph"""
+    from torchlsq import synth
+    dev = torch.device("cuda:0")
+    x = synth.normal_like(8 * 32 * 14 * 14, 9, 0.4, 1.0, device=dev).view(8, 32, 14, 14)
+    s, b = synth.uniform_like(32, 5, 0.02, 0.2, device=dev), synth.normal_like(32, 6, 0.0, 0.1, device=dev)
+
+    def f(x, s, b):
+        h = x * 2.0
+        q_pt = torch.ops.torchlsq.lsq_levels_per_tensor(h, s[:1], b[:1], 0, 255, 0, 255, 0)
+        q_pc = torch.ops.torchlsq.lsq_levels_per_channel(h, s, b, 1, -8, 7, -128, 127, 0)
+        return q_pt.to(torch.int16) + q_pc.to(torch.int16)
+
+    ref = f(x, s, b)
+    out = torch.compile(f, backend="inductor", fullgraph=True)(x, s, b)
+    assert out.dtype == torch.int16 and torch.equal(out, ref)
