@@ -394,7 +394,8 @@ __device__ __forceinline__ LaneSite lane_site_own(const PcGeom& g, int V) {
     const int64_t j = own_window(g);
     s.p0 = j * g.wpos + static_cast<int64_t>(threadIdx.x - slot * lanes) * V;
     // The lanes past the last row slot (the workgroup is whole waves) are STAND-INS of the last row slot's lanes: they walk its
-    // rows, compute and store the very same bytes a second time, and their sums are dropped.  Every wave so runs the loop's fast
+    // rows and compute the very same values a second time; their stores are masked off and their sums dropped (a duplicate
+    // store is not merged with the original's: measured +10 % HBM write traffic).  Every wave so runs the loop's fast
     // form (all lanes valid for all rows); with idle lanes the last wave took the generic row-at-a-time loop, whose waits are
     // longer -- and an owner workgroup, alone on its CU for the whole launch, is as slow as its slowest wave.
     s.counts = static_cast<int32_t>(slot) < g.R;

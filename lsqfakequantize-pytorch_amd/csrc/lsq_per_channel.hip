@@ -705,7 +705,8 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
                 }
             }
         }
-        if (valid) store_elems<IO, V, NTS>(dx, e, out);
+        // (owner windows: the stand-in lanes past the last row slot computed a row another lane stores)
+        if (valid && (!OWN || site.counts)) store_elems<IO, V, NTS>(dx, e, out);
     };
     auto emit_row = [&](int64_t oo, const E (&gi)[V], const E (&xi)[V], bool valid) {
         emit_row_at(oo * g.L + site.p0, gi, xi, valid, std::false_type{});
