@@ -46,6 +46,18 @@ for CTR in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc_own_$CTR
 done
 cat $O/r04_owner_pattern_probe_pmc.txt
+# SQ counters of the owner kernel next to the 256-lane-window kernel on config 5 (same driver, both kernels in one run)
+: > $O/r04_sq_counters_owner_vs_windows.txt
+i=0
+for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  for DT in bf16 f32; do
+    rocprofv3 --pmc $SET --kernel-trace -d $O/sq_${DT}_$i -o o -- python3 tools/exp_knob_ab.py set_own 1 2 $DT 256x2048x7x7@1 > /dev/null 2>&1
+    echo "## $DT [256,2048,7,7] axis 1: bwd_pc_kernel<..., 512> = owner windows, <..., 256> = 256-lane windows" >> $O/r04_sq_counters_owner_vs_windows.txt
+    python3 tools/rocprof_summary.py $O/sq_${DT}_$i --pmc | grep -E "^(SQ_|GRBM)" | grep "bwd_pc_kernel" | cut -c1-175 >> $O/r04_sq_counters_owner_vs_windows.txt
+    rm -rf $O/sq_${DT}_$i
+  done
+done
 python3 tools/exp_timeline.py --build > /dev/null 2>&1      # the -DLSQ_TIMELINE experiment build is not shipped: made here (~1 min)
 python3 tools/exp_timeline.py --own 2>/dev/null > $O/r04_owner_timeline.txt; grep -E "^##|busy span|per row|epilogue" $O/r04_owner_timeline.txt | cut -c1-220
 fi
