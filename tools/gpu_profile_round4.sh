@@ -58,6 +58,7 @@ for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
     rm -rf $O/sq_${DT}_$i
   done
 done
+python3 tools/exp_module_sync_cost.py 2>/dev/null > $O/r04_module_sync_cost.txt; cat $O/r04_module_sync_cost.txt | cut -c1-200
 python3 tools/exp_timeline.py --build > /dev/null 2>&1      # the -DLSQ_TIMELINE experiment build is not shipped: made here (~1 min)
 python3 tools/exp_timeline.py --own 2>/dev/null > $O/r04_owner_timeline.txt; grep -E "^##|busy span|per row|epilogue" $O/r04_owner_timeline.txt | cut -c1-220
 fi
