@@ -57,8 +57,12 @@ def _backward_counted(grad, x, scale, shift, quant_min, quant_max, type_min, typ
 
 def sharded_backward(grad, x, scale, shift, quant_min, quant_max, type_min, type_max, axis=1,
                      use_grad_scaling=True, grad_scaler=1.0, is_affine=True, is_perchannel=False,
-                     eval_mode=False, init_mode=False, group=None, global_numel=None, async_op=False):
+                     eval_mode=False, init_mode=False, group=None, global_numel=None, async_op=False, reduce=True):
     """Local fused backward + the one all-reduce.  Returns (dx, ds, db[, work]).
+
+    reduce=False: no collective here -- the rank-local sums (already scaled with the GLOBAL element count) are returned and
+    something else adds them up over the ranks: DistributedDataParallel's own bucketed gradient all-reduce, which averages
+    scale.grad / shift.grad together with every other parameter's gradient.  Needs the global count up front.
 
     `global_numel`: None = local numel * world size (equal shards); an int = the caller knows it; COLLECTIVE = nobody
     does (uneven shards): the count is summed in the same collective and the scaler derived from it on the device.
@@ -67,6 +71,7 @@ def sharded_backward(grad, x, scale, shift, quant_min, quant_max, type_min, type
     sym = not is_affine
     if global_numel == COLLECTIVE and not eval_mode:
         assert not async_op, "async_op is not available with global_numel=COLLECTIVE"
+        assert reduce, "reduce=False needs the global element count up front (global_numel=None or an int)"
         return _backward_counted(grad, x, scale, shift, quant_min, quant_max, type_min, type_max, axis, use_grad_scaling,
                                  grad_scaler, sym, is_perchannel, init_mode, group, ws)
     n4s = x.numel() * ws if global_numel is None or global_numel == COLLECTIVE else int(global_numel)
@@ -81,7 +86,7 @@ def sharded_backward(grad, x, scale, shift, quant_min, quant_max, type_min, type
         dx, wide = ops.lsq_backward_per_tensor_wide(grad, x, scale, shift, quant_min, quant_max, type_min, type_max,
                                                     use_grad_scaling, grad_scaler, sym, eval_mode, init_mode, n4s)
     work = None
-    if ws > 1 and not eval_mode:
+    if ws > 1 and not eval_mode and reduce:
         work = dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     pd = _param_dtype(x)
     if async_op and work is not None:
@@ -94,7 +99,7 @@ def sharded_backward(grad, x, scale, shift, quant_min, quant_max, type_min, type
 class _ShardedLSQ(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, scale, shift, cfg):
-        (qmin, qmax, tmin, tmax, axis, use_gs, gs, is_affine, is_pc, eval_mode, init_mode, group, gnumel) = cfg
+        (qmin, qmax, tmin, tmax, axis, use_gs, gs, is_affine, is_pc, eval_mode, init_mode, group, gnumel, reduce) = cfg
         ops = torch.ops.torchlsq_native if (x.is_cuda and _E._NATIVE_LSQ is not None) else torch.ops.torchlsq
         sym = not is_affine
         if is_pc:
@@ -109,15 +114,15 @@ class _ShardedLSQ(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         x, scale, shift = ctx.saved_tensors
-        (qmin, qmax, tmin, tmax, axis, use_gs, gs, is_affine, is_pc, eval_mode, init_mode, group, gnumel) = ctx.cfg
+        (qmin, qmax, tmin, tmax, axis, use_gs, gs, is_affine, is_pc, eval_mode, init_mode, group, gnumel, reduce) = ctx.cfg
         dx, ds, db = sharded_backward(grad_out, x, scale, shift, qmin, qmax, tmin, tmax, axis, use_gs, gs, is_affine,
-                                      is_pc, eval_mode, init_mode, group, gnumel)
+                                      is_pc, eval_mode, init_mode, group, gnumel, reduce=reduce)
         return dx, ds, db, None
 
 
 def lsq_sharded(x, scale, shift, quant_min=0, quant_max=255, type_min=None, type_max=None, axis=1,
                 use_grad_scaling=True, grad_scaler=1., is_affine=True, is_perchannel=False,
-                eval_mode=False, init_mode=False, group=None, global_numel=None):
+                eval_mode=False, init_mode=False, group=None, global_numel=None, reduce=True):
     """`torchlsq.functional.lsq` for a tensor whose dim 0 is sharded across the ranks of `group`.
 
     scale/shift are replicated; their gradients come back already summed over all ranks and equal
@@ -125,6 +130,8 @@ def lsq_sharded(x, scale, shift, quant_min=0, quant_max=255, type_min=None, type
     `global_numel`: the element count of the whole batch for the gradient scaler -- None: local numel x world size (equal
     shards); an int; or `COLLECTIVE` ("collective"): shards may be uneven or empty and no rank knows the total, so the
     count is summed in the same all-reduce (one collective per backward either way).
+    `reduce=False`: no collective at all -- scale.grad / shift.grad are the rank's own sums, scaled with the global count
+    (equal shards or an int), for a wrapper that reduces gradients itself (DistributedDataParallel).
     Per-channel quantisation along the sharded dim itself (axis 0) needs no collective and is not
     handled here -- use the plain op on each shard."""
     _assert_has_ops()
@@ -142,7 +149,7 @@ def lsq_sharded(x, scale, shift, quant_min=0, quant_max=255, type_min=None, type
         scale = scale if scale.size(0) == size else scale.repeat(size)
         shift = shift if shift.size(0) == size else shift.repeat(size)
     cfg = (quant_min, quant_max, type_min, type_max, axis, use_grad_scaling, grad_scaler, is_affine, is_perchannel,
-           eval_mode, init_mode, group, global_numel)
+           eval_mode, init_mode, group, global_numel, bool(reduce))
     return _ShardedLSQ.apply(x, scale, shift, cfg)
 
 

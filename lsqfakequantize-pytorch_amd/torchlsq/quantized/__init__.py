@@ -65,7 +65,10 @@ def prepare_ddp(model, process_group=None, grads="mean"):
     device (a host synchronisation per quantizer and step).  The flags evolve identically on every rank by construction, the
     synchronised observers' min / max too, and the synchronised quantizers' scale.grad / shift.grad arrive already reduced,
     so all of them go on the model's `_ddp_params_and_buffers_to_ignore` list.  (Parameters the quantizers create at their
-    first call are only known to a DDP built AFTER that call -- as with the reference module, run one batch first.)"""
+    first call are only known to a DDP built AFTER that call -- as with the reference module, run one batch first.)
+    `grads='ddp'`: the quantizers make no collective of their own in the LSQ steps and DDP averages scale.grad / shift.grad in
+    its buckets like any other gradient (equal shards per rank; see `LSQFakeQuantizer.enable_rank_sync`) -- the parameters
+    then stay OFF the ignore list."""
     synced = set(id(m) for m in enable_rank_sync(model, process_group, grads))
     ignore = list(getattr(model, "_ddp_params_and_buffers_to_ignore", []))
     for name, mod in model.named_modules():
@@ -74,7 +77,8 @@ def prepare_ddp(model, process_group=None, grads="mean"):
         prefix = name + "." if name else ""
         ignore += [prefix + b for b in ("fake_quant_enabled", "observer_enabled", "learning_enabled", "current_batch")]
         if id(mod) in synced:
-            ignore += [prefix + "scale", prefix + "shift"]
+            if grads != "ddp":           # ('ddp': the module leaves the reduction of its gradients to DDP)
+                ignore += [prefix + "scale", prefix + "shift"]
             if mod.activation_post_process is not None:
                 ignore += [prefix + "activation_post_process." + b for b, _ in mod.activation_post_process.named_buffers()]
     model._ddp_params_and_buffers_to_ignore = sorted(set(ignore))

@@ -236,9 +236,15 @@ class LSQFakeQuantizer(ObserverBase):
         `grads`: 'sum' = the gradients of the reference on the concatenated batch for the same upstream gradients;
         'mean' = that divided by the world size, DistributedDataParallel's convention (it averages every other parameter's
         gradient; DDP may average these again -- they are equal on all ranks, so that changes nothing -- or skip them:
-        `torchlsq.quantized.prepare_ddp`).  Weight quantizers see replicated tensors and need none of this: on them the
+        `torchlsq.quantized.prepare_ddp`); 'ddp' = NO collective of this module's own in the LSQ steps: the rank-local sums,
+        scaled with the global element count (local numel x world size: equal shards, which DDP's averaging assumes anyway),
+        are left for DDP's bucketed gradient all-reduce to average with everything else -- the same numbers as 'mean' to an
+        fp32 rounding and zero extra host time per call (c10d's all_reduce enqueue is ~60 us: profiles/r04_module_sync_cost.txt),
+        but only correct under a wrapper that averages gradients, the parameters must NOT be on its ignore list, and while
+        observer-driven init batches are still running (the quantizer is a plain fake-quantizer then: no parameter gradients)
+        DDP needs `find_unused_parameters=True`, as it does with the reference module.  Weight quantizers see replicated tensors and need none of this: on them the
         switch is accepted and does nothing.  No-op while torch.distributed is not initialised or the group has one rank."""
-        assert grads in ('sum', 'mean'), "grads must be 'sum' or 'mean'"
+        assert grads in ('sum', 'mean', 'ddp'), "grads must be 'sum', 'mean' or 'ddp'"
         if self.otype != OTYPES['weight']:
             assert not (self.is_perchannel and self.ch_axis == 0), \
                 'rank sync shards dim 0 (the batch): a per-channel quantizer along dim 0 has nothing to synchronise'
@@ -558,12 +564,13 @@ class LSQFakeQuantizer(ObserverBase):
             if sync_ws > 1 and full_lsq:
                 # the input is this rank's shard of the batch: one all-reduce per backward, scaler from the global count
                 from torchlsq.distributed import COLLECTIVE, lsq_sharded
+                ddp = self._sync_grads == 'ddp'       # the wrapper averages the gradients: no collective of our own
                 gs = self.grad_scaler / sync_ws if self._sync_grads == 'mean' else self.grad_scaler
                 return lsq_sharded(x, self.scale, self.shift, quant_min=self.quant_min, quant_max=self.quant_max,
                                    type_min=tmin, type_max=tmax, axis=self.ch_axis, use_grad_scaling=self.use_grad_scaling,
                                    grad_scaler=gs, is_affine=self.is_affine, is_perchannel=self.is_perchannel,
                                    eval_mode=False, init_mode=backprop_init, group=self._group_ref.group,
-                                   global_numel=COLLECTIVE)
+                                   global_numel=None if ddp else COLLECTIVE, reduce=not ddp)
             return lsq(x, self.scale, self.shift, quant_min=self.quant_min, quant_max=self.quant_max,
                        type_min=tmin, type_max=tmax, axis=self.ch_axis, use_grad_scaling=self.use_grad_scaling,
                        grad_scaler=self.grad_scaler, is_affine=self.is_affine, is_perchannel=self.is_perchannel,

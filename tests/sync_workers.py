@@ -174,7 +174,7 @@ def replay(rank, world, port, uneven, device, out_q, names=SYNC_SCENARIOS, sync=
         dist.destroy_process_group()
 
 
-def ddp_train(rank, world, port, device, out_q, steps=6):
+def ddp_train(rank, world, port, device, grads, out_q, steps=6):
     """A small QAT model under DistributedDataParallel (prepare_ddp) next to the same model trained in ONE process on the
     whole batch: the replicas must stay bit-identical to each other and follow the single-process trajectory."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -220,7 +220,16 @@ def ddp_train(rank, world, port, device, out_q, steps=6):
                 refresh["n"] += 1
                 return orig()
             q._refresh_host_state = counted
-        ddp = DDP(prepare_ddp(repl))                 # 'mean' gradients: DDP's convention
+        calls = {"n": 0}
+        real_all_reduce = dist.all_reduce
+
+        def counting_all_reduce(*a, **k):
+            calls["n"] += 1
+            return real_all_reduce(*a, **k)
+        dist.all_reduce = counting_all_reduce
+        # 'mean': the module reduces its gradients itself (its parameters are on DDP's ignore list); 'ddp': DDP does -- and has to
+        # be told that parameters may go without a gradient (the observer-driven init batches run the quantizers in eval mode)
+        ddp = DDP(prepare_ddp(repl, grads=grads), find_unused_parameters=(grads == "ddp"))
         opt_s = torch.optim.SGD(single.parameters(), lr=0.05)
         opt_r = torch.optim.SGD(ddp.parameters(), lr=0.05)
         refresh["n"] = 0
@@ -238,12 +247,19 @@ def ddp_train(rank, world, port, device, out_q, steps=6):
             dist.all_gather(gathered, flat)
             if i == 1:
                 refresh["n"] = 0        # (the first call after .to(device) re-reads the moved buffers once: not DDP's doing)
+            if i == 3:
+                calls["n"] = 0          # the observer-driven init batches (2) are over: LSQ steps from here on
             if any(not torch.equal(g, gathered[0]) for g in gathered):
                 problems.append("step %d: replicas differ across ranks" % i)
             for (n1, p1), (_, p2) in zip(single.named_parameters(), repl.named_parameters()):
                 if not torch.allclose(p1, p2, rtol=2e-4, atol=1e-6):
                     problems.append("step %d: %s diverges from the single-process run: max |diff| %g" %
                                     (i, n1, float((p1 - p2).abs().max())))
+        # explicit all-reduces of the module in the LSQ steps: one per activation quantizer and backward ('mean'), none ('ddp')
+        n_act = sum(1 for q in quantizers if q.dtype == torch.quint8)
+        want = 0 if grads == "ddp" else n_act * (steps - 3)
+        if calls["n"] != want:
+            problems.append("%d explicit all-reduces in the LSQ steps, expected %d (grads=%r)" % (calls["n"], want, grads))
         if refresh["n"] != 0:
             problems.append("the state flags were re-read from the device %d times under DDP (buffer broadcasts not ignored)" % refresh["n"])
         out_q.put((rank, problems))

@@ -70,8 +70,11 @@ def test_negative_control_without_sync_the_replicas_leave_the_reference_trace():
     assert any("grad" in m for m in problems)
 
 
-def test_ddp_replicas_stay_identical_and_follow_single_process_training():
-    _run(sync_workers.ddp_train, 2, "cpu")
+@pytest.mark.parametrize("grads", ["mean", "ddp"])
+def test_ddp_replicas_stay_identical_and_follow_single_process_training(grads):
+    """grads='mean': the quantizers all-reduce their own gradient sums (count in the collective); 'ddp': no collective of
+    their own -- DDP's bucketed all-reduce averages scale.grad / shift.grad like any other gradient"""
+    _run(sync_workers.ddp_train, 2, "cpu", grads)
 
 
 def test_sync_is_a_noop_outside_a_job_and_on_weights():

@@ -25,9 +25,10 @@ def test_synced_module_replays_the_reference_traces_on_the_gpu_world4_uneven():
     _run(sync_workers.replay, 4, True, "cuda:0", timeout=900)
 
 
-def test_ddp_on_the_gpu_replicas_identical():
+@pytest.mark.parametrize("grads", ["mean", "ddp"])
+def test_ddp_on_the_gpu_replicas_identical(grads):
     assert torch.cuda.is_available()
-    _run(sync_workers.ddp_train, 2, "cuda:0", timeout=600)
+    _run(sync_workers.ddp_train, 2, "cuda:0", grads, timeout=600)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16])
