@@ -125,3 +125,53 @@ def test_gpu_levels_only_layouts_and_unaligned():
         _, want = torch.ops.torchlsq.lsq_quantize_per_tensor(v, s[:1], b[:1], 0, 255, 0, 255, 128)
         got = torch.ops.torchlsq.lsq_levels_per_tensor(v, s[:1], b[:1], 0, 255, 0, 255, 128)
         assert torch.equal(got, want)
+
+
+def test_cpu_torch_convert_after_qat_reproduces_the_fake_quantized_model(oracle_cpu_backend):
+    """The step after the path: a QAT model whose QConfig holds LSQFakeQuantizers goes through torch's own
+    `torch.ao.quantization.convert` -- which reads `calculate_qparams()`, `qscheme`, `ch_axis`, `dtype` of every quantizer
+    (reference quantized/modules/observers.py:378-422) -- and the resulting int8 model (quantized conv kernels of the CPU
+    backend) reproduces the fake-quantized model's output to within one output level (here: exactly)."""
+    import warnings
+    from torch.ao.quantization import DeQuantStub, QConfig, QuantStub, convert, prepare_qat
+    from torch.ao.quantization.observer import MovingAverageMinMaxObserver, MovingAveragePerChannelMinMaxObserver
+    from torchlsq.quantized import LSQFakeQuantizer
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q, self.dq = QuantStub(), DeQuantStub()
+            self.c1 = torch.nn.Conv2d(3, 8, 3, padding=1)
+            self.r = torch.nn.ReLU()
+            self.c2 = torch.nn.Conv2d(8, 4, 3, padding=1)
+
+        def forward(self, x):
+            return self.dq(self.c2(self.r(self.c1(self.q(x)))))
+
+    torch.manual_seed(0)
+    m = Net()
+    m.qconfig = QConfig(activation=LSQFakeQuantizer.with_args(observer=MovingAverageMinMaxObserver, otype="activation", init_batches=3),
+                        weight=LSQFakeQuantizer.with_args(observer=MovingAveragePerChannelMinMaxObserver, otype="weight", dtype=torch.qint8,
+                                                          qscheme=torch.per_channel_symmetric))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        prepare_qat(m.train(), inplace=True)
+        x = torch.randn(8, 3, 16, 16)
+        opt = None
+        for i in range(8):
+            y = m(x)
+            if i == 0:                              # the quantizers' parameters exist after the first call
+                opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+            opt.zero_grad()
+            (y ** 2).mean().backward()
+            opt.step()
+        m.eval()
+        y_fake = m(x)
+        mq = convert(m, inplace=False)
+        y_int8 = mq(x)
+    assert type(mq.c1).__name__ == "Conv2d" and "quantized" in type(mq.c1).__module__
+    out_scale = float(mq.c2.scale)
+    assert float((y_fake - y_int8).abs().max()) <= out_scale * 1.001, (float((y_fake - y_int8).abs().max()), out_scale)
+    # the weights torch quantized with the module's qparams are the module's own levels
+    wq = m.c1.weight_fake_quant
+    assert torch.equal(mq.c1.weight().int_repr(), wq.quantize(m.c1.weight).int_repr())
