@@ -175,3 +175,29 @@ def test_cpu_torch_convert_after_qat_reproduces_the_fake_quantized_model(oracle_
     # the weights torch quantized with the module's qparams are the module's own levels
     wq = m.c1.weight_fake_quant
     assert torch.equal(mq.c1.weight().int_repr(), wq.quantize(m.c1.weight).int_repr())
+
+
+def test_cpu_fx_graph_mode_qat_and_convert(oracle_cpu_backend):
+    """the same through FX graph mode (`prepare_qat_fx` inserts the quantizers from the QConfigMapping, `convert_fx` lowers to
+    the int8 kernels): the module is a drop-in `activation_post_process` / `weight_fake_quant` there too"""
+    import warnings
+    from torch.ao.quantization import QConfig, QConfigMapping
+    from torch.ao.quantization.observer import MovingAverageMinMaxObserver, MovingAveragePerChannelMinMaxObserver
+    from torch.ao.quantization.quantize_fx import convert_fx, prepare_qat_fx
+    from torchlsq.quantized import LSQFakeQuantizer
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 3, padding=1))
+    qc = QConfig(activation=LSQFakeQuantizer.with_args(observer=MovingAverageMinMaxObserver, otype="activation", init_batches=3),
+                 weight=LSQFakeQuantizer.with_args(observer=MovingAveragePerChannelMinMaxObserver, otype="weight", dtype=torch.qint8,
+                                                   qscheme=torch.per_channel_symmetric))
+    x = torch.randn(8, 3, 16, 16)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        p = prepare_qat_fx(m.train(), QConfigMapping().set_global(qc), (x,))
+        assert sum(isinstance(mod, LSQFakeQuantizer) for mod in p.modules()) >= 4
+        for _ in range(6):
+            p(x)
+        p.eval()
+        y_fake = p(x)
+        y_int8 = convert_fx(p)(x)
+    assert float((y_fake - y_int8).abs().max()) <= 0.05 * float(y_fake.abs().max()) + 1e-6
