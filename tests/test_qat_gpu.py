@@ -169,3 +169,54 @@ def test_eval_backward_while_the_observer_rewrites_the_parameters(binding):
         assert not torch.equal(grads[True], grads[False])
     finally:
         E.set_host_binding(saved)
+
+
+def test_train_on_the_gpu_then_convert_on_the_cpu():
+    """QAT on the MI355X, then the user's last step: `model.cpu()` and torch's `convert` to int8 kernels.  The quantizers'
+    parameters and state follow the device move (the module re-reads its moved buffers), and the int8 model reproduces what
+    the fake-quantized model computed on the GPU to within one output level."""
+    import warnings
+    import torchlsq  # noqa: F401
+    from torch.ao.quantization import DeQuantStub, QConfig, QuantStub, convert, prepare_qat
+    from torch.ao.quantization.observer import MovingAverageMinMaxObserver, MovingAveragePerChannelMinMaxObserver
+    from torchlsq.quantized import LSQFakeQuantizer
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q, self.dq = QuantStub(), DeQuantStub()
+            self.c1 = torch.nn.Conv2d(3, 16, 3, padding=1)
+            self.r = torch.nn.ReLU()
+            self.c2 = torch.nn.Conv2d(16, 8, 3, padding=1)
+
+        def forward(self, x):
+            return self.dq(self.c2(self.r(self.c1(self.q(x)))))
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    m = Net().to(dev)
+    m.qconfig = QConfig(activation=LSQFakeQuantizer.with_args(observer=MovingAverageMinMaxObserver, otype="activation", init_batches=3),
+                        weight=LSQFakeQuantizer.with_args(observer=MovingAveragePerChannelMinMaxObserver, otype="weight", dtype=torch.qint8,
+                                                          qscheme=torch.per_channel_symmetric))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        prepare_qat(m.train(), inplace=True)
+        x = torch.randn(8, 3, 16, 16, device=dev)
+        opt = None
+        for i in range(8):
+            y = m(x)
+            if i == 0:
+                opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+            opt.zero_grad()
+            (y ** 2).mean().backward()
+            opt.step()
+        m.eval()
+        y_gpu = m(x).cpu()
+        m.cpu()
+        y_cpu = m(x.cpu())                           # the same fake-quantized model on the CPU kernels (liblsq_cpu.so)
+        mq = convert(m, inplace=False)
+        y_int8 = mq(x.cpu())
+    out_scale = float(mq.c2.scale)
+    assert float((y_cpu - y_gpu).abs().max()) <= out_scale * 1.001          # conv arithmetic differs between the devices, the quantizers do not
+    assert float((y_cpu - y_int8).abs().max()) <= out_scale * 1.001
+    assert torch.equal(mq.c1.weight().int_repr(), m.c1.weight_fake_quant.quantize(m.c1.weight).int_repr())
