@@ -124,3 +124,32 @@ def test_prepare_ddp_lists_what_ddp_need_not_touch(oracle_cpu_backend):
         assert dict(model.named_modules())[n]._sync and dict(model.named_modules())[n]._sync_grads == "mean"
     for n in wgt:            # weights: replicated input, DDP averages their gradients like any parameter's; only the flags are skipped
         assert n + ".scale" not in ig and n + ".fake_quant_enabled" in ig and not dict(model.named_modules())[n]._sync
+
+
+def test_prepared_model_with_sync_survives_save_load_and_deepcopy(oracle_cpu_backend):
+    """torch.save(model) / torch.load and copy.deepcopy of a QAT model whose activation quantizers are rank-synchronised: the
+    process group is not part of the pickle (it comes back as the default group) and is shared by a deep copy"""
+    import copy
+    import io
+    import torch
+    from torch.ao.quantization import QConfig, prepare_qat
+    from torch.ao.quantization.observer import MovingAverageMinMaxObserver, MovingAveragePerChannelMinMaxObserver
+    from torchlsq.quantized import LSQFakeQuantizer, enable_rank_sync
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU())
+    m.qconfig = QConfig(activation=LSQFakeQuantizer.with_args(observer=MovingAverageMinMaxObserver, otype="activation", init_batches=1),
+                        weight=LSQFakeQuantizer.with_args(observer=MovingAveragePerChannelMinMaxObserver, otype="weight", dtype=torch.qint8,
+                                                          qscheme=torch.per_channel_symmetric))
+    prepare_qat(m.train(), inplace=True)
+    x = torch.randn(2, 3, 8, 8)
+    for _ in range(3):
+        m(x)
+    assert len(enable_rank_sync(m)) == 1
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m2 = torch.load(buf, weights_only=False)
+    assert torch.equal(m2(x), m(x))
+    assert sorted(q._sync for q in m2.modules() if isinstance(q, LSQFakeQuantizer)) == [False, True]
+    assert all(q._group_ref.group is None for q in m2.modules() if isinstance(q, LSQFakeQuantizer))
+    m3 = copy.deepcopy(m)
+    assert torch.equal(m3(x), m(x))
