@@ -82,6 +82,21 @@ def prepare_ddp(model, process_group=None, grads="mean"):
             if mod.activation_post_process is not None:
                 ignore += [prefix + "activation_post_process." + b for b, _ in mod.activation_post_process.named_buffers()]
     model._ddp_params_and_buffers_to_ignore = sorted(set(ignore))
+    # DDP broadcasts rank 0's parameters and buffers when it is constructed -- except what is on the list: do that once here, so
+    # that replicas that did not start identical (a checkpoint restored on rank 0 only) are identical before they are left alone
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        named = dict(model.named_parameters())
+        named.update(dict(model.named_buffers()))
+        src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+        with torch.no_grad():
+            for name in model._ddp_params_and_buffers_to_ignore:
+                t = named.get(name)
+                if t is not None and t.numel() > 0:
+                    dist.broadcast(t.data if isinstance(t, torch.nn.Parameter) else t, src=src, group=process_group)
+        for mod in model.modules():
+            if isinstance(mod, LSQFakeQuantizer):
+                mod._refresh_host_state()       # the flags may just have been overwritten
     return model
 
 

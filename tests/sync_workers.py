@@ -220,6 +220,14 @@ def ddp_train(rank, world, port, device, grads, out_q, steps=6):
                 refresh["n"] += 1
                 return orig()
             q._refresh_host_state = counted
+        if rank != 0:      # a replica that did NOT start identical (e.g. a checkpoint restored on rank 0 only): prepare_ddp
+            with torch.no_grad():     # broadcasts what it tells DDP to leave alone
+                for q in quantizers:
+                    if q.dtype == torch.quint8:
+                        q.scale.mul_(1.7)
+                        q.shift.add_(0.3)
+                        q.current_batch[0] = 1        # ... including the state flags: left alone, this rank would leave the
+                                                      # init phase one batch early and the ranks' collectives would not pair up
         calls = {"n": 0}
         real_all_reduce = dist.all_reduce
 
