@@ -32,3 +32,19 @@ def _build_and_run(tmp_path, flags, env_extra):
 def test_cpu_kernels_under_asan_and_ubsan(tmp_path):
     _build_and_run(tmp_path, ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"],
                    {"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1"})
+
+
+def test_launch_geometry_invariants_under_ubsan(tmp_path):
+    """lsq_pc_geom.hpp compiled HOST-ONLY with UBSan and driven over 300 000 random shapes (tests/geom_driver.cpp): window,
+    row-group, owner and segment geometry never divide by zero or overflow, and keep the invariants the kernels rely on (whole
+    waves, fewer than one wave of stand-in lanes, the ring's rows, the LDS budget per CU, splits <= row tiles, ...)"""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.isfile(hipcc):
+        pytest.skip("no hipcc")
+    exe = str(tmp_path / "geom")
+    csrc = os.path.join(ROOT, "lsqfakequantize-pytorch_amd", "csrc")
+    b = subprocess.run([hipcc, "-std=c++17", "-O1", "-g", "--cuda-host-only", "-fsanitize=undefined", "-fno-sanitize-recover=undefined",
+                        "-I", csrc, os.path.join(ROOT, "tests", "geom_driver.cpp"), "-o", exe], capture_output=True, text=True, timeout=900)
+    assert b.returncode == 0, b.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.stdout[-1000:], r.stderr[-3000:])
