@@ -94,6 +94,16 @@ def test_argument_validation_never_reaches_the_gpu():
     assert lib.lsq_hip_backward_per_channel(0, None, None, None, None, None, None, 4, 0, 4, None, None, ctypes.byref(p), None, None, 0, None) == -1
     assert lib.lsq_hip_forward_per_channel(0, None, None, 0, 8, 4, None, None, ctypes.byref(p), None, None) == 0
     assert lib.lsq_hip_backward_per_tensor_workspace(0, 1 << 20) >= 256 * 8 * 16
+    # ABI v4: the sharded epilogue and the levels-only forward validate before they launch, too
+    assert lib.lsq_hip_sharded_finish(0, None, 4, 1, ctypes.byref(p), None, None, None) == -1 and b"NULL" in lib.lsq_hip_last_error()
+    assert lib.lsq_hip_sharded_finish(0, 8, 0, 1, ctypes.byref(p), 8, 8, None) == -1                   # no channels
+    assert lib.lsq_hip_sharded_finish(0, 8, 3, 0, ctypes.byref(p), 8, 8, None) == -1                   # per-tensor has one channel
+    assert lib.lsq_hip_sharded_finish(0, 12, 1, 0, ctypes.byref(p), 8, 8, None) == -1 and b"aligned" in lib.lsq_hip_last_error()
+    wide = E.LsqParams(-200, 127, -200, 255, 1, 0, 0, 0, 1.0, 0)          # 328 levels: fit neither int8 nor uint8
+    ex = E.LsqFwdExtras(64, 0, 0)
+    assert lib.lsq_hip_forward_per_tensor(0, 64, None, 16, 64, 64, ctypes.byref(wide), ctypes.byref(ex), None) == -1
+    assert b"neither int8 nor uint8" in lib.lsq_hip_last_error()
+    assert lib.lsq_hip_forward_per_tensor(0, 64, None, 16, 64, 64, ctypes.byref(p), None, None) == -1    # y == NULL needs levels
 
 
 def test_cpu_library_exports_its_header_and_devices_never_substitute():
