@@ -170,6 +170,14 @@ std::atomic<int> g_ticket_mode{[] {
     return !e ? 2 : (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2));
 }()};
 constexpr int kTicketSlots = 64;
+// Behind every ticket sits the per-tensor backward's workspace (its block partial sums: a constant 256 KiB): a launch that has
+// a ticket -- eager, not being captured, alone on its stream slot -- has a private scratch area with the same lifetime rules, so
+// the host-bound small tensors the ticket exists for also skip one allocator round trip per backward (~0.9 us of ~9).
+inline size_t ticket_workspace_bytes() {
+    static const size_t b = (lsq_hip_backward_per_tensor_workspace(LSQ_F32, 1) + 4095) & ~size_t(4095);
+    return b;
+}
+inline size_t ticket_slot_stride() { return LSQ_TICKET_BYTES + ticket_workspace_bytes(); }
 struct TicketSlab {
     char* base = nullptr;
     int next = 0;
@@ -197,7 +205,7 @@ void* ticket_for(const Tensor& x, void* stream, bool per_channel) {
         // which was just seen not to be capturing, with a stream-level wait: a hipMalloc / device-wide synchronisation here
         // would be illegal -- and would invalidate the capture -- while ANOTHER stream captures in global mode.  Never
         // returned to the allocator (a raw pointer, not a Tensor: nothing to destroy after the runtime at process exit).
-        const size_t bytes = static_cast<size_t>(kTicketSlots) * LSQ_TICKET_BYTES;
+        const size_t bytes = static_cast<size_t>(kTicketSlots) * ticket_slot_stride();
         void* p = nullptr;
         try {
             c10::DeviceGuard guard(x.device());
@@ -213,7 +221,7 @@ void* ticket_for(const Tensor& x, void* stream, bool per_channel) {
         slab.base = static_cast<char*>(p);
     }
     if (slab.next >= kTicketSlots) return nullptr;            // more streams than slots: two-launch route for the rest
-    void* t = slab.base + static_cast<size_t>(slab.next++) * LSQ_TICKET_BYTES;
+    void* t = slab.base + static_cast<size_t>(slab.next++) * ticket_slot_stride();
     g_tickets.emplace(key, t);
     return t;
 }
@@ -296,10 +304,20 @@ BackwardOut backward_impl(const Tensor& grad, const Tensor& x, const Tensor& sca
     }
     Tensor ds = at::empty({1}, popt), db = at::empty({1}, popt);
     if (want_wide) wide = at::empty({2}, x.options().dtype(at::kDouble));
-    const Tensor ws = byte_workspace(x, lsq_hip_backward_per_tensor_workspace(code, xd.numel()));
+    Tensor ws;                                   // with a ticket: the slot's own workspace, no allocation
+    void* ws_ptr = nullptr;
+    size_t ws_bytes = 0;
+    if (extras.ticket) {
+        ws_ptr = static_cast<char*>(extras.ticket) + LSQ_TICKET_BYTES;
+        ws_bytes = ticket_workspace_bytes();
+    } else {
+        ws = byte_workspace(x, lsq_hip_backward_per_tensor_workspace(code, xd.numel()));
+        ws_ptr = ws.data_ptr();
+        ws_bytes = static_cast<size_t>(ws.numel());
+    }
     status(lsq_hip_backward_per_tensor(code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(), ds.data_ptr(), db.data_ptr(),
                                        want_wide ? wide.data_ptr<double>() : nullptr, xd.numel(), sc.data_ptr(), sh.data_ptr(), &p,
-                                       &extras, ws.data_ptr(), static_cast<size_t>(ws.numel()), stream),
+                                       &extras, ws_ptr, ws_bytes, stream),
            "lsq_hip_backward_per_tensor");
     return {dx, ds, db, wide};
 }
