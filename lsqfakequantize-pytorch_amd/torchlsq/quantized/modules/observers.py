@@ -160,6 +160,10 @@ class LSQFakeQuantizer(ObserverBase):
     """
     init_modes = ('learnable', 'observer')
     fuse_observer_tail = True     # observer-driven init batches on the GPU: one launch after the statistics pass
+    # rank sync off unless switched on (class-level defaults: a module pickled by an earlier build has no such attributes)
+    _sync = False
+    _sync_grads = 'sum'
+    _group_ref = _GroupRef(None)
 
     @staticmethod
     def sign(x):
@@ -242,8 +246,9 @@ class LSQFakeQuantizer(ObserverBase):
         fp32 rounding and zero extra host time per call (c10d's all_reduce enqueue is ~60 us: profiles/r04_module_sync_cost.txt),
         but only correct under a wrapper that averages gradients, the parameters must NOT be on its ignore list, and while
         observer-driven init batches are still running (the quantizer is a plain fake-quantizer then: no parameter gradients)
-        DDP needs `find_unused_parameters=True`, as it does with the reference module.  Weight quantizers see replicated tensors and need none of this: on them the
-        switch is accepted and does nothing.  No-op while torch.distributed is not initialised or the group has one rank."""
+        DDP needs `find_unused_parameters=True`, as it does with the reference module.
+        Weight quantizers see replicated tensors and need none of this: on them the switch is accepted and does nothing.
+        No-op while torch.distributed is not initialised or the group has one rank."""
         assert grads in ('sum', 'mean', 'ddp'), "grads must be 'sum', 'mean' or 'ddp'"
         if self.otype != OTYPES['weight']:
             assert not (self.is_perchannel and self.ch_axis == 0), \
