@@ -118,3 +118,42 @@ def test_owner_windows_run_to_run_and_graph_replay(T):
     torch.cuda.synchronize()
     for u, v, w in zip(a, c, d):
         assert torch.equal(u, v) and torch.equal(u, w)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_owner_windows_random_shapes_forced(T, seed):
+    """seeded random NCHW-style shapes with owner windows FORCED wherever the plan allows (lsq_hip_debug_set_own(1): also above
+    the policy's size bound), against the oracle: row counts that leave ragged last tiles (the generic row loop), runs of 1 to 8
+    channels, one or two channels per lane, few rows (thin workgroups), all storage types"""
+    from torchlsq import extension as E
+    rng = np.random.RandomState(1000 + seed)
+    dev = torch.device("cuda:0")
+    dtype = [torch.float32, torch.bfloat16, torch.float16, torch.float64][seed % 4]
+    C = int(rng.choice([768, 1024, 1536, 2048, 3072, 4096]))
+    inner = int(rng.choice([4, 6, 8, 9, 12, 16, 25, 36, 49, 50, 64, 81, 100, 144, 196]))
+    outer = int(rng.randint(16, 160))
+    while outer * C * inner > (3 << 22):
+        outer = max(16, outer // 2)
+        if outer == 16:
+            break
+    shape = (outer, C, inner)
+    x, g, s, b = _inputs(shape, dtype, dev, seed=100 + seed)
+    q = (-8, 7, -128, 127) if seed % 2 else (0, 127, 0, 255)
+    sym, init = bool(seed % 3 == 1), bool(seed % 5 == 2)
+    T.set_knob("set_own", 1)
+    try:
+        dx, ds, db = E.hip_backward_per_channel(g, x, s, b, 1, *q, True, 1.0, sym, False, init)
+        note = T.last_launch()
+    finally:
+        T.set_knob("set_own", 0)
+    torch.cuda.synchronize()
+    xs = x.double().cpu().numpy() if dtype == torch.float64 else x.float().cpu().numpy()
+    gs = g.double().cpu().numpy() if dtype == torch.float64 else g.float().cpu().numpy()
+    r = O.bwd_pc(gs, xs, s.cpu().numpy(), b.cpu().numpy(), outer, C, inner, *q, True, 1.0, sym, False, init)
+    tag = "%s %s sym=%d init=%d (%s %dx%d of %d lanes)" % (shape, dtype, sym, init, note["kind"], note["grid_x"], note["grid_y"], note["block"])
+    if dtype in (torch.float32, torch.float64):
+        assert_bits_equal(dx.cpu().numpy(), r.dx, tag + " dx")
+    else:
+        assert torch.equal(dx.cpu().view(torch.int16), torch.from_numpy(np.ascontiguousarray(r.dx)).to(dtype).view(torch.int16)), tag + " dx"
+    assert_reduction_close(ds.cpu().numpy(), r.ds_wide, r.abs_ds, tag + " ds")
+    assert_reduction_close(db.cpu().numpy(), r.db_wide, r.abs_db, tag + " db")
