@@ -1078,54 +1078,6 @@ __global__ __launch_bounds__(kBlock) void finalize_pc_kernel(const double2* __re
     }
 }
 
-#ifdef LSQ_TOOLS
-// Round-4 experiment (a), tools build only (lsq_hip_debug_set_fin_ch(64)): the leanest finalize this partial layout allows --
-// ONE wave per workgroup, 16 lanes per channel (4 channels per wave), lane j reads split j (, j + 16, ...) of the one or two
-// windows holding a piece of its channel, every load independent; a fixed xor tree over the 16 lanes (DPP / ds_swizzle, no
-// LDS stage, no barrier, no second phase) and lane 0 of the group rounds and stores.  See profiles/r04_finalize_lean_ab.txt.
-template <typename T>
-__global__ __launch_bounds__(64) void finalize_pc_lean_kernel(const double2* __restrict__ partials, PcGeom g, int eval_mode, int sym,
-                                                              T sym_term, T* __restrict__ ds, T* __restrict__ db,
-                                                              double* __restrict__ wide) {
-    const int sub = threadIdx.x & 15;
-    const int64_t c = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 4);
-    double s = 0.0, b = 0.0;
-    if (!eval_mode && c < g.C) {
-        const bool f32 = g.fits32 != 0;
-        int64_t w_lo = 0, w_hi = 0;
-        if (g.R == 1) {
-            w_lo = udiv(c * g.inner, g.wpos, f32);
-            w_hi = udiv((c + 1) * g.inner - 1, g.wpos, f32);
-        }
-        const int64_t stride = g.n_windows * g.k_slots;
-        for (int64_t w = w_lo; w <= w_hi; ++w) {
-            const int64_t c_lo = (g.R == 1) ? udiv(w * g.wpos, g.inner, f32) : 0;
-            const double2* col = partials + w * g.k_slots + (c - c_lo);
-            for (int sy = sub; sy < g.splits; sy += 16) {
-                const double2 v = col[static_cast<int64_t>(sy) * stride];
-                s += v.x;
-                b += v.y;
-            }
-        }
-    }
-#pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) {
-        s += shfl_xor_f64(s, m);
-        b += shfl_xor_f64(b, m);
-    }
-    if (sub == 0 && c < g.C) {
-        double tb = b;
-        if (!eval_mode && sym) tb = 0.0 + static_cast<double>(sym_term);
-        ds[c] = static_cast<T>(s);
-        db[c] = static_cast<T>(tb);
-        if (wide) {
-            wide[c] = s;
-            wide[g.C + c] = tb;
-        }
-    }
-}
-#endif
-
 // Finalize (row-group windows): the partials are [splits][n_windows * w V] in slot order (slot = component * w + lane
 // inside a window), so consecutive threads read consecutive 16-byte partials; thread -> slot -> channel
 // c = window * w V + lane * V + component.  fin_ch slots x (256 / fin_ch) interleaved slices of the splits per
@@ -1620,12 +1572,6 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
             hipLaunchKernelGGL((finalize_ww_kernel<T>), dim3(fgrid), dim3(kBlock), 0, c.stream, c.partials, g, fin_ch,
                                p.eval_mode ? 1 : 0, p.sym ? 1 : 0, c.sym_term, c.ds, c.db, c.wide);
         }
-#ifdef LSQ_TOOLS
-        else if (knob::get(knob::kFinCh) == 64) {
-            hipLaunchKernelGGL((finalize_pc_lean_kernel<T>), dim3(static_cast<unsigned>((c.C + 3) / 4)), dim3(64), 0, c.stream, c.partials,
-                               g, p.eval_mode ? 1 : 0, p.sym ? 1 : 0, c.sym_term, c.ds, c.db, c.wide);
-        }
-#endif
         else {
             const unsigned fgrid_w = static_cast<unsigned>((c.C + fin_ch - 1) / fin_ch);
             hipLaunchKernelGGL((finalize_pc_kernel<T>), dim3(fgrid_w), dim3(kBlock), 0, c.stream, c.partials, g, fin_ch,

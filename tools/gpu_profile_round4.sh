@@ -36,9 +36,8 @@ for CTR in FETCH_SIZE WRITE_SIZE; do
 done
 cat $O/r04_levels_only_pmc.txt
 python3 tools/exp_owner_probe.py > $O/r04_owner_pattern_probe.txt 2>/dev/null; cat $O/r04_owner_pattern_probe.txt
-python3 tools/exp_knob_ab.py set_fin_ch 64 0 bf16 256x2048x7x7@1 128x512x28x28@1 > $O/r04_finalize_lean_ab.txt 2>/dev/null
-python3 tools/exp_knob_ab.py set_fin_ch 64 0 f32 256x2048x7x7@1 >> $O/r04_finalize_lean_ab.txt 2>/dev/null
-cat $O/r04_finalize_lean_ab.txt
+# (r04_finalize_lean_ab.txt: `exp_knob_ab.py set_fin_ch 64 0 ...` against the lean one-wave finalize kernel of commit 6576283,
+#  removed after the measurement)
 python3 tools/exp_owner_windows.py > $O/r04_owner_windows_ab.txt 2>/dev/null; cut -c1-200 $O/r04_owner_windows_ab.txt
 for CTR in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $CTR --kernel-trace -d $O/pmc_own_$CTR -o own -- python3 tools/exp_owner_probe.py one 1 16 49 1 > /dev/null 2>&1
