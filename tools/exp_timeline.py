@@ -94,7 +94,9 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         lib.lsq_hip_debug_set_timeline(None)
-        waves = note["grid_x"] * note["grid_y"] * (note["block"] // 64)
+        # (the kernel numbers its waves with its LAUNCH BOUND's waves per workgroup: 8 for owner windows whatever they launch)
+        per_wg = 8 if note["kind"] == "owners" else note["block"] // 64
+        waves = note["grid_x"] * note["grid_y"] * per_wg
         rec = buf[:waves * 8].view(waves, 8).cpu().numpy().astype(np.float64)
         rec = rec[rec[:, 0] > 0]
         # every XCD counts its own shader clock: stamps are comparable inside one XCC only, so entry / exit times are taken
