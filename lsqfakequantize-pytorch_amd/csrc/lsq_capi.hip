@@ -319,7 +319,7 @@ void lsq_hip_debug_set_seg_min_div(int v) { lsq::knob::set(lsq::knob::kSegMinDiv
 void lsq_hip_debug_set_fwd_direct(int v) { lsq::knob::set(lsq::knob::kFwdDirect, v < 0 || v > 4 ? 0 : v); }
 void lsq_hip_debug_set_seg_no_up_front(int v) { lsq::knob::set(lsq::knob::kSegNoUpFront, v ? 1 : 0); }
 void lsq_hip_debug_set_fin_ch(int v) { lsq::knob::set(lsq::knob::kFinCh, v); }
-void lsq_hip_debug_set_own(int v) { lsq::knob::set(lsq::knob::kOwn, v < 0 || v > 2 ? 0 : v); }
+void lsq_hip_debug_set_own(int v) { lsq::knob::set(lsq::knob::kOwn, v < 0 || v > 3 ? 0 : v); }
 
 #ifdef LSQ_TIMELINE
 void lsq_hip_debug_set_timeline(void* device_buffer) { lsq::knob::timeline_buffer().store(static_cast<unsigned long long*>(device_buffer)); }

@@ -136,6 +136,7 @@ struct PcGeom {
     int32_t ring_nt;         // LDS-DMA ring: issue its copies with the streaming hint (global_load_lds ... nt)
     int32_t direct;          // forward, a lane's components are different channels: no LDS table, the lane reads its own scale / shift
     int32_t own;             // OWNER windows (make_geom_own): lanes per row of the owner's run; 0 otherwise
+    int32_t own_prio;        // owner windows: the waves of a SIMD take turns at the higher issue priority (bwd_pc_kernel)
 #ifdef LSQ_TIMELINE
     unsigned long long* timeline;   // experiment build (tools/exp_timeline.py): 8 x u64 per wave of the window backward
 #endif
@@ -196,6 +197,7 @@ static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec,
     g.ring_nt = 0;
     g.direct = 0;
     g.own = 0;
+    g.own_prio = 0;
 #ifdef LSQ_TIMELINE
     g.timeline = nullptr;
 #endif
@@ -236,6 +238,7 @@ static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_
     g.ring_nt = 0;
     g.direct = 0;
     g.own = 0;
+    g.own_prio = 0;
 #ifdef LSQ_TIMELINE
     g.timeline = nullptr;
 #endif
@@ -335,6 +338,7 @@ static inline PcGeom make_geom_own(int64_t outer, int64_t C, int64_t inner, int 
     g.ring_nt = 0;
     g.direct = 0;
     g.own = o.lanes_per_row;
+    g.own_prio = 1;
 #ifdef LSQ_TIMELINE
     g.timeline = nullptr;
 #endif

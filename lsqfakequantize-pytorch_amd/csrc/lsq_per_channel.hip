@@ -761,7 +761,21 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
                 static_assert(!PRE32 || DMA <= kPreRows, "a pre-sum group is at most kPreRows rows");
                 const int64_t step_e = walk.step * g.L;
                 int64_t e_cur = walk.row(0) * g.L + site.p0;          // i == 0 here
+                // Owner windows: the waves of a SIMD take turns at the higher issue priority, block by block.  An owner
+                // workgroup has its CU to itself and ends at a barrier, so it is as slow as its slowest wave -- and the
+                // arbiter serves the OLDER wave of a SIMD first: waves 0-3 walked their rows in 20.8 us, waves 4-6 (the second
+                // wave of their SIMD) in 27.9 us, and the first four then sat 7 us at the barrier
+                // (profiles/r04_owner_timeline.txt).  Alternating s_setprio makes the two finish together.
+                [[maybe_unused]] const int own_phase = OWN ? __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 8)) & 1 : 0;
+                [[maybe_unused]] int own_blk = 0;
                 auto block = [&](auto first_block) {
+                    if constexpr (OWN) {
+                        if (g.own_prio) {
+                            if ((own_blk ^ own_phase) & 1) __builtin_amdgcn_s_setprio(2);
+                            else __builtin_amdgcn_s_setprio(0);
+                            ++own_blk;
+                        }
+                    }
 #pragma unroll
                     for (int u = 0; u < DMA; ++u) {
                         if (decltype(first_block)::value) LSQ_TL_WAIT(wait_vm_upto(2 * (DMA - 1) + u));
@@ -786,6 +800,7 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
                 static_assert(2 * (DMA - 1) + DMA <= 15, "wait_vm_upto covers counts up to 15");
                 if (i + 2 * DMA <= dma_n) block(std::true_type{});
                 while (i + 2 * DMA <= dma_n) block(std::false_type{});
+                if constexpr (OWN) __builtin_amdgcn_s_setprio(0);
                 if constexpr (PRE32) {
 #pragma unroll
                     for (int j = 0; j < kAcc / 2; ++j) { pre_s[j] = f2{0.0f, 0.0f}; pre_b[j] = f2{0.0f, 0.0f}; }
@@ -1591,7 +1606,8 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
     // OWNER windows first (lsq_pc_geom.hpp, plan_own): activations whose channel rows are short (NCHW with small H x W) and
     // whose tensor is small enough for the finalize launch to matter -- one launch, no workspace.
     if constexpr (kDmaAble && !WW && !EVAL && V > 1 && CPL <= 2) {
-        const int own = knob::get(knob::kOwn);          // tools builds: 1 = wherever the shape allows, 2 = never
+        const int own_knob = knob::get(knob::kOwn);     // tools builds: 1 = wherever the shape allows, 2 = never, 3 = 1 without the priority turns
+        const int own = own_knob == 3 ? 1 : own_knob;
         const int64_t bytes = c.outer * c.C * c.inner * static_cast<int64_t>(sizeof(typename IO::elem));
         if (own != 2 && (own == 1 || (c.default_variant && c.outer * c.C * c.inner <= kOwnMaxElems))) {
             auto launch_own = [&](auto block_c) -> bool {
@@ -1602,6 +1618,7 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
                 if (c.plan_need) return true;            // no workspace
                 PcGeom g = make_geom_own(c.outer, c.C, c.inner, V, op);
                 g.ring_nt = ring_nt_for(bytes, true, false);
+                g.own_prio = own_knob == 3 ? 0 : 1;
 #if defined(LSQ_TOOLS) && defined(LSQ_TIMELINE)
                 g.timeline = knob::timeline_buffer().load();
 #endif

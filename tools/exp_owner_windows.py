@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Round-4 experiment (c): OWNER windows of the per-channel backward (lsq_pc_geom.hpp plan_own: a fat workgroup owns k whole
 channels for all rows; no partials, no finalize launch) against the 256-lane windows + finalize launch, backward op, cold
-inputs, HIP-graph replay; with the ring's streaming hint on (policy) and off.  Output: profiles/r04_owner_windows_ab.txt."""
+inputs, HIP-graph replay; owner windows with and without the waves' turns at the higher issue priority.  Output: profiles/r04_owner_windows_ab.txt."""
 import sys
 
 import torch
@@ -18,17 +18,15 @@ SHAPES = [(256, 2048, 7, 7), (128, 1024, 14, 14), (128, 512, 28, 28),           
 
 def main():
     print("# tools/exp_owner_windows.py: backward op (kernel + finalize launch where there is one), us, cold inputs; own: 2 = 256-lane windows,")
-    print("# 1 = owner windows (at most 512 lanes); nt: the ring copies' streaming hint, 0 = policy (on above 32 MB), 2 = off")
+    print("# 1 = owner windows (at most 512 lanes), 3 = owner windows without the waves' turns at the higher issue priority;")
+    print("# the ring copies' streaming hint by the policy (on above 32 MB)")
     for dt_name in sys.argv[1:] or ["bf16", "f32"]:
         dtype = {"bf16": torch.bfloat16, "f32": torch.float32}[dt_name]
         for shape in SHAPES:
-            row = []
-            for nt in (0, 2):
-                lsq_tools.set_knob("set_ring_nt", nt)
-                r = time_bwd(shape, dtype, (("win", 2), ("own", 1)), "set_own", axis=1)
-                row.append("nt %d: " % nt + "  ".join("%s %6.1f (%s)" % (k, r[k][0], r[k][1].split(" of ")[0] + " of " + r[k][1].split(" of ")[1].split(",")[0]) for k in ("win", "own")))
-            lsq_tools.set_knob("set_ring_nt", 0)
-            print("%-4s %-20s %s" % (dt_name, "x".join(str(d) for d in shape), "  |  ".join(row)), flush=True)
+            r = time_bwd(shape, dtype, (("win", 2), ("own", 1), ("own, no turns", 3)), "set_own", axis=1)
+            row = "  ".join("%s %6.1f (%s)" % (k, r[k][0], r[k][1].split(" of ")[0] + " of " + r[k][1].split(" of ")[1].split(",")[0])
+                            for k in ("win", "own", "own, no turns"))
+            print("%-4s %-20s %s   own / win %+5.1f %%" % (dt_name, "x".join(str(d) for d in shape), row, (r["own"][0] / r["win"][0] - 1) * 100), flush=True)
 
 
 if __name__ == "__main__":

@@ -68,6 +68,7 @@ def main():
         for c_ in base_cases:
             cases.append(("WINDOWS " + c_[0],) + c_[1:] + (2,))
             cases.append(("OWNERS  " + c_[0],) + c_[1:] + (1,))
+            cases.append(("OWNERS without the priority turns " + c_[0],) + c_[1:] + (3,))
     else:
         cases = [c_ + (0,) for c_ in cases]
     print("# tools/exp_timeline.py: per-wave shader-clock stamps of the window-mode backward (one launch, cold inputs); us")
@@ -98,6 +99,8 @@ def main():
         per_wg = 8 if note["kind"] == "owners" else note["block"] // 64
         waves = note["grid_x"] * note["grid_y"] * per_wg
         rec = buf[:waves * 8].view(waves, 8).cpu().numpy().astype(np.float64)
+        wave_in_wg = np.arange(waves) % per_wg
+        wave_in_wg = wave_in_wg[rec[:, 0] > 0]
         rec = rec[rec[:, 0] > 0]
         # every XCD counts its own shader clock: stamps are comparable inside one XCC only, so entry / exit times are taken
         # relative to the first entry on the same XCC; the HW_ID register (bits 8-11 CU, 13-15 SE on gfx9) gives the CU
@@ -151,6 +154,18 @@ def main():
                 m_ = conc == c_
                 print("      waves with %d wave(s) alive on their SIMD at mid-loop: %5d   row time median %.2f us  (p10 %.2f, p90 %.2f)" % (
                     c_, int(m_.sum()), np.median(per_row[m_]), np.percentile(per_row[m_], 10), np.percentile(per_row[m_], 90)))
+            if note["kind"] == "owners":     # which waves of a workgroup are the slow ones?
+                loop_us = us(rec[:, 2] - rec[:, 1])
+                for w in np.unique(wave_in_wg):
+                    m_ = wave_in_wg == w
+                    print("      wave %d of its workgroup: %5d   rows %3d   row loop median %6.2f us (p10 %6.2f, p90 %6.2f)   SIMD %s" % (
+                        w, int(m_.sum()), int(np.median(rec[m_, 5])), np.median(loop_us[m_]), np.percentile(loop_us[m_], 10),
+                        np.percentile(loop_us[m_], 90), " ".join("%d:%d" % (v, int((simd[m_] == v).sum())) for v in range(4))))
+                xcd_of = rec[:, 7].astype(np.int64) & 0xf
+                for x_ in np.unique(xcd_of):
+                    m_ = xcd_of == x_
+                    print("      XCC %d: %5d waves   row loop median %6.2f us (p10 %6.2f, p90 %6.2f)" % (
+                        x_, int(m_.sum()), np.median(loop_us[m_]), np.percentile(loop_us[m_], 10), np.percentile(loop_us[m_], 90)))
             # waves alive over time on one CU (the one with the most waves)
             kbig = max(np.unique(cu_key), key=lambda k: int((cu_key == k).sum()))
             m = cu_key == kbig
