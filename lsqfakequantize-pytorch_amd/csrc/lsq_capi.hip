@@ -319,6 +319,8 @@ void lsq_hip_debug_set_seg_min_div(int v) { lsq::knob::set(lsq::knob::kSegMinDiv
 void lsq_hip_debug_set_fwd_direct(int v) { lsq::knob::set(lsq::knob::kFwdDirect, v < 0 || v > 4 ? 0 : v); }
 void lsq_hip_debug_set_seg_no_up_front(int v) { lsq::knob::set(lsq::knob::kSegNoUpFront, v ? 1 : 0); }
 void lsq_hip_debug_set_fin_ch(int v) { lsq::knob::set(lsq::knob::kFinCh, v); }
+void lsq_hip_debug_set_own_min_run(int v) { lsq::knob::set(lsq::knob::kOwnMinRun, v < 0 ? 0 : v); }
+void lsq_hip_debug_set_own_fat(int v) { lsq::knob::set(lsq::knob::kOwnFat, v < 0 || v > 2 ? 0 : v); }
 void lsq_hip_debug_set_own(int v) { lsq::knob::set(lsq::knob::kOwn, v < 0 || v > 3 ? 0 : v); }
 
 #ifdef LSQ_TIMELINE

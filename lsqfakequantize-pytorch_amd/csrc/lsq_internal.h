@@ -47,6 +47,10 @@ void lsq_hip_debug_set_fin_ch(int v);
 /* owner windows of the per-channel backward: 0 = the policy, 1 = wherever the shape allows, 2 = never,
    3 = like 1 but without the waves' turns at the higher issue priority (A/B) */
 void lsq_hip_debug_set_own(int v);
+/* owner windows: shortest run (bytes of one row an owner reads) the plan accepts; 0 = the default (kOwnMinRunBytes) */
+void lsq_hip_debug_set_own_min_run(int v);
+/* owner windows: channel group of the plan -- 0 = the policy, 1 = the smallest that works, 2 = the largest that still gives every CU an owner */
+void lsq_hip_debug_set_own_fat(int v);
 /* tuning only: override the workgroups-per-CU of the observer-statistics kernels (0 = defaults) */
 void lsq_hip_debug_set_observe_wg_per_cu(int v);
 #ifdef __cplusplus

@@ -287,15 +287,18 @@ struct OwnPlan {
     int R;                // row slots per workgroup
     int block_threads;    // R * lanes_per_row rounded up to whole waves
     int per_cu;           // owners resident per CU the plan was sized for
+    int run_bytes;        // bytes of one row an owner reads (k * inner * element size)
 };
-static inline OwnPlan plan_own(int64_t outer, int64_t C, int64_t inner, int vec, int elem_bytes, int dma_depth, int cus,
-                               int block_limit = 512) {
-    OwnPlan o{0, 0, 0, 0, 0};
-    if (vec <= 1 || inner < vec) return o;                         // (inner < V: the row-group / last-axis kernels' ground)
-    int k = 0;
-    for (int kk = 1; kk <= vec; ++kk)
-        if ((kk * inner) % vec == 0 && C % kk == 0) { k = kk; break; }
-    if (k == 0) return o;
+// min_run_bytes: the shortest run an owner may have (a run is what a workgroup reads of ONE row); the plan grows the channel
+// group until the run is that long.  The default is no minimum: short runs are fine on small tensors ([64,1024,5,5] fp32,
+// 400-byte runs: 11.3 -> 8.1 us; [256,2048,7] fp32, 112-byte runs: 16.7 -> 14.1 us) and it is the launch policy that keeps
+// them off larger ones (lsq_per_channel.hip, kOwnMaxElemsShortRun; profiles/r04_owner_min_run.txt).  Tools builds can set one.
+constexpr int kOwnMinRunBytes = 1;
+constexpr int kOwnFatDefault = 1;
+// one candidate: owners of k channels
+static inline OwnPlan plan_own_k(int64_t k, int64_t outer, int64_t C, int64_t inner, int vec, int elem_bytes, int dma_depth, int cus,
+                                 int block_limit) {
+    OwnPlan o{0, 0, 0, 0, 0, 0};
     const int64_t lanes = k * inner / vec;
     if (lanes > 256) return o;                                     // long channel rows: the 256-lane windows / segment walk
     const int64_t owners = C / k;
@@ -304,23 +307,44 @@ static inline OwnPlan plan_own(int64_t outer, int64_t C, int64_t inner, int vec,
     // waves a CU can hold per owner: 16 of the 1024-lane launch bound, and the ring's LDS (dma_depth stages of 2 KiB per wave)
     const int lds_waves = static_cast<int>(((160 * 1024) / per_cu - 2048) / (dma_depth * kDmaStageBytes));
     const int max_lanes = std::min(block_limit, std::min(1024 / per_cu, lds_waves * 64)) / 64 * 64;
-    int r_max = static_cast<int>(std::min<int64_t>(max_lanes / lanes, outer));
+    const int r_max = static_cast<int>(std::min<int64_t>(max_lanes / lanes, outer));
     if (r_max < 2) return o;
+    // a divisor of the row count close to the maximum: every lane then walks the same number of rows.  None (58 rows = 2 x 29
+    // against 10 row slots): all the slots, and a short last tile -- the kernel's blocks stop one tile early and the rest is
+    // walked row by row (bwd_pc_kernel, `ragged`).
     int R = r_max;
-    for (int d = r_max; d * 5 >= r_max * 3; --d)                   // a divisor of the row count close to the maximum: every
-        if (outer % d == 0) { R = d; break; }                      // lane then walks the same number of rows (the loop's fast form)
+    for (int d = r_max; d * 5 >= r_max * 3; --d)
+        if (outer % d == 0) { R = d; break; }
     // the ring wants 2 x its depth of row tiles per lane: few rows -> fewer row slots (a thinner workgroup), down to two
     while (R > 2 && (outer + R - 1) / R < 2 * dma_depth) {
         int next = R - 1;
-        for (int d = R - 1; d >= 2; --d)
+        for (int d = R - 1; d >= 2 && d * 5 >= (R - 1) * 3; --d)
             if (outer % d == 0) { next = d; break; }
         R = next;
     }
     if ((outer + R - 1) / R < 2 * dma_depth) return o;              // too few rows per lane to run the ring
-    o.k = k; o.lanes_per_row = static_cast<int>(lanes); o.R = R; o.per_cu = per_cu;
+    o.k = static_cast<int>(k); o.lanes_per_row = static_cast<int>(lanes); o.R = R; o.per_cu = per_cu;
     o.block_threads = static_cast<int>((R * lanes + 63) / 64 * 64);
-    (void)elem_bytes;
+    o.run_bytes = static_cast<int>(k * inner * elem_bytes);
     return o;
+}
+// fat: among the channel groups that work, 0 = the smallest (most owners), 1 = the LARGEST that still gives every CU an owner
+// (fewer, fatter owners with longer runs; the smallest when none does)
+static inline OwnPlan plan_own(int64_t outer, int64_t C, int64_t inner, int vec, int elem_bytes, int dma_depth, int cus,
+                               int block_limit = 512, int min_run_bytes = kOwnMinRunBytes, int fat = kOwnFatDefault) {
+    OwnPlan first{0, 0, 0, 0, 0, 0}, best{0, 0, 0, 0, 0, 0};
+    if (vec <= 1 || inner < vec) return first;                     // (inner < V: the row-group / last-axis kernels' ground)
+    // channel counts whose run is whole packets, divides C, is long enough and no wider than 256 lanes
+    // (fewer than 3/4 CUs' worth of owners from some kk on: nothing beyond it can work -- at most C / (3/4 CUs) candidates)
+    for (int64_t kk = 1; kk <= C && kk * inner <= static_cast<int64_t>(256) * vec && 4 * (C / kk) >= 3 * static_cast<int64_t>(cus); ++kk) {
+        if ((kk * inner) % vec != 0 || C % kk != 0 || kk * inner * elem_bytes < min_run_bytes) continue;
+        const OwnPlan o = plan_own_k(kk, outer, C, inner, vec, elem_bytes, dma_depth, cus, block_limit);
+        if (o.k == 0) continue;
+        if (first.k == 0) first = o;
+        if (!fat) break;
+        if (C / kk >= cus) best = o;
+    }
+    return (fat && best.k) ? best : first;
 }
 static inline PcGeom make_geom_own(int64_t outer, int64_t C, int64_t inner, int vec, const OwnPlan& o) {
     PcGeom g;

@@ -746,7 +746,13 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
                 emit_row(walk.row(it) < g.outer ? walk.row(it) : g.outer - 1, gi, xi, it < walk.n_rows);
             }
         };
-        auto loop = [&](auto all_valid, auto nt) {
+        // ragged (owner windows only): the last row tile is short -- the lanes of the row slots past its end have one row
+        // fewer.  The blocks then stop one tile early (their refills never reach the short tile) and the rows they leave are
+        // walked one at a time with the validity and the row clamp of the generic form.
+        auto loop = [&](auto all_valid, auto nt, auto ragged) {
+            constexpr bool kTailValid = decltype(all_valid)::value && !decltype(ragged)::value;
+            [[maybe_unused]] const std::integral_constant<bool, kTailValid> tail_valid{};
+            const int64_t dma_blocks = dma_n - (decltype(ragged)::value ? 1 : 0);
             if constexpr (decltype(all_valid)::value) {
                 // Steady state in blocks of DMA rows: the ring stage of a row is a compile-time constant (its LDS addresses
                 // are instruction offsets), the lane's row addresses advance by one add (every lane walks every row: no
@@ -798,8 +804,8 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
                     i += DMA;
                 };
                 static_assert(2 * (DMA - 1) + DMA <= 15, "wait_vm_upto covers counts up to 15");
-                if (i + 2 * DMA <= dma_n) block(std::true_type{});
-                while (i + 2 * DMA <= dma_n) block(std::false_type{});
+                if (i + 2 * DMA <= dma_blocks) block(std::true_type{});
+                while (i + 2 * DMA <= dma_blocks) block(std::false_type{});
                 if constexpr (OWN) __builtin_amdgcn_s_setprio(0);
                 if constexpr (PRE32) {
 #pragma unroll
@@ -809,15 +815,15 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
             // the rows the blocks left over (and every row of a wave with dead lanes or a ragged last tile): one at a time,
             // ring stage and validity at run time.  `stores`: dx stores younger than row i's copies -- known only when every
             // row of the wave stores (see above); otherwise they are left out of the count (the wait is then longer).
-            auto stores = [&](int64_t row) { return decltype(all_valid)::value ? static_cast<int>(row < DMA ? row : DMA) : 0; };
+            auto stores = [&](int64_t row) { return kTailValid ? static_cast<int>(row < DMA ? row : DMA) : 0; };
             for (; i + DMA < dma_n; ++i) {           // the ring is full, one refill per row
                 LSQ_TL_WAIT(wait_vm_upto(2 * (DMA - 1) + stores(i)));
-                consume(i, true, all_valid);
+                consume(i, true, tail_valid);
                 if (PRE32 && (i & (kPreRows - 1)) == kPreRows - 1) flush_pre(std::true_type{});
             }
             for (; i < dma_n; ++i) {                 // the last DMA rows: nothing left to request
                 LSQ_TL_WAIT(wait_vm_upto(static_cast<int>(2 * (dma_n - 1 - i)) + stores(i)));
-                consume(i, false, all_valid);
+                consume(i, false, tail_valid);
                 if (PRE32 && (i & (kPreRows - 1)) == kPreRows - 1) flush_pre(std::true_type{});
             }
             flush_pre(std::true_type{});
@@ -831,10 +837,15 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
         };
         // every lane of this wave walks all dma_n rows (no dead lane, no ragged last tile): no per-row validity selects
         if (__builtin_amdgcn_readfirstlane(__all(site.live && walk.n_rows == dma_n) ? 1 : 0)) {
-            if (g.ring_nt) loop(std::true_type{}, std::true_type{});
-            else loop(std::true_type{}, std::false_type{});
+            if (g.ring_nt) loop(std::true_type{}, std::true_type{}, std::false_type{});
+            else loop(std::true_type{}, std::false_type{}, std::false_type{});
+        } else if (OWN && __builtin_amdgcn_readfirstlane(__all(site.live && walk.n_rows + 1 >= dma_n) ? 1 : 0)) {
+            if constexpr (OWN) {       // some of this wave's row slots miss the last tile only
+                if (g.ring_nt) loop(std::true_type{}, std::true_type{}, std::true_type{});
+                else loop(std::true_type{}, std::false_type{}, std::true_type{});
+            }
         } else {
-            loop(std::false_type{}, std::false_type{});
+            loop(std::false_type{}, std::false_type{}, std::false_type{});
         }
     } else if (PIPE) {
         // Software pipeline, two register buffers: the loads of group k+1 are issued BEFORE the arithmetic of
@@ -1227,14 +1238,23 @@ template <int ELEM_BYTES>
 constexpr int kBigBlockOf = ELEM_BYTES < 4 ? 768 : 1024;
 // Owner windows (plan_own): launch bound of their kernels (the workgroup is R x lanes-per-row threads, at most this: eight
 // waves, so the 16-bit kernel keeps its ~120 registers without spilling) and the tensor size up to which the policy takes
-// them.  Measured (profiles/r04_owner_windows_ab.txt, backward op, cold): they win where the finalize launch is a large
-// share of the op -- [64,2048,7,7] bf16 15.8 -> 12.8 us, fp32 22.7 -> 18.8 us -- are level at 12.8 M elements and LOSE 15-30 %
-// from 25 M elements on (config 5: bf16 34.0 -> 39.5 us, fp32 59.1 -> 75.5 us; without the ring's streaming hint 38.8 / 69.7):
-// every owner walks the same rows at the same time and the kernel streams at 3.9-4.4 TB/s where the 256-lane windows,
-// whose row slabs spread the chip over the whole tensor, reach 5 TB/s -- although a no-arithmetic probe of the owner pattern
-// streams at 5.5 (profiles/r04_owner_pattern_probe.txt).
+// them.  Measured with one owner per CU (plan_own's fattest channel group; profiles/r04_owner_windows_ab2.txt, backward op,
+// cold): they win where the finalize launch is a large share of the op -- [64,2048,7,7] bf16 15.6 -> 11.9 us, fp32 22.9 ->
+// 18.5; [16,1024,14,14] fp32 17.2 -> 9.9 -- stay ahead in 16-bit storage up to 19 M elements ([192,2048,7,7] 28.2 -> 27.2,
+// [96,1024,14,14] 28.7 -> 26.8) and in fp32 up to 12.8 M ([128,2048,7,7] 33.4 -> 32.9, [32,512,28,28] 33.9 -> 31.2), and are
+// behind from there: fp32 16 M +2 %, 19 M +5 %, BASELINE config 5 (25.7 M) bf16 33.8 -> 35.6 us, fp32 59.8 -> 65.7 -- every owner
+// walks the same rows at the same time and the access pattern tops out at 5.4 TB/s (profiles/r04_owner_pattern_probe.txt),
+// where the row slabs of the 256-lane windows spread the chip over the whole tensor.
+// Short runs (channel rows of a few positions: 1-D feature maps, 3x3 ... 10x10) are fine -- [128,2048,4,4] fp32 17.9 -> 11.9 us,
+// [512,2048,8] 26.2 -> 23.1, [128,2048,5,5] 25.5 -> 19.4, bf16 [512,2048,8] 18.3 -> 13.7 -- unless they are under 512 bytes AND
+// not whole 128-byte lines: every row of every owner then shares a partial line with its neighbours ([rows,2048,7] fp32, eight
+// channels = 224 bytes: 384 rows 21.2 -> 20.4 us, 512 rows 24.9 -> 25.5, 768 rows 32.2 -> 39.3); those only up to 5 * 2^20
+// elements ([256,2048,7] 17.0 -> 11.8 us, [292,2048,7] 18.2 -> 13.8, [192,2048,3,3] 15.5 -> 11.1).  profiles/r04_owner_short_runs.txt, r04_owner_min_run.txt.
 constexpr int kOwnBlock = 512;
-constexpr int64_t kOwnMaxElems = int64_t{1} << 23;
+template <int ELEM_BYTES>
+constexpr int64_t kOwnMaxElemsOf = ELEM_BYTES < 4 ? int64_t{20} << 20 : (ELEM_BYTES == 4 ? int64_t{13} << 20 : int64_t{1} << 23);
+constexpr int64_t kOwnMaxElemsShortRun = int64_t{5} << 20;
+constexpr int kOwnShortRunBytes = 512;
 constexpr int kWwBwdBlocksPerCU = 4;     // row-group windows: one full round for every storage type (3-4 resident per CU)
 // Rows a forward workgroup walks at least, per unit of its per-workgroup overhead (make_geom): that overhead is only
 // the channel-table build -- VEC channels per lane when the quantized axis is the last one, so twice as heavy per
@@ -1609,12 +1629,17 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
         const int own_knob = knob::get(knob::kOwn);     // tools builds: 1 = wherever the shape allows, 2 = never, 3 = 1 without the priority turns
         const int own = own_knob == 3 ? 1 : own_knob;
         const int64_t bytes = c.outer * c.C * c.inner * static_cast<int64_t>(sizeof(typename IO::elem));
-        if (own != 2 && (own == 1 || (c.default_variant && c.outer * c.C * c.inner <= kOwnMaxElems))) {
+        if (own != 2 && (own == 1 || (c.default_variant && c.outer * c.C * c.inner <= kOwnMaxElemsOf<static_cast<int>(sizeof(typename IO::elem))>))) {
+            const int64_t elems = c.outer * c.C * c.inner;
             auto launch_own = [&](auto block_c) -> bool {
                 constexpr int OB = decltype(block_c)::value;
+                const int min_run = knob::get(knob::kOwnMinRun);           // tools builds: bytes, 0 = kOwnMinRunBytes
+                const int fat = knob::get(knob::kOwnFat);                  // tools builds: 1 = smallest channel group, 2 = fattest
                 const OwnPlan op = plan_own(c.outer, c.C, c.inner, V, static_cast<int>(sizeof(typename IO::elem)), kDmaDepth,
-                                            device_info().cu_count, OB);
+                                            device_info().cu_count, OB, min_run > 0 ? min_run : kOwnMinRunBytes,
+                                            fat ? fat - 1 : kOwnFatDefault);
                 if (op.k == 0) return false;
+                if (own != 1 && op.run_bytes < kOwnShortRunBytes && op.run_bytes % 128 != 0 && elems > kOwnMaxElemsShortRun) return false;
                 if (c.plan_need) return true;            // no workspace
                 PcGeom g = make_geom_own(c.outer, c.C, c.inner, V, op);
                 g.ring_nt = ring_nt_for(bytes, true, false);

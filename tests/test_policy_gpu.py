@@ -88,32 +88,49 @@ def test_streaming_hint_above_32_mb(T, dtype):
     esz = 4 if dtype == torch.float32 else 2
     lo, hi = _rows(32 * MB // esz + 1, 2048 * 7)        # NCHW-style windows: [rows, 2048, 7] quantized on axis 1
     (_, b_lo), (_, b_hi) = _case(T, (lo, 2048, 7), 1, dtype, (-8, 7, -128, 127)), _case(T, (hi, 2048, 7), 1, dtype, (-8, 7, -128, 127))
-    # (fp32: 32 MB is also the 2^23 elements up to which such a tensor takes owner windows -- test_owner_windows_band)
+    # ([rows,2048,7]: runs of 224 / 112 bytes -- owner windows only up to 5 * 2^20 elements, test_owner_windows_band)
     assert b_lo["kind"] in ("windows", "owners") and b_hi["kind"] == "windows" and b_lo["ring_depth"] == b_hi["ring_depth"] == 4
     assert (b_lo["ring_nt"], b_hi["ring_nt"]) == (0, 1)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_owner_windows_band(T, dtype):
-    """NCHW activations with short channel rows, up to 2^23 elements: OWNER windows -- a fat workgroup owns k whole channels
-    (the smallest count whose run is whole 16-byte packets) for ALL rows, stores d_scale / d_shift itself, one launch, no
-    workspace (profiles/r04_owner_windows_ab.txt: -7 .. -45 % there); above 2^23 elements, with too few owners for the chip,
-    or with channel rows longer than 256 lanes: the 256-lane windows + finalize launch as before"""
+    """NCHW activations with short channel rows, up to 20 M elements in 16-bit storage / 13 M in fp32: OWNER windows -- a fat
+    workgroup owns k whole channels (the LARGEST packet-aligned group that still gives every CU an owner) for ALL rows, stores
+    d_scale / d_shift itself, one launch, no workspace (profiles/r04_owner_windows_ab2.txt: -2 .. -50 % there); above the
+    bound, with too few owners for the chip, with runs that are under 512 bytes and not whole cache lines above 5 * 2^20 elements,
+    or with channel rows longer than
+    256 lanes: the 256-lane windows + finalize launch as before"""
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    k = 8 if dtype == torch.bfloat16 else 4                          # 7 x 7 = 49 elements per channel row
-    lo, hi = _rows((1 << 23) + 1, 2048 * 49)
-    (_, a), (_, b) = _case(T, (lo, 2048, 7, 7), 1, dtype, (-8, 7, -128, 127)), _case(T, (hi, 2048, 7, 7), 1, dtype, (-8, 7, -128, 127))
+    q = (-8, 7, -128, 127)
+    # 7 x 7 = 49 elements per channel row; 2048 channels in groups of 8 = one owner per CU on a 256-CU part
+    lo, hi = (208, 216) if dtype == torch.bfloat16 else (135, 136)       # 20.9 / 21.7 M and 13.5 / 13.6 M elements
+    assert lo * 2048 * 49 <= ((20 << 20) if dtype == torch.bfloat16 else (13 << 20)) < hi * 2048 * 49
+    (_, a), (_, b) = _case(T, (lo, 2048, 7, 7), 1, dtype, q), _case(T, (hi, 2048, 7, 7), 1, dtype, q)
     assert a["kind"] == "owners" and b["kind"] == "windows", (a, b)
-    assert a["grid_x"] == 2048 // k and a["grid_y"] == 1 and a["block"] <= 512 and a["ring_depth"] == 4, a
+    assert a["grid_y"] == 1 and a["block"] <= 512 and a["ring_depth"] == 4, a
+    assert a["grid_x"] >= cus and (cus != 256 or a["grid_x"] == 256), a            # the fattest group that leaves no CU without an owner
     # few rows: thinner workgroups (fewer row slots), still one launch
-    (_, c) = _case(T, (16, 2048, 7, 7), 1, dtype, (-8, 7, -128, 127))
+    (_, c) = _case(T, (16, 2048, 7, 7), 1, dtype, q)
     assert c["kind"] == "owners" and c["block"] < a["block"], (a, c)
     # too few owners to cover the chip (512 channels / k): windows
-    (_, d) = _case(T, (64, 512, 7, 7), 1, dtype, (-8, 7, -128, 127))
+    k = 8 if dtype == torch.bfloat16 else 4
+    (_, d) = _case(T, (64, 512, 7, 7), 1, dtype, q)
     assert d["kind"] == "windows" and (512 // k) * 4 < 3 * cus, d
     # long channel rows (56 x 56): windows
     (_, e) = _case(T, (8, 256, 56, 56), 1, dtype)
     assert e["kind"] == "windows", e
+    # 58 rows = 2 x 29: no divisor near the ten (five) row slots a workgroup holds -- all the slots and a short last tile
+    (_, f) = _case(T, (58, 2048, 7, 7), 1, dtype, q)
+    assert f["kind"] == "owners" and f["block"] > 256, f
+    # short runs are fine (eight channels of 8 positions: 256 / 128 bytes, whole cache lines) ...
+    (_, g) = _case(T, (512, 2048, 8), 1, dtype, q)
+    assert g["kind"] == "owners", g
+    if dtype == torch.float32:
+        # ... unless they are under 512 bytes and not whole 128-byte lines (eight channels of 7 positions = 224 bytes): those
+        # only up to 5 * 2^20 elements
+        (_, h), (_, i) = _case(T, (360, 2048, 7), 1, dtype, q), _case(T, (368, 2048, 7), 1, dtype, q)
+        assert h["kind"] == "owners" and i["kind"] == "windows", (h, i)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -9,11 +9,14 @@ import torch
 from exp_knob_ab import lib, time_bwd
 import lsq_tools
 
-SHAPES = [(256, 2048, 7, 7), (128, 1024, 14, 14), (128, 512, 28, 28),                                   # 25-51 M elements: windows win
-          (96, 2048, 7, 7), (80, 2048, 7, 7), (64, 1024, 14, 14), (48, 1024, 14, 14), (32, 2048, 14, 14),       # 8-13 M: mixed
-          (64, 2048, 7, 7), (32, 2048, 7, 7), (16, 2048, 7, 7), (32, 1024, 14, 14), (16, 1024, 14, 14),         # <= 2^23: the policy's band
-          (32, 512, 28, 28), (16, 512, 28, 28), (32, 256, 28, 28), (64, 256, 14, 14), (128, 256, 14, 14),
-          (64, 512, 7, 7), (32, 256, 56, 56)]                                                                   # not eligible: windows either way
+SHAPES = [(256, 2048, 7, 7), (128, 1024, 14, 14), (128, 512, 28, 28), (64, 2048, 14, 14), (64, 512, 28, 28),            # 25-51 M elements
+          (192, 2048, 7, 7), (96, 1024, 14, 14), (48, 512, 28, 28), (160, 2048, 7, 7), (80, 1024, 14, 14), (40, 512, 28, 28),  # 16-19 M
+          (128, 2048, 7, 7), (64, 1024, 14, 14), (32, 2048, 14, 14), (32, 512, 28, 28),                                  # 12.8 M
+          (96, 2048, 7, 7), (80, 2048, 7, 7), (48, 1024, 14, 14),                                                        # 8-10 M
+          (64, 2048, 7, 7), (32, 2048, 7, 7), (16, 2048, 7, 7), (32, 1024, 14, 14), (16, 1024, 14, 14),                  # <= 2^23: the policy's band
+          (16, 512, 28, 28), (32, 256, 28, 28), (64, 256, 14, 14), (128, 256, 14, 14),
+          (58, 2048, 7, 7), (83, 2048, 7, 7), (33, 2048, 7, 7), (83, 512, 14, 14), (37, 1024, 14, 14),                   # row counts without a divisor near the row slots: a short last tile
+          (64, 512, 7, 7), (32, 256, 56, 56)]                                                                            # not eligible: windows either way
 
 
 def main():

@@ -5,7 +5,7 @@ For each threshold (tests/test_policy_gpu.py pins the branch taken on either sid
 of it -- the two points next to the threshold are the shapes just below / just above it -- and the forward and the backward op are
 timed on the GPU (HIP-graph replay, inputs rotated through > 1 GB so that they come from HBM).  Reported per point: us per op
 and ps per element; the step across the threshold, in ps per element, is flagged when it exceeds 10 %.
-Output: profiles/r03_policy_cliffs.txt."""
+Output: profiles/r03_policy_cliffs.txt, r04_policy_cliffs.txt (another box, + the owner band's bound)."""
 import os
 import sys
 
@@ -98,6 +98,17 @@ def main():
     sweep("160 MB: fp32 row groups leave the ring ([rows,768])", last(768), 160 * MB // 4 + 1, 1, f32)
     for dt in (f32, bf16):
         sweep("512 MB: row groups give way to 256-lane windows ([rows,2048])", last(2048), 512 * MB // (4 if dt == f32 else 2), 1, dt)
+    # (round 4) owner windows: NCHW activations of at most 13 M (fp32) / 20 M (16-bit) elements take one launch without finalize
+    sweep("13 * 2^20 elements: owner windows up to here, 256-lane windows + finalize above ([rows,2048,7,7] axis 1)",
+          lambda r: (r, 2048, 7, 7), (13 << 20) + 1, 1, f32, (-8, 7, -128, 127))
+    sweep("13 * 2^20 elements: owner windows up to here ([rows,512,14,14] axis 1)",
+          lambda r: (r, 512, 14, 14), (13 << 20) + 1, 1, f32, (-8, 7, -128, 127))
+    sweep("20 * 2^20 elements: owner windows up to here, 256-lane windows + finalize above ([rows,2048,7,7] axis 1)",
+          lambda r: (r, 2048, 7, 7), (20 << 20) + 1, 1, bf16, (-8, 7, -128, 127))
+    sweep("20 * 2^20 elements: owner windows up to here ([rows,512,14,14] axis 1)",
+          lambda r: (r, 512, 14, 14), (20 << 20) + 1, 1, bf16, (-8, 7, -128, 127))
+    sweep("5 * 2^20 elements: owner windows whose runs are under 512 bytes and not whole cache lines only up to here ([rows,2048,7] axis 1: 224-byte runs)",
+          lambda r: (r, 2048, 7), (5 << 20) + 1, 1, f32, (-8, 7, -128, 127))
     sweep("2^24 elements: NO switch here any more -- the 16-bit last-axis forward rule was implied by its tiles-per-workgroup condition ([rows,4096])", last(4096), 1 << 24, 1, bf16)
 
 
