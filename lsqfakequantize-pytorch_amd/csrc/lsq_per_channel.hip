@@ -1675,6 +1675,10 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
             // profiles/r02_ww_min_rows_sweep.txt)
             const bool big_wide = WW && sizeof(typename IO::elem) >= 4 &&
                                   c.outer * c.C * static_cast<int64_t>(sizeof(typename IO::elem)) > (int64_t{160} << 20);
+            // ... and not below 2^24 elements either: register loops are level or ahead there on every row width -- 1 M elements
+            // -8 .. -12 % ([1024,1024] 10.1 -> 8.9 us), 2-4 M 0 .. -6 %, 8.4 M -3 .. -11 %, 12.6 M -3 .. -6 %; from 16.8 M on the
+            // ring leads ([16384,1024] 51.3 -> 44.7 us).  profiles/r04_rowgroup_ring_small.txt, r04_rowgroup_mid.txt
+            const bool small_wide = WW && sizeof(typename IO::elem) >= 4 && c.outer * c.C < (int64_t{1} << 24);
             if constexpr (WW && !EVAL) {
                 // Mid-sized tensors whose rows fit one window (8 M .. 80 M elements: [64,197,768], [256,197,768], NHWC
                 // [16,56,56,256]): ONE 768/1024-lane workgroup per CU instead of three or four 3-4-wave ones -- the same
@@ -1684,10 +1688,17 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
                 // profiles/r03_ww_big_upper_ab.txt -- 16-bit storage -7 % at 48 M elements, -1 .. -4 % at 64 M, +1 .. +5 % at 96 M).
                 const int big = knob::get(knob::kWwBig);
                 const int64_t elems = c.outer * c.C;
-                // (4- and 8-byte storage only up to 64 MB -- tensors that are usually still cache-resident; from HBM the
-                // usual workgroups win there: [256,197,768] fp32 cold 91.5 vs 102.7 us, profiles/r02_cold_buffers_pc.txt)
-                const bool fits = sizeof(typename IO::elem) < 4 || elems * static_cast<int64_t>(sizeof(typename IO::elem)) <= (int64_t{64} << 20);
-                const bool use_big = big == 1 || (big == 0 && c.default_variant && c.C / V <= kBlock && fits &&
+                // (round 2 kept 4- and 8-byte storage up to 64 MB: [256,197,768] fp32 cold 91.5 vs 102.7 us for the usual
+                // workgroups, profiles/r02_cold_buffers_pc.txt)
+                // Round 4, another box (profiles/r04_rowgroup_mid.txt): 16-bit storage only -- in fp32 the fat workgroup never
+                // led (8.4 M: 26.3-29.4 us against 24.1-26.1 for register loops; 12.6 M: level with the usual ring) -- and
+                // only for rows of at least 64 lanes: [rows,64] bf16 loses 11-16 % with it (12.6 M elements 33.5 -> 28.0 us),
+                // [rows,128] 5-7 %, [rows,256] 2-3 %; from [rows,512] on it is level or ahead up to 67 M elements.  At the lower
+                // end, 8.4-11 M elements, it is -1 .. -8 % on nine shapes of twelve and +9 / +14 % on two with power-of-two row
+                // counts ([8192,1024], [4096,2048]), with a third of the partial rows (profiles/r04_ww_big_low_end.txt): the
+                // lower end stays at 2^23.
+                const bool fits = sizeof(typename IO::elem) < 4;
+                const bool use_big = big == 1 || (big == 0 && c.default_variant && c.C / V <= kBlock && c.C / V >= 64 && fits &&
                                                   elems >= (int64_t{1} << 23) && elems < (int64_t{5} << 24));
                 constexpr int kBigBlock = kBigBlockOf<sizeof(typename IO::elem)>;
                 if (use_big &&
@@ -1695,9 +1706,13 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
                         device_info().cu_count, big == 1 ? 0 : 2, INT64_MAX, kBigBlock))
                     return result;
             }
-            if (!(big_wide && c.v.dma != 2) &&
+            // The tiles-per-workgroup floor of the ring (as many as it is deep) does not hold for 16-bit row groups: there the
+            // ring is ahead with ONE tile per workgroup too -- [1568,512] bf16 13.1 -> 11.0 us, [16384,128] 21.0 -> 15.8,
+            // [1365,384] 11.9 -> 10.2, nothing behind by more than 2.5 % (profiles/r04_rowgroup_ring_small.txt)
+            const int64_t floor_tiles = (WW && sizeof(typename IO::elem) < 4) ? 1 : kDmaDepth;
+            if (!((big_wide || small_wide) && c.v.dma != 2) &&
                 run(bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, 1, true, true, false, WW, kDmaDepth>, kDmaDepth, target,
-                    c.v.dma == 2 ? 0 : kDmaDepth))
+                    c.v.dma == 2 ? 0 : floor_tiles))
                 return result;
         }
     }

@@ -133,22 +133,38 @@ def test_owner_windows_band(T, dtype):
         assert h["kind"] == "owners" and i["kind"] == "windows", (h, i)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_big_row_group_workgroups_band(T, dtype):
-    """one 768/1024-lane workgroup per CU for last-axis tensors of 2^23 .. 5 * 2^24 elements whose rows fit one window
-    (4-byte storage: only up to 64 MB)"""
+def test_big_row_group_workgroups_band(T):
+    """16-bit storage: one 768-lane workgroup per CU for last-axis tensors of 2^23 .. 5 * 2^24 elements whose rows fit one window
+    and are at least 64 lanes wide ([rows,64] loses 11-16 % with it, profiles/r04_rowgroup_mid.txt); fp32 never (register loops
+    or the usual ring are level or ahead at every size on the round-4 box)"""
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     is_big = lambda note: note["block"] > 256 and note["grid_x"] * note["grid_y"] == cus    # one fat workgroup per CU
+    dtype = torch.bfloat16
     lo, hi = _rows(1 << 23, 768)
     (_, a), (_, b) = _case(T, (lo, 768), 1, dtype), _case(T, (hi, 768), 1, dtype)
     assert not is_big(a) and is_big(b), (a, b)
-    assert b["block"] <= (1024 if dtype == torch.float32 else 768)
-    if dtype == torch.float32:
-        lo, hi = _rows(64 * MB // 4 + 1, 768)          # the 64 MB cap of 4-byte storage
-    else:
-        lo, hi = _rows(5 << 24, 768)                   # the upper end of the band
+    assert b["block"] <= 768
+    lo, hi = _rows(5 << 24, 768)                   # the upper end of the band
     (_, a), (_, b) = _case(T, (lo, 768), 1, dtype), _case(T, (hi, 768), 1, dtype)
     assert is_big(a) and not is_big(b), (a, b)
+    # narrow rows (32 lanes): the usual workgroups, on the ring
+    (_, c) = _case(T, ((1 << 24) // 256, 256), 1, dtype)
+    assert not is_big(c) and c["kind"] == "row-groups" and c["ring_depth"] == 4, c
+    (_, d) = _case(T, ((1 << 24) // 768, 768), 1, torch.float32)
+    assert not is_big(d) and d["kind"] == "row-groups", d
+
+
+def test_row_group_ring_by_storage_type(T):
+    """16-bit row groups: the LDS-DMA ring whatever the size (one tile per workgroup included: -3 .. -25 % on small tensors);
+    fp32: register loops below 2^24 elements (level or ahead at every width: 1 M elements -8 .. -12 %), the ring from there
+    up to 160 MB (profiles/r04_rowgroup_ring_small.txt, r04_rowgroup_mid.txt)"""
+    (_, a) = _case(T, (1568, 512), 1, torch.bfloat16)             # one row tile per workgroup
+    assert a["kind"] == "row-groups" and a["ring_depth"] == 4, a
+    lo, hi = _rows(1 << 24, 1024)
+    (_, b), (_, c) = _case(T, (lo, 1024), 1, torch.float32), _case(T, (hi, 1024), 1, torch.float32)
+    assert b["kind"] == c["kind"] == "row-groups" and (b["ring_depth"], c["ring_depth"]) == (0, 4), (b, c)
+    (_, d) = _case(T, (1024, 1024), 1, torch.float32)
+    assert d["ring_depth"] == 0, d
 
 
 def test_fp32_row_groups_leave_the_ring_above_160_mb(T):

@@ -92,8 +92,8 @@ def main():
         sweep("32 MB: streaming hint on the ring copies (256-lane windows, [rows,2048,7] axis 1)", lambda r: (r, 2048, 7),
               32 * MB // (4 if dt == f32 else 2) + 1, 1, dt, (-8, 7, -128, 127))
     for dt in (f32, bf16):
-        sweep("2^23 elements: one 768/1024-lane workgroup per CU from here ([rows,768])", last(768), 1 << 23, 1, dt)
-    sweep("64 MB: ... and for 4-byte storage only up to here ([rows,768])", last(768), 64 * MB // 4 + 1, 1, f32)
+        sweep("2^23 elements: 16-bit storage, one 768-lane workgroup per CU from here; fp32: nothing ([rows,768])", last(768), 1 << 23, 1, dt)
+    sweep("2^24 elements: fp32 row groups take the ring from here ([rows,1024])", last(1024), 1 << 24, 1, f32)
     sweep("5 * 2^24 elements: ... for 16-bit storage up to here ([rows,768])", last(768), 5 << 24, 1, bf16)
     sweep("160 MB: fp32 row groups leave the ring ([rows,768])", last(768), 160 * MB // 4 + 1, 1, f32)
     for dt in (f32, bf16):
