@@ -26,7 +26,7 @@ def time_bwd(shape, dtype, settings, knob="set_ww_max_log2", axis=1, fwd=False):
     for d in shape:
         n *= d
     esz = 2 if dtype == torch.bfloat16 else 4
-    K = max(2, min(8, -(-(1100 * MB) // (2 * n * esz))))
+    K = max(2, min(int(os.environ.get("LSQ_AB_SETS", "8")), -(-(1100 * MB) // (2 * n * esz))))     # (LSQ_AB_SETS=400: small tensors cold too)
     xs = [synth.normal_like(n, 10 + k, 0.5, 1.0, dtype=dtype, device=dev).view(shape) for k in range(K)]
     gs = [synth.normal_like(n, 50 + k, 0.0, 1e-3, dtype=dtype, device=dev).view(shape) for k in range(K)]
     s = synth.uniform_like(shape[axis], 3, 0.01, 0.05, device=dev)

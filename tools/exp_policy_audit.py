@@ -12,6 +12,7 @@ from exp_knob_ab import time_bwd
 import lsq_tools
 
 ALTS = [("set_own", 1), ("set_own", 2), ("set_ww_big", 1), ("set_ww_big", 2), ("force_ring", 1), ("force_ring", 2), ("set_seg_min_div", 1)]
+ALTS_FWD = [("force_ring", 1), ("force_ring", 2), ("set_fwd_direct", 1), ("set_fwd_direct", 2), ("set_fwd_direct", 4), ("set_seg_min_div", 1)]
 
 
 def shapes(rng, count):
@@ -40,20 +41,23 @@ def shapes(rng, count):
 
 
 def main():
-    count = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    fwd = "--forward" in sys.argv
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    count = int(args[0]) if args else 40
     rng = np.random.default_rng(2024)
-    print("# tools/exp_policy_audit.py: backward op, us, cold inputs; policy = the production launch; every alternative = one tools knob forced")
+    print("# tools/exp_policy_audit.py: %s op, us, cold inputs; policy = the production launch; every alternative = one tools knob forced" % ("forward" if fwd else "backward"))
     print("# (set_own 1/2: owner windows wherever possible / never; set_ww_big 1/2: one fat row-group workgroup per CU always / never;")
-    print("#  force_ring 1/2: register loops / LDS-DMA ring; set_seg_min_div 1: segment walk for whole spans only)")
+    print("#  force_ring 1/2: register loops / LDS-DMA ring; set_seg_min_div 1: segment walk for whole spans only;")
+    print("#  forward only: set_fwd_direct 1/2/4: lanes read their own parameters on the usual grid / the LDS table / direct for every lane form)")
     worst = []
     for dt_name in ("f32", "bf16"):
         dtype = {"bf16": torch.bfloat16, "f32": torch.float32}[dt_name]
         for shape, axis in shapes(rng, count):
-            base = time_bwd(shape, dtype, (("policy", 0),), "set_own", axis=axis)["policy"]
+            base = time_bwd(shape, dtype, (("policy", 0),), "set_own", axis=axis, fwd=fwd)["policy"]
             best = None
-            for knob, v in ALTS:
-                r = time_bwd(shape, dtype, (("alt", v),), knob, axis=axis)["alt"]
-                if r[1] != base[1] and (best is None or r[0] < best[0]):
+            for knob, v in (ALTS_FWD if fwd else ALTS):
+                r = time_bwd(shape, dtype, (("alt", v),), knob, axis=axis, fwd=fwd)["alt"]
+                if (fwd or r[1] != base[1]) and (best is None or r[0] < best[0]):      # (the forward's note does not tell table from direct)
                     best = (r[0], "%s %d" % (knob, v), r[1])
             line = "%-4s %-22s axis %d  policy %7.1f [%s]" % (dt_name, "x".join(map(str, shape)), axis, base[0], base[1])
             if best is not None:
