@@ -516,7 +516,7 @@ struct SegWalk {
 // Rows of at least one workgroup's span (W = 256 lanes x 16 bytes) always.  `short_rows_cus` > 0 (the forward and the
 // backward op; the CU count) adds SHORT rows, where part of the workgroup idles but the walk still wins because it needs no
 // partials and no finalize launch (profiles/r03_seg_min_ab.txt, forward / backward op against the window kernels):
-//   up to 16 workgroups per CU, rows of at least W/8:  [768,768] fp32 -14 % / -47 %, [64,64,3,3] -20 % / -50 %,
+//   up to 8 workgroups per CU, rows of at least W/8 (up to 16: W/2):  [768,768] fp32 -14 % / -47 %, [64,64,3,3] -20 % / -50 %,
 //       [3072,768] bf16 -1 % / -5 %, [1000,512] bf16 -1 % / -27 %;
 //   any channel count, rows of at least 3W/4:  [50257,768] fp32 -13 % / -33 %;
 //   not shorter rows on many channels: [32768,256] fp32 +60 % / +50 %, [16384,768] bf16 (3W/8) +18 % / +53 %.
@@ -528,7 +528,12 @@ static inline bool pick_segment_mode(int vec, int64_t outer, int64_t C, int64_t 
     if (short_rows_cus <= 0) return false;
     const int div = knob::get(knob::kSegMinDiv);     // tools builds, lsq_hip_debug_set_seg_min_div: rows of at least W/div
     if (div > 0) return inner * div >= W;
-    return C <= static_cast<int64_t>(short_rows_cus) * 16 ? inner * 8 >= W : inner * 4 >= 3 * W;
+    // (round 4, profiles/r04_seg_weights.txt: 48 weight shapes x two storage types -- the walk is 40-57 % ahead on nearly all of
+    //  them, but at 16 workgroups per CU rows under W/2 are behind in 16-bit storage: [4096,288] +32 %, [4096,576] +18 %,
+    //  [4096,768] +11 %, level from [4096,1024] on; at 8 per CU still ahead, [2048,288] -11 %.  So W/8 holds up to 8 per CU.)
+    if (C <= static_cast<int64_t>(short_rows_cus) * 8) return inner * 8 >= W;
+    if (C <= static_cast<int64_t>(short_rows_cus) * 16) return inner * 2 >= W;
+    return inner * 4 >= 3 * W;
 }
 
 static inline bool grid_fits(const SegGeom& g) { return g.C * g.segs <= 0x7fffffffLL && g.osplits <= 65535; }

@@ -218,8 +218,8 @@ def test_forward_of_16_bit_last_axis_takes_the_coarser_grid_when_it_has_the_rows
 
 def test_short_channel_rows_take_the_segment_walk(T):
     """weights on axis 0 whose channel rows are shorter than a workgroup's span (256 lanes x 16 bytes): one workgroup per
-    channel -- no partials, no finalize launch -- for rows of at least 1/8 of the span on up to 16 workgroups per CU, for rows of
-    at least 3/4 of it on any channel count; window kernels otherwise (profiles/r03_seg_min_ab.txt)"""
+    channel -- no partials, no finalize launch -- for rows of at least 1/8 of the span on up to 8 workgroups per CU, 1/2 of it
+    up to 16 per CU, 3/4 of it on any channel count; window kernels otherwise (profiles/r03_seg_min_ab.txt, r04_seg_weights.txt)"""
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     f32, bf16 = torch.float32, torch.bfloat16
     q = (-128, 127, -128, 127)
@@ -227,7 +227,9 @@ def test_short_channel_rows_take_the_segment_walk(T):
     for shape, dtype, want in (((768, 768), f32, "segment"), ((64, 64, 3, 3), f32, "segment"), ((768, 768), bf16, "segment"),
                                ((512, 128), f32, "segment"), ((512, 124), f32, "windows"),          # 1/8 of 1024 elements
                                ((512, 256), bf16, "segment"), ((512, 248), bf16, "windows"),        # 1/8 of 2048
-                               ((16 * cus, 256), f32, "segment"), ((many, 256), f32, "windows"),    # 16 workgroups per CU
+                               ((8 * cus, 256), f32, "segment"), ((8 * cus + 8, 256), f32, "windows"),    # 8 workgroups per CU: 1/8 of the span
+                               ((16 * cus, 512), f32, "segment"), ((16 * cus, 504), f32, "windows"),      # 16 per CU: half the span
+                               ((many, 512), f32, "windows"),
                                ((many, 768), f32, "segment"), ((many, 764), f32, "windows"),        # 3/4 of the span: any count
                                ((many, 1536), bf16, "segment"), ((many, 1528), bf16, "windows"),
                                ((8, 512, 768), f32, "windows")):                                    # eight "rows" of channels: not a weight
