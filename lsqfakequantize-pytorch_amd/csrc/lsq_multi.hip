@@ -14,7 +14,8 @@
 //    build, upload or keep alive, nothing to synchronise, HIP-graph capturable; the workgroup finds its item with a
 //    32-step scalar scan of `first[]` (SGPR compares, no memory beyond the kernarg lines every workgroup reads anyway);
 //  * d_scale / d_shift are finished by the workgroup itself (SegDirect): no partials, no workspace, no finalize launch.
-// A tensor takes part if the single-tensor policy would give it one workgroup per channel (multi_eligible); the host
+// A tensor takes part if the single-tensor policy would give it one workgroup per channel (multi_eligible: pick_segment_mode's
+// rule with its `fused` allowance for short rows on many channels); the host
 // layer sends the others through the single-tensor entry points.
 #include "lsq_kernels.hpp"
 #include "lsq_pc_geom.hpp"
@@ -101,7 +102,7 @@ template <typename IO>
 bool multi_eligible(int64_t outer, int64_t channels, int64_t inner, bool aligned16) {
     if (outer <= 0 || channels <= 0 || inner <= 0 || channels > 0x3fffffffLL) return false;
     const int vec = pick_vec(IO::VEC, channels * inner, aligned16);
-    if (vec != IO::VEC || !pick_segment_mode(vec, outer, channels, inner, device_info().cu_count)) return false;
+    if (vec != IO::VEC || !pick_segment_mode(vec, outer, channels, inner, device_info().cu_count, /*fused=*/true)) return false;
     const SegGeom sg = make_seg_geom(outer, channels, inner, vec, device_info().cu_count * 16);     // the segment kernels' default grid
     return sg.segs == 1 && sg.osplits == 1;
 }

@@ -520,7 +520,7 @@ struct SegWalk {
 //       [3072,768] bf16 -1 % / -5 %, [1000,512] bf16 -1 % / -27 %;
 //   any channel count, rows of at least 3W/4:  [50257,768] fp32 -13 % / -33 %;
 //   not shorter rows on many channels: [32768,256] fp32 +60 % / +50 %, [16384,768] bf16 (3W/8) +18 % / +53 %.
-static inline bool pick_segment_mode(int vec, int64_t outer, int64_t C, int64_t inner, int short_rows_cus = 0) {
+static inline bool pick_segment_mode(int vec, int64_t outer, int64_t C, int64_t inner, int short_rows_cus = 0, bool fused = false) {
     if (vec == 1 || inner % vec != 0) return false;
     const int64_t W = static_cast<int64_t>(kBlock) * vec;
     if (outer >= 8 || C * ((inner + W - 1) / W) > 0x7fffffffLL) return false;
@@ -531,7 +531,9 @@ static inline bool pick_segment_mode(int vec, int64_t outer, int64_t C, int64_t 
     // (round 4, profiles/r04_seg_weights.txt: 48 weight shapes x two storage types -- the walk is 40-57 % ahead on nearly all of
     //  them, but at 16 workgroups per CU rows under W/2 are behind in 16-bit storage: [4096,288] +32 %, [4096,576] +18 %,
     //  [4096,768] +11 %, level from [4096,1024] on; at 8 per CU still ahead, [2048,288] -11 %.  So W/8 holds up to 8 per CU.)
-    if (C <= static_cast<int64_t>(short_rows_cus) * 8) return inner * 8 >= W;
+    //  `fused`: the question is asked for the multi-tensor launch (lsq_multi.hip: the tensor is one of many in ONE launch, which
+    //  is worth more than the family choice of a single call) -- W/8 up to 16 per CU as before.
+    if (C <= static_cast<int64_t>(short_rows_cus) * (fused ? 16 : 8)) return inner * 8 >= W;
     if (C <= static_cast<int64_t>(short_rows_cus) * 16) return inner * 2 >= W;
     return inner * 4 >= 3 * W;
 }

@@ -1,5 +1,6 @@
 """GPU: many per-channel quantizers in one launch (lsq_hip_*_per_channel_multi -> functional.lsq_foreach -> LSQWeightGroup)
-against the same tensors through single calls: outputs and every gradient bit-identical."""
+against the same tensors through single calls: outputs and every gradient bit-identical (one exception, parameter gradients of
+16-bit short rows on very many channels: test_short_rows_on_many_channels_fuse_although_single_calls_take_windows)."""
 import numpy as np
 import pytest
 import torch
@@ -62,6 +63,33 @@ def test_foreach_equals_single_calls_bit_for_bit(dtype, mode):
                 assert u is None and v is None, (what, i)
                 continue
             assert u.shape == v.shape and _bits(u) == _bits(v), "%s of tensor %d %s differs (%s, %s)" % (what, i, shapes[i], dtype, mode)
+
+
+def test_short_rows_on_many_channels_fuse_although_single_calls_take_windows():
+    """16-bit weights with rows under half a workgroup's span on more than 8 x CUs channels ([3072,768], [4096,576]): a single
+    call takes the window kernels (the walk is 11-32 % behind there, profiles/r04_seg_weights.txt), the multi-tensor launch
+    still takes them as one-workgroup-per-channel segments (one launch is worth more): y and dx are the single calls' bits,
+    d_scale / d_shift are summed in another order -- both within the parity bar of the oracle"""
+    from helpers import assert_reduction_close
+    from oracle import lsq_oracle as O
+    from torchlsq import extension as E
+    dev = torch.device("cuda:0")
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    shapes = [(12 * cus, 768), (16 * cus, 576), (9 * cus, 768), (512, 512, 3, 3)]
+    dtype = torch.bfloat16
+    xs, gs, ss, bs = _weights(shapes, dtype, dev, 5100)
+    assert all(E.hip_multi_eligible(x, 0) for x in xs)
+    kw = dict(quant_min=-128, quant_max=127, type_min=-128, type_max=127, is_affine=True, use_grad_scaling=True, grad_scaler=1.0)
+    single = _run(None, xs, gs, ss, bs, kw, fused=False)
+    fused = _run(None, xs, gs, ss, bs, kw, fused=True)
+    for i, shape in enumerate(shapes):
+        assert _bits(single[0][i]) == _bits(fused[0][i]) and _bits(single[1][i]) == _bits(fused[1][i]), shape
+        outer, C, inner = O.axis_to_ocl(shape, 0)
+        r = O.bwd_pc(gs[i].float().cpu().numpy(), xs[i].float().cpu().numpy(), ss[i].cpu().numpy(), bs[i].cpu().numpy(), outer, C, inner,
+                     -128, 127, -128, 127, True, 1.0, False, False, False)
+        for route in (single, fused):
+            assert_reduction_close(route[2][i].cpu().numpy(), r.ds_wide, r.abs_ds, "%s ds" % (shape,))
+            assert_reduction_close(route[3][i].cpu().numpy(), r.db_wide, r.abs_db, "%s db" % (shape,))
 
 
 def test_fifty_conv_weights():
