@@ -67,13 +67,13 @@ def test_owner_windows_against_the_oracle(T, shape, dtype):
         assert took == 3, (shape, dtype)
 
 
+@pytest.mark.parametrize("shape", [(32, 2048, 7, 7), (37, 2048, 7, 7)])       # 37 rows: a short last tile (the loop's ragged form)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_owner_windows_wide_output_and_global_count(T, dtype):
+def test_owner_windows_wide_output_and_global_count(T, dtype, shape):
     """the sharded path's `wide` output (un-rounded fp64 sums) and a foreign element count in the scaler, straight from the
     owner kernel's epilogue; and the packed route (unscaled terms, caller's buffer)"""
     from torchlsq import extension as E
     dev = torch.device("cuda:0")
-    shape = (32, 2048, 7, 7)
     x, g, s, b = _inputs(shape, dtype, dev, seed=9)
     q = (-8, 7, -128, 127)
     n = x.numel()
