@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LSQ_HIP_ABI_VERSION 4
+#define LSQ_HIP_ABI_VERSION 5
 
 /* Storage type of x / grad / y / dx.  Arithmetic is fp32 for F32, BF16 and F16 storage and fp64
  * for F64 (reference CPU path: AT_DISPATCH_FLOATING_TYPES, lsq_cpu.cpp:37,92,182,243).
@@ -60,7 +60,8 @@ enum lsq_dtype {
 enum lsq_status {
     LSQ_OK = 0,
     LSQ_EINVAL = -1,    /* bad argument (null pointer, negative size, unknown dtype, ...) */
-    LSQ_EWORKSPACE = -2 /* workspace too small or misaligned */
+    LSQ_EWORKSPACE = -2, /* workspace too small or misaligned */
+    LSQ_ECOMM = -3       /* rank communicator: RCCL missing or an RCCL call failed (lsq_hip_last_error has its message) */
 };
 
 /* Scalar arguments shared by the four ops; field-for-field the trailing arguments of the
@@ -242,6 +243,52 @@ int lsq_hip_per_channel_multi_ok(int dtype, int64_t outer, int64_t channels, int
 
 int lsq_hip_forward_per_channel_multi(int dtype, const lsq_pc_item* items, int32_t count, const lsq_params* p, void* stream);
 int lsq_hip_backward_per_channel_multi(int dtype, const lsq_pc_item* items, int32_t count, const lsq_params* p, void* stream);
+
+/* ---- which launch a per-channel backward gets (host-only, nothing is launched) ---------------------- */
+
+/* The launch policy of lsq_hip_backward_per_channel run as a PLAN for a dense [outer, channels, inner] tensor of `dtype`
+ * whose buffers are (aligned16 != 0) or are not 16-byte aligned, with the modes of `p` (sym / init_mode / eval_mode):
+ *   out8 = [grid x, grid y, workgroups resident per CU the grid was sized for (0: not used), registers of the kernel
+ *           instantiation (0: not asked), kernel family -- 1 = 256-lane windows, 2 = row-group windows, 3 = segment walk,
+ *           4 = owner windows (one launch, no workspace) --, LDS-DMA ring depth (0 = register loops), workgroup size,
+ *           ring copies issued with the streaming hint]
+ * It is the same code path the launch takes (the sizes of lsq_hip_backward_per_channel_workspace come from it too), so a
+ * test on the SHIPPED library can tell which kernel family a shape runs without a debug build (tests/test_shipped_binary_gpu.py).
+ * Depends on the current device (CU count, the instantiation's register count): needs a GPU. */
+int lsq_hip_plan_backward_per_channel(int dtype, int64_t outer, int64_t channels, int64_t inner, int aligned16,
+                                      const lsq_params* p, int32_t* out8);
+
+/* ---- rank communicator: the one collective of the batch-sharded backward ------------------------------- */
+
+/* north_star: "batches shard across the 8 GPUs of one node with a single RCCL all-reduce over xGMI for the scale/shift
+ * gradient scalars".  The reference has no distributed code; a data-parallel user of it would all-reduce scale.grad / shift.grad
+ * through torch.distributed, whose enqueue costs ~60 us of host time per call -- as much as a rank's whole config-4 step
+ * takes on the GPU.  These entry points issue the same RCCL all-reduce directly, from the library: a communicator of its own
+ * (one per process group and rank, created once from a 128-byte id that rank 0 generates and the host layer broadcasts),
+ * and two ways to run a reduction --
+ *   lsq_hip_comm_all_reduce        on `stream`, in order with the kernels around it;
+ *   lsq_hip_comm_all_reduce_begin  on the communicator's own high-priority stream, after everything enqueued on `stream`
+ *                                  so far; `stream` itself goes on (the next step's kernels overlap the reduction) until
+ *   lsq_hip_comm_all_reduce_end    makes `stream` wait for reduction `ticket` (up to 8 may be outstanding).
+ * Both forms are legal under HIP-graph capture when every begin is ended before the capture ends.  send == recv reduces in
+ * place.  Elements: LSQ_F64 (the un-rounded [sum ds, sum db, count] of lsq_hip_backward_*'s dsdb_wide) or LSQ_F32 (the packed
+ * [min, -max] of the rank-synchronised observer).  The calls are made on the device the communicator was created on (the
+ * current device of lsq_hip_comm_create), from one thread at a time per communicator, in the same order on every rank.
+ * RCCL is resolved with dlopen at the first call (the copy the process already has loaded, else the system's): liblsq_hip.so
+ * has no link-time dependency on it, and without RCCL these calls return LSQ_ECOMM. */
+typedef struct lsq_comm lsq_comm;
+#define LSQ_COMM_ID_BYTES 128
+enum lsq_comm_op { LSQ_COMM_SUM = 0, LSQ_COMM_MIN = 1, LSQ_COMM_MAX = 2 };
+
+int lsq_hip_comm_unique_id(void* id /* LSQ_COMM_ID_BYTES, host memory */);
+int lsq_hip_comm_create(const void* id, int32_t rank, int32_t nranks, lsq_comm** out);
+int lsq_hip_comm_destroy(lsq_comm* comm);
+/* out4 = [rank, nranks, device, RCCL version code] */
+int lsq_hip_comm_info(const lsq_comm* comm, int32_t* out4);
+int lsq_hip_comm_all_reduce(lsq_comm* comm, const void* send, void* recv, int64_t count, int dtype, int op, void* stream);
+int lsq_hip_comm_all_reduce_begin(lsq_comm* comm, const void* send, void* recv, int64_t count, int dtype, int op,
+                                  void* stream, int32_t* ticket);
+int lsq_hip_comm_all_reduce_end(lsq_comm* comm, int32_t ticket, void* stream);
 
 /* ---- eval-mode backward from the saved mask ---------------------------------------------------- */
 

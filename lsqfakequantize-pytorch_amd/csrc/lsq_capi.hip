@@ -20,6 +20,13 @@
 namespace {
 
 thread_local char g_last_error[512] = "";
+}  // namespace
+
+namespace lsq {
+char* error_buffer() { return g_last_error; }      // lsq_comm.hip reports through the same thread-local message
+}  // namespace lsq
+
+namespace {
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -244,6 +251,26 @@ int lsq_hip_backward_per_channel(int dtype, const void* grad, const void* x, voi
                                  const lsq_bwd_extras* extras, void* workspace, size_t workspace_bytes, void* stream) {
     return lsq_hip_backward_per_channel_ex(dtype, grad, x, dx, ds, db, dsdb_wide, outer, channels, inner, scale, shift,
                                            p, extras, workspace, workspace_bytes, stream, 0);
+}
+
+int lsq_hip_plan_backward_per_channel(int dtype, int64_t outer, int64_t channels, int64_t inner, int aligned16,
+                                      const lsq_params* p, int32_t* out8) {
+    if (int rc = check_common(dtype, p)) return rc;
+    if (outer <= 0 || channels <= 0 || inner <= 0 || !out8)
+        return fail(LSQ_EINVAL, "plan_backward_per_channel: positive [outer, C, inner] and an output array");
+    lsq::LaunchNote note{0, 0, 0, 0, 0, 0, 0, 0};
+    size_t need = 0;
+    hipError_t e = hipSuccess;
+    // only the alignment of the (never dereferenced) buffer addresses matters to a plan
+    LSQ_DISPATCH_IO(dtype, {
+        void* const fake = reinterpret_cast<void*>(static_cast<uintptr_t>(aligned16 ? 4096 : 4096 + sizeof(typename IO::elem)));
+        e = lsq::backward_per_channel<IO>(fake, fake, fake, fake, fake, nullptr, outer, channels, inner, fake, fake, *p, fake, 0,
+                                          nullptr, 0, nullptr, &need, &note);
+    });
+    if (int rc = hip_status(e, "lsq_hip_plan_backward_per_channel")) return rc;
+    out8[0] = note.grid_x; out8[1] = note.grid_y; out8[2] = note.resident_per_cu; out8[3] = note.vgprs_hint;
+    out8[4] = note.kind; out8[5] = note.dma_depth; out8[6] = note.block; out8[7] = note.ring_nt;
+    return LSQ_OK;
 }
 
 int lsq_hip_per_channel_multi_ok(int dtype, int64_t outer, int64_t channels, int64_t inner, int aligned16) {

@@ -1,0 +1,220 @@
+// lsq_comm.hip -- the ONE collective of the batch-sharded backward, issued by the library itself (include/lsq_hip.h,
+// "rank communicator").  Host code only.
+//
+// The reference has no distributed code; north_star shards the batch over the GPUs of a node
+// with "a single RCCL all-reduce over xGMI for the scale/shift gradient scalars".  A rank's step on BASELINE config 4 is
+// ~90 us of GPU time, and torch.distributed's all_reduce costs ~60 us of HOST time per call (Work object, event pool,
+// watchdog bookkeeping, Python: profiles/r04_module_sync_cost.txt) -- one enqueue away from host-bound.  Here the same RCCL
+// call is made directly: ncclAllReduce on a communicator of the library's own, either on the caller's stream or (begin /
+// end) on a side stream ordered with two events, so a 16-24-byte reduction overlaps the next step's kernels and costs the
+// host a handful of HIP calls.
+//
+// RCCL is NOT a link dependency: the library is resolved at the first lsq_hip_comm_* call with dlopen -- the copy PyTorch has
+// already loaded when there is one (RTLD_NOLOAD on its name: one RCCL per process), the system's otherwise -- so liblsq_hip.so
+// loads and every other entry point works on a box without RCCL.
+#include <dlfcn.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/lsq_hip.h"
+
+namespace lsq {
+char* error_buffer();                 // lsq_capi.hip: the thread-local message behind lsq_hip_last_error()
+constexpr size_t kErrorBytes = 512;
+}  // namespace lsq
+
+namespace {
+
+// the subset of rccl.h this file needs (layout-compatible: an opaque handle, a 128-byte id, int enums)
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[LSQ_COMM_ID_BYTES]; } ncclUniqueId;
+enum { ncclSuccess = 0 };
+enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 };
+enum { ncclFloat32 = 7, ncclFloat64 = 8 };
+
+struct Rccl {
+    void* handle = nullptr;
+    int (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
+    char error[256] = "";
+};
+
+int fail(int code, const char* fmt, ...) {      // the message lsq_hip_last_error() returns (the calling thread's buffer)
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(lsq::error_buffer(), lsq::kErrorBytes, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+const Rccl* rccl() {
+    static Rccl lib;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // the copy this process already runs (PyTorch's: libtorch_hip.so needs "librccl.so") before a second one
+        const char* loaded[] = {"librccl.so", "librccl.so.1"};
+        for (const char* n : loaded) {
+            if (lib.handle) break;
+            lib.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        }
+        const char* fresh[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : fresh) {
+            if (lib.handle) break;
+            lib.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        }
+        if (!lib.handle) {
+            snprintf(lib.error, sizeof(lib.error), "RCCL not found (dlopen librccl.so: %s)", dlerror());
+            return;
+        }
+        auto sym = [&](const char* name) -> void* {
+            void* p = dlsym(lib.handle, name);
+            if (!p && !lib.error[0]) snprintf(lib.error, sizeof(lib.error), "RCCL lacks %s", name);
+            return p;
+        };
+        lib.GetUniqueId = reinterpret_cast<decltype(lib.GetUniqueId)>(sym("ncclGetUniqueId"));
+        lib.CommInitRank = reinterpret_cast<decltype(lib.CommInitRank)>(sym("ncclCommInitRank"));
+        lib.CommDestroy = reinterpret_cast<decltype(lib.CommDestroy)>(sym("ncclCommDestroy"));
+        lib.AllReduce = reinterpret_cast<decltype(lib.AllReduce)>(sym("ncclAllReduce"));
+        lib.GetErrorString = reinterpret_cast<decltype(lib.GetErrorString)>(sym("ncclGetErrorString"));
+        lib.GetVersion = reinterpret_cast<decltype(lib.GetVersion)>(sym("ncclGetVersion"));
+    });
+    return lib.error[0] ? nullptr : &lib;
+}
+
+int rccl_status(const Rccl* r, int rc, const char* what) {
+    if (rc == ncclSuccess) return LSQ_OK;
+    return fail(LSQ_ECOMM, "%s: RCCL error %d (%s)", what, rc, r->GetErrorString ? r->GetErrorString(rc) : "?");
+}
+
+int hip_status(hipError_t e, const char* what) {
+    if (e == hipSuccess) return LSQ_OK;
+    return fail(static_cast<int>(e), "%s: %s (%s)", what, hipGetErrorName(e), hipGetErrorString(e));
+}
+
+constexpr int kTickets = 8;      // begin / end pairs that may be outstanding at once
+
+}  // namespace
+
+struct lsq_comm {
+    ncclComm_t comm;
+    int rank, nranks, device;
+    hipStream_t side;                      // the stream the overlapped reductions run on
+    hipEvent_t ready[kTickets];            // recorded on the caller's stream: the buffer's producer has been enqueued
+    hipEvent_t done[kTickets];             // recorded on `side` behind the reduction
+    std::atomic<uint32_t> next;
+};
+
+extern "C" {
+
+int lsq_hip_comm_unique_id(void* id) {
+    if (!id) return fail(LSQ_EINVAL, "comm_unique_id: NULL buffer");
+    const Rccl* r = rccl();
+    if (!r) return fail(LSQ_ECOMM, "comm_unique_id: RCCL is not available on this system");
+    ncclUniqueId u;
+    if (int rc = rccl_status(r, r->GetUniqueId(&u), "ncclGetUniqueId")) return rc;
+    std::memcpy(id, u.internal, LSQ_COMM_ID_BYTES);
+    return LSQ_OK;
+}
+
+int lsq_hip_comm_create(const void* id, int32_t rank, int32_t nranks, lsq_comm** out) {
+    if (!id || !out) return fail(LSQ_EINVAL, "comm_create: NULL argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(LSQ_EINVAL, "comm_create: rank %d of %d", rank, nranks);
+    const Rccl* r = rccl();
+    if (!r) return fail(LSQ_ECOMM, "comm_create: RCCL is not available on this system");
+    lsq_comm* c = new lsq_comm();
+    c->rank = rank; c->nranks = nranks; c->next.store(0);
+    if (int rc = hip_status(hipGetDevice(&c->device), "hipGetDevice")) { delete c; return rc; }
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, LSQ_COMM_ID_BYTES);
+    if (int rc = rccl_status(r, r->CommInitRank(&c->comm, nranks, u, rank), "ncclCommInitRank")) { delete c; return rc; }
+    // the side stream outranks the streaming kernels it runs next to: its whole job is one tiny launch per step
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    hipError_t e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi);
+    for (int i = 0; i < kTickets && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {      // (a communicator that cannot get a stream is not worth tearing down carefully)
+        r->CommDestroy(c->comm);
+        delete c;
+        return hip_status(e, "comm_create: side stream / events");
+    }
+    *out = c;
+    return LSQ_OK;
+}
+
+int lsq_hip_comm_destroy(lsq_comm* c) {
+    if (!c) return LSQ_OK;
+    const Rccl* r = rccl();
+    (void)hipStreamSynchronize(c->side);
+    for (int i = 0; i < kTickets; ++i) {
+        (void)hipEventDestroy(c->ready[i]);
+        (void)hipEventDestroy(c->done[i]);
+    }
+    (void)hipStreamDestroy(c->side);
+    int rc = r ? rccl_status(r, r->CommDestroy(c->comm), "ncclCommDestroy") : LSQ_OK;
+    delete c;
+    return rc;
+}
+
+int lsq_hip_comm_info(const lsq_comm* c, int32_t* out4) {
+    if (!c || !out4) return fail(LSQ_EINVAL, "comm_info: NULL argument");
+    int version = 0;
+    const Rccl* r = rccl();
+    if (r && r->GetVersion) (void)r->GetVersion(&version);
+    out4[0] = c->rank; out4[1] = c->nranks; out4[2] = c->device; out4[3] = version;
+    return LSQ_OK;
+}
+
+static int check_reduce(const lsq_comm* c, const void* send, void* recv, int64_t count, int dtype, int op, int* nccl_type,
+                        int* nccl_op) {
+    if (!c || !send || !recv) return fail(LSQ_EINVAL, "comm_all_reduce: NULL argument");
+    if (count <= 0) return fail(LSQ_EINVAL, "comm_all_reduce: count must be positive");
+    if (dtype != LSQ_F32 && dtype != LSQ_F64) return fail(LSQ_EINVAL, "comm_all_reduce: LSQ_F32 or LSQ_F64 elements");
+    if (op < LSQ_COMM_SUM || op > LSQ_COMM_MAX) return fail(LSQ_EINVAL, "comm_all_reduce: unknown reduction %d", op);
+    *nccl_type = dtype == LSQ_F64 ? ncclFloat64 : ncclFloat32;
+    *nccl_op = op == LSQ_COMM_SUM ? ncclSum : (op == LSQ_COMM_MIN ? ncclMin : ncclMax);
+    return LSQ_OK;
+}
+
+int lsq_hip_comm_all_reduce(lsq_comm* c, const void* send, void* recv, int64_t count, int dtype, int op, void* stream) {
+    int t = 0, o = 0;
+    if (int rc = check_reduce(c, send, recv, count, dtype, op, &t, &o)) return rc;
+    const Rccl* r = rccl();
+    return rccl_status(r, r->AllReduce(send, recv, static_cast<size_t>(count), t, o, c->comm, static_cast<hipStream_t>(stream)),
+                       "ncclAllReduce");
+}
+
+int lsq_hip_comm_all_reduce_begin(lsq_comm* c, const void* send, void* recv, int64_t count, int dtype, int op, void* stream,
+                                  int32_t* ticket) {
+    int t = 0, o = 0;
+    if (int rc = check_reduce(c, send, recv, count, dtype, op, &t, &o)) return rc;
+    if (!ticket) return fail(LSQ_EINVAL, "comm_all_reduce_begin: NULL ticket");
+    const Rccl* r = rccl();
+    const uint32_t k = c->next.fetch_add(1) % kTickets;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = hip_status(hipEventRecord(c->ready[k], s), "comm_all_reduce_begin: hipEventRecord")) return rc;
+    if (int rc = hip_status(hipStreamWaitEvent(c->side, c->ready[k], 0), "comm_all_reduce_begin: hipStreamWaitEvent")) return rc;
+    if (int rc = rccl_status(r, r->AllReduce(send, recv, static_cast<size_t>(count), t, o, c->comm, c->side), "ncclAllReduce")) return rc;
+    if (int rc = hip_status(hipEventRecord(c->done[k], c->side), "comm_all_reduce_begin: hipEventRecord")) return rc;
+    *ticket = static_cast<int32_t>(k);
+    return LSQ_OK;
+}
+
+int lsq_hip_comm_all_reduce_end(lsq_comm* c, int32_t ticket, void* stream) {
+    if (!c || ticket < 0 || ticket >= kTickets) return fail(LSQ_EINVAL, "comm_all_reduce_end: bad ticket %d", ticket);
+    return hip_status(hipStreamWaitEvent(static_cast<hipStream_t>(stream), c->done[ticket], 0), "comm_all_reduce_end: hipStreamWaitEvent");
+}
+
+}  // extern "C"

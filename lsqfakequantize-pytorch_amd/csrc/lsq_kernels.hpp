@@ -200,8 +200,9 @@ inline int resident_blocks_per_cu(const void* kernel, size_t lds_bytes) {
     return n;
 }
 
-#ifdef LSQ_TOOLS
-// what the last window-mode backward launch of this thread looked like (lsq_hip_debug_last_launch; tools build only)
+// what a per-channel backward launch looks like: filled by a PLAN of the launch policy (lsq_hip_plan_backward_per_channel,
+// production and tools build alike) and -- tools build only -- kept per thread for the last real launch
+// (lsq_hip_debug_last_launch)
 struct LaunchNote {
     int grid_x, grid_y, resident_per_cu, vgprs_hint;
     int kind;        // 1 = 256-lane windows, 2 = row-group windows, 3 = segment mode, 4 = owner windows
@@ -209,6 +210,7 @@ struct LaunchNote {
     int block;       // workgroup size
     int ring_nt;
 };
+#ifdef LSQ_TOOLS
 inline LaunchNote& last_launch_note() {
     thread_local LaunchNote note = {0, 0, 0, 0, 0, 0, 0, 0};
     return note;
@@ -335,7 +337,8 @@ template <typename IO>
 hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void* ds, void* db, double* wide,
                                 int64_t outer, int64_t channels, int64_t inner, const void* scale,
                                 const void* shift, const lsq_params& p, void* workspace, size_t workspace_bytes,
-                                uint32_t* ticket, int variant, hipStream_t stream, size_t* plan_need = nullptr);
+                                uint32_t* ticket, int variant, hipStream_t stream, size_t* plan_need = nullptr,
+                                LaunchNote* plan_note = nullptr);
 
 // many per-channel quantizers in one launch (lsq_multi.hip)
 template <typename IO>

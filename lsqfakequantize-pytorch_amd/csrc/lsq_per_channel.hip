@@ -1511,6 +1511,7 @@ struct BwdPcCall {
     Variant v;
     hipStream_t stream;
     size_t* plan_need;     // not null: PLAN only -- record the workspace bytes the launch would need, launch nothing
+    LaunchNote* plan_note; // PLAN only, may be null: what the launch would look like (lsq_hip_plan_backward_per_channel)
 };
 
 
@@ -1589,6 +1590,9 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
         const size_t need = static_cast<size_t>(g.splits) * g.n_windows * g.k_slots * sizeof(double2);
         if (c.plan_need) {
             if (!p.eval_mode) *c.plan_need = std::max(*c.plan_need, need);
+            if (c.plan_note)
+                *c.plan_note = LaunchNote{static_cast<int>(g.n_windows), g.splits, per_cu, registers_of(reinterpret_cast<const void*>(kern)),
+                                          WW ? 2 : 1, dma_depth, g.block_threads, g.ring_nt};
             return true;
         }
         if (!p.eval_mode && c.workspace_bytes < need) { result = hipErrorInvalidValue; return true; }
@@ -1640,9 +1644,13 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
                                             fat ? fat - 1 : kOwnFatDefault);
                 if (op.k == 0) return false;
                 if (own != 1 && op.run_bytes < kOwnShortRunBytes && op.run_bytes % 128 != 0 && elems > kOwnMaxElemsShortRun) return false;
-                if (c.plan_need) return true;            // no workspace
                 PcGeom g = make_geom_own(c.outer, c.C, c.inner, V, op);
                 g.ring_nt = ring_nt_for(bytes, true, false);
+                if (c.plan_need) {                       // no workspace
+                    if (c.plan_note)
+                        *c.plan_note = LaunchNote{static_cast<int>(g.n_windows), 1, op.per_cu, 0, 4, kDmaDepth, g.block_threads, g.ring_nt};
+                    return true;
+                }
                 g.own_prio = own_knob == 3 ? 0 : 1;
 #if defined(LSQ_TOOLS) && defined(LSQ_TIMELINE)
                 g.timeline = knob::timeline_buffer().load();
@@ -1809,7 +1817,7 @@ template <typename IO>
 hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void* ds, void* db, double* wide,
                                 int64_t outer, int64_t channels, int64_t inner, const void* scale,
                                 const void* shift, const lsq_params& p, void* workspace, size_t workspace_bytes,
-                                uint32_t* ticket, int variant, hipStream_t stream, size_t* plan_need) {
+                                uint32_t* ticket, int variant, hipStream_t stream, size_t* plan_need, LaunchNote* plan_note) {
     using T = typename IO::arith;
     (void)ticket;
     const DeviceInfo& dev = device_info();
@@ -1834,6 +1842,7 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
         const size_t need = static_cast<size_t>(channels) * sg.segs * sg.osplits * sizeof(double2);
         if (plan_need) {
             if (!p.eval_mode) *plan_need = std::max(*plan_need, need);
+            if (plan_note) *plan_note = LaunchNote{static_cast<int>(sg.C * sg.segs), sg.osplits, 0, 0, 3, 0, kBlock, 0};
             return hipSuccess;
         }
         if (!p.eval_mode && workspace_bytes < need) return hipErrorInvalidValue;
@@ -1863,13 +1872,13 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
         // the chip holds (variant: workgroups per CU requested, rounded to whole rounds)
         BwdPcCall<T> call{grad, x, dx, static_cast<T*>(ds), static_cast<T*>(db), wide, outer, channels, inner, scale, shift, &p,
                           gs, sym_term, partials, workspace_bytes, variant == 0 ? dev.cu_count * kWwBwdBlocksPerCU : target,
-                          /*default_variant=*/variant == 0, /*whole_rounds=*/true, v, stream, plan_need};
+                          /*default_variant=*/variant == 0, /*whole_rounds=*/true, v, stream, plan_need, plan_note};
         return bwd_pc_modes<IO, VB, VB, true>(call);
     }
     const int target_w = (variant == 0 && last_axis) ? dev.cu_count * kLastAxisBwdBlocksPerCU : target;
     BwdPcCall<T> call{grad, x, dx, static_cast<T*>(ds), static_cast<T*>(db), wide, outer, channels, inner, scale, shift, &p,
                       gs, sym_term, partials, workspace_bytes, target_w, /*default_variant=*/variant == 0,
-                      /*whole_rounds=*/!last_axis, v, stream, plan_need};
+                      /*whole_rounds=*/!last_axis, v, stream, plan_need, plan_note};
     if (vecw == 1) return bwd_pc_modes<IO, 1, 1>(call);
     if (cpl == 1) return bwd_pc_modes<IO, VB, 1>(call);
     if (cpl == 2) return bwd_pc_modes<IO, VB, 2>(call);
@@ -1882,7 +1891,7 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
                                                 hipStream_t);                                                        \
     template hipError_t backward_per_channel<IO>(const void*, const void*, void*, void*, void*, double*, int64_t,    \
                                                  int64_t, int64_t, const void*, const void*, const lsq_params&,      \
-                                                 void*, size_t, uint32_t*, int, hipStream_t, size_t*);              \
+                                                 void*, size_t, uint32_t*, int, hipStream_t, size_t*, LaunchNote*); \
     template size_t bwd_pc_workspace_bytes<IO>(int64_t, int64_t, int64_t);
 // One translation unit per storage type (the Makefile compiles this file four times with -DLSQ_PC_IO=io_f32 ... in
 // parallel: the window kernels' template space takes minutes in one piece); without the macro, all four.

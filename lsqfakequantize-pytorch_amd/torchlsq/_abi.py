@@ -56,7 +56,7 @@ class LsqPcItem(ctypes.Structure):
 
 
 LSQ_TICKET_BYTES = 4096
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
 _PP = ctypes.POINTER(LsqParams)
@@ -80,6 +80,14 @@ C_ABI = {
                                             _vp, _sz, _vp]),
     "lsq_hip_sharded_finish": (_int, [_int, _vp, _i64, ctypes.c_int32, _PP, _vp, _vp, _vp]),
     "lsq_hip_per_channel_multi_ok": (_int, [_int, _i64, _i64, _i64, _int]),
+    "lsq_hip_plan_backward_per_channel": (_int, [_int, _i64, _i64, _i64, _int, _PP, ctypes.POINTER(ctypes.c_int32 * 8)]),
+    "lsq_hip_comm_unique_id": (_int, [_vp]),
+    "lsq_hip_comm_create": (_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_vp)]),
+    "lsq_hip_comm_destroy": (_int, [_vp]),
+    "lsq_hip_comm_info": (_int, [_vp, ctypes.POINTER(ctypes.c_int32 * 4)]),
+    "lsq_hip_comm_all_reduce": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
+    "lsq_hip_comm_all_reduce_begin": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, ctypes.POINTER(ctypes.c_int32)]),
+    "lsq_hip_comm_all_reduce_end": (_int, [_vp, ctypes.c_int32, _vp]),
     "lsq_hip_forward_per_channel_multi": (_int, [_int, ctypes.POINTER(LsqPcItem), ctypes.c_int32, _PP, _vp]),
     "lsq_hip_backward_per_channel_multi": (_int, [_int, ctypes.POINTER(LsqPcItem), ctypes.c_int32, _PP, _vp]),
     "lsq_hip_backward_from_mask": (_int, [_int, _vp, _vp, _vp, _i64, _vp]),

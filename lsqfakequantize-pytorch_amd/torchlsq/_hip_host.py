@@ -672,3 +672,107 @@ def hip_meanstd(x, axis=None):
     return _two_stats(x, axis, "lsq_meanstd", _abi._LIB.lsq_hip_meanstd_workspace, _abi._LIB.lsq_hip_meanstd_per_tensor,
                       _abi._LIB.lsq_hip_meanstd_per_channel)
 
+
+
+# ---- which launch a per-channel backward gets (lsq_hip_plan_backward_per_channel) --------------------------------------------
+_PLAN_KINDS = {0: "none", 1: "windows", 2: "row-groups", 3: "segment", 4: "owners"}
+
+
+def hip_plan_backward_per_channel(x, axis, sym=False, eval_mode=False, init_mode=False, aligned=None):
+    """The launch the library's policy gives the per-channel backward of GPU tensor `x` along `axis` -- kernel family, grid,
+    workgroup size, loop form -- as a dict; nothing is launched.  The SHIPPED library answers (no debug build needed)."""
+    _assert_has_ops()
+    _require_gpu("lsq_plan_backward_per_channel", x)
+    xd, order = _dense(x)
+    outer, C, inner = _ocl(xd, order, axis)
+    _, pref = _params(0, 127, 0, 255, True, 1.0, sym, eval_mode, init_mode)
+    out = (ctypes.c_int32 * 8)()
+    al = (xd.data_ptr() & 15) == 0 if aligned is None else bool(aligned)
+    rc = _on_device(x.device.index, _abi._LIB.lsq_hip_plan_backward_per_channel, _DTYPE_CODE[x.dtype], outer, C, inner,
+                    1 if al else 0, pref, ctypes.byref(out))
+    if rc:
+        _status(rc, "lsq_hip_plan_backward_per_channel")
+    return dict(grid_x=out[0], grid_y=out[1], resident_per_cu=out[2], vgprs=out[3], kind=_PLAN_KINDS.get(out[4], "?"),
+                ring_depth=out[5], block=out[6], ring_nt=out[7])
+
+
+# ---- rank communicator (lsq_hip_comm_*): the one collective of the batch-sharded backward, issued by the library ----------
+LSQ_COMM_SUM, LSQ_COMM_MIN, LSQ_COMM_MAX = 0, 1, 2
+LSQ_COMM_ID_BYTES = 128
+_COMM_DTYPES = {torch.float32: _abi.LSQ_F32, torch.float64: _abi.LSQ_F64}
+
+
+class HipComm:
+    """A communicator of the library's own over RCCL (include/lsq_hip.h, "rank communicator") for one rank on one GPU.
+    `unique_id()` on one rank, the 128 bytes to every rank by any means, `HipComm(id, rank, nranks, device)` on all of them
+    (a collective call: it returns once every rank has joined).  all_reduce runs on the current stream of the device;
+    begin / end run it on the communicator's own stream, ordered behind the work already enqueued on the current stream."""
+
+    @staticmethod
+    def unique_id():
+        _assert_has_ops()
+        buf = (ctypes.c_ubyte * LSQ_COMM_ID_BYTES)()
+        rc = _abi._LIB.lsq_hip_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p))
+        if rc:
+            _status(rc, "lsq_hip_comm_unique_id")
+        return bytes(buf)
+
+    def __init__(self, uid, rank, nranks, device):
+        _assert_has_ops()
+        _check(len(uid) == LSQ_COMM_ID_BYTES, "HipComm: the id is %d bytes" % LSQ_COMM_ID_BYTES)
+        self.device = torch.device(device)
+        self.index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.rank, self.nranks = int(rank), int(nranks)
+        handle = ctypes.c_void_p()
+        buf = (ctypes.c_ubyte * LSQ_COMM_ID_BYTES).from_buffer_copy(uid)
+        rc = _on_device(self.index, _abi._LIB.lsq_hip_comm_create, ctypes.cast(buf, ctypes.c_void_p), self.rank, self.nranks,
+                        ctypes.byref(handle))
+        if rc:
+            _status(rc, "lsq_hip_comm_create")
+        self.handle = handle.value
+
+    def info(self):
+        out = (ctypes.c_int32 * 4)()
+        rc = _abi._LIB.lsq_hip_comm_info(self.handle, ctypes.byref(out))
+        if rc:
+            _status(rc, "lsq_hip_comm_info")
+        return dict(rank=out[0], nranks=out[1], device=out[2], rccl_version=out[3])
+
+    def _args(self, t, out, op):
+        _check(t.is_cuda and t.device.index == self.index and t.is_contiguous() and t.dtype in _COMM_DTYPES,
+               "HipComm: a contiguous float32 / float64 tensor on cuda:%d" % self.index)
+        recv = t if out is None else out
+        _check(recv.dtype == t.dtype and recv.numel() == t.numel() and recv.is_contiguous() and recv.device == t.device,
+               "HipComm: `out` must match the input")
+        return t.data_ptr(), recv.data_ptr(), t.numel(), _COMM_DTYPES[t.dtype], int(op)
+
+    def all_reduce(self, t, op=LSQ_COMM_SUM, out=None):
+        """in place (or into `out`) on the device's current stream"""
+        a = self._args(t, out, op)
+        rc = _on_device(self.index, _abi._LIB.lsq_hip_comm_all_reduce, self.handle, *a, _stream_of(self.index))
+        if rc:
+            _status(rc, "lsq_hip_comm_all_reduce")
+        return t if out is None else out
+
+    def begin(self, t, op=LSQ_COMM_SUM, out=None):
+        """start the reduction on the communicator's stream behind the current stream's work; returns a ticket for end()"""
+        a = self._args(t, out, op)
+        ticket = ctypes.c_int32(-1)
+        rc = _on_device(self.index, _abi._LIB.lsq_hip_comm_all_reduce_begin, self.handle, *a, _stream_of(self.index),
+                        ctypes.byref(ticket))
+        if rc:
+            _status(rc, "lsq_hip_comm_all_reduce_begin")
+        return ticket.value
+
+    def end(self, ticket):
+        """the device's current stream waits for reduction `ticket` (the host does not)"""
+        rc = _on_device(self.index, _abi._LIB.lsq_hip_comm_all_reduce_end, self.handle, int(ticket), _stream_of(self.index))
+        if rc:
+            _status(rc, "lsq_hip_comm_all_reduce_end")
+
+    def destroy(self):
+        if self.handle:
+            h, self.handle = self.handle, None
+            rc = _on_device(self.index, _abi._LIB.lsq_hip_comm_destroy, h)
+            if rc:
+                _status(rc, "lsq_hip_comm_destroy")

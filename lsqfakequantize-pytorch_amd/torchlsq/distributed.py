@@ -12,6 +12,8 @@ plus a reduction, so it shards by splitting dim 0 (the batch) across ranks:
     the reference's on the concatenated (unsharded) tensor (lsq_cpu.cpp:103 uses x.numel()).
 `backend="nccl"` is RCCL on ROCm builds of PyTorch; the CPU tests use gloo.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -19,11 +21,114 @@ from . import extension as _E
 from .extension import _assert_has_ops, _param_dtype
 
 
+_ASSUME_PEERS = [False]     # measurements / tests on ONE GPU: communicate as if the process group had more than one rank
+
+
 def _world(group):
-    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    ws = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    return max(ws, 2) if _ASSUME_PEERS[0] else ws
+
+
+def assume_peers(on=True):
+    """A world of one that communicates as if it had peers: every all-reduce is then an identity, so the sharded op must
+    equal the plain op while the whole call path -- extra launches, the collective's enqueue -- is the N > 1 one.  For the
+    one-GPU measurements and tests (bench.py `cfg4_shard_collective`, tests/test_rccl_world1_gpu.py)."""
+    _ASSUME_PEERS[0] = bool(on)
 
 
 COLLECTIVE = "collective"      # global_numel=COLLECTIVE: the element count travels in the all-reduce (uneven shards)
+
+
+# ---- the collective itself: the library's own RCCL communicator when there is one, torch.distributed otherwise ----------
+# torch.distributed's all_reduce costs ~60 us of HOST time per call (profiles/r04_module_sync_cost.txt), as much as a rank's
+# whole BASELINE-config-4 step takes on the GPU; lsq_hip_comm_all_reduce* (include/lsq_hip.h) makes the same RCCL call with a
+# handful of HIP calls.  One communicator per (process group, GPU), created at the first sharded backward of GPU tensors over
+# an RCCL ("nccl") process group: rank 0's 128-byte id is broadcast through that group, every rank joins, and the ranks then
+# AGREE (one MIN all-reduce of a flag) that all of them succeeded -- otherwise all of them keep torch.distributed.
+# TORCHLSQ_COLLECTIVE=c10d switches the native route off; gloo groups and CPU tensors never take it.
+_COMMS = {}                 # (group key, device index) -> HipComm, or None: this group stays on torch.distributed
+_NATIVE_COLLECTIVE = [os.environ.get("TORCHLSQ_COLLECTIVE", "native").lower() != "c10d"]
+
+
+def set_native_collective(on):
+    """True: GPU tensors over an RCCL group reduce through the library's own communicator (the default); False: always
+    torch.distributed.all_reduce.  Communicators already created stay alive but are not used while it is off."""
+    _NATIVE_COLLECTIVE[0] = bool(on)
+
+
+def _group_key(group):
+    return 0 if group is None else id(group)
+
+
+def native_comm(group, device, create=True):
+    """The HipComm of (group, device), created on first use -- a COLLECTIVE call then: every rank of the group must make its
+    first sharded call at the same point, which data-parallel training does by construction.  None = torch.distributed."""
+    if not _NATIVE_COLLECTIVE[0] or not (dist.is_available() and dist.is_initialized()):
+        return None
+    key = (_group_key(group), device.index)
+    if key in _COMMS:
+        return _COMMS[key]
+    if not create or dist.get_backend(group) != "nccl":
+        _COMMS[key] = None
+        return None
+    rank, ws = dist.get_rank(group), dist.get_world_size(group)
+    comm, ok = None, 1
+    try:
+        uid = torch.zeros(_E.LSQ_COMM_ID_BYTES, dtype=torch.uint8, device=device)
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(_E.HipComm.unique_id()), dtype=torch.uint8))
+    except Exception:       # no RCCL behind the library: still take part in the two collectives below
+        ok = 0
+        uid = torch.zeros(_E.LSQ_COMM_ID_BYTES, dtype=torch.uint8, device=device)
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast(uid, src=src, group=group)
+    if ok:
+        try:
+            comm = _E.HipComm(bytes(uid.cpu().numpy().tobytes()), rank, ws, device)
+        except Exception:
+            ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) != 1:
+        if comm is not None:
+            try:
+                comm.destroy()
+            except Exception:
+                pass
+        comm = None
+    _COMMS[key] = comm
+    return comm
+
+
+def destroy_native_comms():
+    """tear the library's communicators down (before dist.destroy_process_group(); collective per communicator)"""
+    for key, comm in list(_COMMS.items()):
+        if comm is not None:
+            comm.destroy()
+        del _COMMS[key]
+
+
+class _NativeWork:
+    """what sharded_backward(async_op=True) hands back on the native route: wait() = the current stream waits (not the host)"""
+    __slots__ = ("comm", "ticket")
+
+    def __init__(self, comm, ticket):
+        self.comm, self.ticket = comm, ticket
+
+    def wait(self):
+        self.comm.end(self.ticket)
+        return True
+
+
+def _all_reduce_sum(t, group, async_op=False):
+    """in-place SUM of the fp64 buffer `t` over the ranks: the one collective of a sharded backward"""
+    comm = native_comm(group, t.device) if t.is_cuda else None
+    if comm is not None:
+        if async_op:
+            return _NativeWork(comm, comm.begin(t))
+        comm.all_reduce(t)
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
 def _finish(packed, channels, per_channel, x_dtype, qmax, use_gs, gs):
@@ -50,7 +155,7 @@ def _backward_counted(grad, x, scale, shift, quant_min, quant_max, type_min, typ
         dx, _ = _E.cpu_backward(grad, x, scale, shift, axis, is_perchannel, quant_min, quant_max, type_min, type_max, False,
                                 1.0, sym, False, init_mode, want_wide=True, wide_out=packed)
     if ws > 1:
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce_sum(packed, group)
     ds, db = _finish(packed, C, is_perchannel, x.dtype, quant_max, use_grad_scaling, grad_scaler)
     return dx, ds, db
 
@@ -87,7 +192,7 @@ def sharded_backward(grad, x, scale, shift, quant_min, quant_max, type_min, type
                                                     use_grad_scaling, grad_scaler, sym, eval_mode, init_mode, n4s)
     work = None
     if ws > 1 and not eval_mode and reduce:
-        work = dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        work = _all_reduce_sum(wide, group, async_op=async_op)
     pd = _param_dtype(x)
     if async_op and work is not None:
         return dx, wide, work           # caller waits, then rounds: wide[0].to(pd), wide[1].to(pd)
@@ -158,7 +263,23 @@ def all_reduce_minmax(cur_min, cur_max, group=None):
     initialisation of a replicated quantizer needs so that every rank derives the same scale / shift from the whole batch
     (reference quantized/modules/observers.py:446-449 sees the whole batch on its one device).  Returns new tensors."""
     n = cur_min.numel()
-    packed = torch.cat([cur_min.reshape(-1), -cur_max.reshape(-1)])
+    # torch.aminmax (what the reference's observers see, quantized/modules/observers.py:446-449) makes BOTH results NaN when
+    # the batch holds a NaN; what MIN does with a NaN is the backend's business (RCCL and gloo differ, and ranks could end up
+    # with different parameters exactly when the data is bad).  So NaNs do not travel: a third slot per value carries
+    # "this rank saw a NaN" (-1, else 0) through the same MIN, the values themselves go in with NaN replaced by +inf, and
+    # every rank poisons its result where any rank raised the flag -- the aminmax answer on the whole batch, on every rank.
+    lo, hi = cur_min.reshape(-1), cur_max.reshape(-1)
+    bad = torch.isnan(lo) | torch.isnan(hi)
+    inf = torch.full_like(lo, float("inf"))
+    packed = torch.cat([torch.where(bad, inf, lo), torch.where(bad, inf, -hi), -bad.to(lo.dtype)])
     if _world(group) > 1:
-        dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=group)
-    return packed[:n].reshape(cur_min.shape), (-packed[n:]).reshape(cur_max.shape)
+        comm = native_comm(group, packed.device) if (packed.is_cuda and packed.dtype in (torch.float32, torch.float64)) else None
+        if comm is not None:
+            comm.all_reduce(packed, op=_E.LSQ_COMM_MIN)
+        else:
+            dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=group)
+    nan = torch.full_like(lo, float("nan"))
+    poisoned = packed[2 * n:] < 0
+    gmin = torch.where(poisoned, nan, packed[:n])
+    gmax = torch.where(poisoned, nan, -packed[n:2 * n])
+    return gmin.reshape(cur_min.shape), gmax.reshape(cur_max.shape)

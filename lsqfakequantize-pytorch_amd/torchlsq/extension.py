@@ -28,7 +28,9 @@ from ._hip_host import (_SINGLE_LAUNCH_BWD, _TICKET_SLABS, _TICKETS, _WS_BYTES_P
                         _like_layout, _ocl, _param_dtype, _params, _physical_order, _ROW_MAJOR, hip_backward_from_mask,
                         hip_backward_per_channel, hip_backward_per_channel_multi, hip_backward_per_tensor,
                         hip_forward_per_channel, hip_forward_per_channel_multi, hip_forward_per_tensor, hip_meanstd,
-                        hip_minmax, hip_multi_eligible, hip_observer_update, hip_sharded_finish, saves_mask, set_single_launch_backward)
+                        hip_minmax, hip_multi_eligible, hip_observer_update, hip_plan_backward_per_channel, hip_sharded_finish, HipComm, LSQ_COMM_ID_BYTES,
+                        LSQ_COMM_MAX, LSQ_COMM_MIN, LSQ_COMM_SUM,
+                        saves_mask, set_single_launch_backward)
 from ._cpu_host import _cpu_meanstd, _cpu_minmax, cpu_backward, cpu_forward, cpu_levels, cpu_sharded_finish  # noqa: F401
 
 

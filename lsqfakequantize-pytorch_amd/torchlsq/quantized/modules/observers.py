@@ -294,6 +294,10 @@ class LSQFakeQuantizer(ObserverBase):
             cur_min = torch.full((1,), float('inf'), dtype=stat_dtype, device=x.device)
             cur_max = -cur_min
         gmin, gmax = all_reduce_minmax(cur_min.to(stat_dtype), cur_max.to(stat_dtype), group)
+        # an EMPTY batch on every rank (this rank's is: only then is it worth a look at the result) leaves the stand-in
+        # extremes (+inf, -inf), which the observer would read as min = -inf, max = +inf: nothing was observed, skip the step
+        if x.numel() == 0 and bool((gmin > gmax).all()):
+            return
         # the stock observer only ever looks at its input through aminmax: a two-element-per-channel stand-in with the
         # global extremes drives its own update rule (running / moving average) exactly as the whole batch would
         if per_channel:

@@ -101,6 +101,21 @@ CONFIGS = {
                 affine=True, x_mean=0.5, x_std=1.0, scale=(0.01, 0.05), shift=("normal", 0.0, 0.1), dtype="float32"),
     "vit": dict(shape=(64, 197, 768), per_channel=True, axis=2, qmin=0, qmax=127, tmin=0, tmax=255,
                 affine=True, x_mean=0.5, x_std=1.0, scale=(0.01, 0.05), shift=("normal", 0.0, 0.1), dtype="float32"),
+    # NOT in BASELINE.json either: NCHW activations inside the band the launch policy serves with OWNER windows (at most 13 M
+    # fp32 / 20 M 16-bit elements, short channel rows; lsq_pc_geom.hpp plan_own) -- digest-pinned against the reference so that
+    # the kernel family the SHIPPED library picks for them is held to the reference's own per-channel backward
+    # (tests/test_shipped_binary_gpu.py).  own33: 33 rows leave a short last row tile (the loop's ragged form).
+    "own33": dict(shape=(33, 2048, 7, 7), per_channel=True, axis=1, qmin=-8, qmax=7, tmin=-128, tmax=127,
+                  affine=True, x_mean=0.0, x_std=1.0, scale=(0.05, 0.35), shift=("normal", 0.0, 0.1), dtype="float32"),
+    "own64": dict(shape=(64, 2048, 7, 7), per_channel=True, axis=1, qmin=-8, qmax=7, tmin=-128, tmax=127,
+                  affine=False, x_mean=0.0, x_std=1.0, scale=(0.05, 0.35), shift=0.0, dtype="float32"),
+    "own16": dict(shape=(16, 1024, 14, 14), per_channel=True, axis=1, qmin=0, qmax=127, tmin=0, tmax=255,
+                  affine=True, x_mean=0.8, x_std=1.0, scale=(0.01, 0.05), shift=("normal", 0.0, 0.1), dtype="float32"),
+    "own32": dict(shape=(32, 512, 28, 28), per_channel=True, axis=1, qmin=0, qmax=255, tmin=0, tmax=255,
+                  affine=True, x_mean=0.8, x_std=1.0, scale=(0.005, 0.02), shift=("normal", 0.0, 0.1), dtype="float32"),
+    # ... and a last-axis activation big enough for the fp32 row groups' LDS-DMA ring (from 2^24 elements on)
+    "rgring": dict(shape=(16400, 1024), per_channel=True, axis=1, qmin=0, qmax=127, tmin=0, tmax=255,
+                   affine=True, x_mean=0.5, x_std=1.0, scale=(0.01, 0.05), shift=("normal", 0.0, 0.1), dtype="float32"),
 }
 
 SEED_X, SEED_G, SEED_SCALE, SEED_SHIFT = 11, 23, 37, 41

@@ -383,7 +383,15 @@ def make_digests(ref, big, only=None):
             ("cfg5_absgrad", "cfg5", False, True), ("cfg5_bf16_absgrad", "cfg5", True, True),
             # |grad| x the sign of each element's d_scale factor: every d_scale term >= 0 (synth.ds_term_sign)
             ("cfg3_dspos", "cfg3", False, "dspos"), ("cfg5_dspos", "cfg5", False, "dspos"),
-            ("cfg5_bf16_dspos", "cfg5", True, "dspos")]
+            ("cfg5_bf16_dspos", "cfg5", True, "dspos"),
+            # shapes the shipped library's policy sends to owner windows / the row groups' fat workgroup and ring
+            # (synth.CONFIGS; tests/test_shipped_binary_gpu.py): the reference's own lsq_backward_per_channel_impl
+            # (lsq_cpu.cpp:197-294) on them
+            ("own33_fp32", "own33", False, False), ("own33_bf16", "own33", True, False),
+            ("own64_fp32", "own64", False, False), ("own64_bf16", "own64", True, False),
+            ("own16_fp32", "own16", False, False), ("own32_bf16", "own32", True, False),
+            ("vit_fp32", "vit", False, False), ("vit_bf16", "vit", True, False),
+            ("rgring_fp32", "rgring", False, False)]
     if big:
         jobs += [("cfg2", "cfg2", False, False), ("cfg2_absgrad", "cfg2", False, True),
                  ("cfg4", "cfg4", False, False)]

@@ -185,6 +185,38 @@ def two_calls_one_backward(module_cls, device="cpu"):
                 scale_after_call2=tolist(p2[0]), shift_after_call2=tolist(p2[1]), y1_sha=sha(y1.cpu()), y2_sha=sha(y2.cpu()))
 
 
+def nan_in_the_batch(module_cls, per_channel, device="cpu", rows=None, sync_kwargs=None):
+    """Observer-driven init batches with a NaN in ONE of them (last row, so that a batch split over ranks has it in the last
+    shard only): what the module's parameters look like after every call.  torch.aminmax makes both extremes NaN, the
+    observer's state and the derived scale / shift follow (reference quantized/modules/observers.py:446-449) -- per tensor
+    everything, per channel only the channel that saw it.  `rows` = (lo, hi): feed only that slice of dim 0 (a rank's shard of
+    the same batches; tests/sync_workers.py)."""
+    from torch.ao.quantization.observer import MovingAverageMinMaxObserver, MovingAveragePerChannelMinMaxObserver
+    kw = dict(otype="activation", init_batches=3)
+    if per_channel:
+        kw.update(qscheme=torch.per_channel_affine, ch_axis=1)
+    kw.update(sync_kwargs or {})
+    m = module_cls(MovingAveragePerChannelMinMaxObserver if per_channel else MovingAverageMinMaxObserver, **kw)
+    m.train()
+    shape = [4, 8, 6, 6]
+    n = int(np.prod(shape))
+    out = []
+    for i in range(5):
+        x = S.normal_like(n, 400 + i, 0.8, 1.0).view(shape).clone()
+        if i == 2:
+            x[3, 5, 1, 2] = float("nan")          # last row, channel 5
+        x = x.to(device)
+        if rows is not None:
+            x = x[rows[0]:rows[1]]
+        y = m(x)
+        if i == 0 and device != "cpu":
+            m.to(device)
+        enc = lambda t: [("nan" if v != v else float(v)) for v in t.detach().reshape(-1).tolist()]
+        out.append(dict(call=i, scale=enc(m.scale), shift=enc(m.shift), y_nan=int(torch.isnan(y.detach()).sum()),
+                        observer_enabled=int(m.observer_enabled[0]), current_batch=int(m.current_batch[0])))
+    return out
+
+
 def import_reference_module():
     from oracle import build_ref
     build_ref.build_all(verbose=False)
@@ -235,6 +267,8 @@ if __name__ == "__main__":
                         for ot, dt in (("weight", "qint8"), ("activation", "quint8")) for lb in (True, False)],
     )
     extras["two_calls_one_backward"] = two_calls_one_backward(ref.LSQFakeQuantizer)
+    extras["nan_in_the_batch"] = dict(per_tensor=nan_in_the_batch(ref.LSQFakeQuantizer, False),
+                                      per_channel=nan_in_the_batch(ref.LSQFakeQuantizer, True))
     with open(os.path.join(HERE, "module_traces.json"), "w") as f:
         json.dump(dict(generator="tests/golden/make_module_traces.py", torch=torch.__version__,
                        reference="DeadAt0m/LSQFakeQuantize-PyTorch torchlsq/quantized/modules/observers.py (imported in place)",

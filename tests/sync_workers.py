@@ -276,3 +276,53 @@ def ddp_train(rank, world, port, device, grads, out_q, steps=6):
         out_q.put((rank, problems + ["rank %d raised %r\n%s" % (rank, e, traceback.format_exc())]))
     finally:
         dist.destroy_process_group()
+
+
+def nan_sync(rank, world, port, device, out_q):
+    """A NaN in ONE rank's shard of an observer-driven init batch (the last row of the batch: the last rank's): every rank must
+    end up with the parameters the REFERENCE module has after seeing the whole batch (tests/golden/module_traces.json,
+    extras.nan_in_the_batch: torch.aminmax turns both extremes NaN) -- the same on all ranks, bit for bit.  What a NaN does in
+    a MIN all-reduce is the backend's business, so the collective never sees one (torchlsq.distributed.all_reduce_minmax)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    _setup_paths()
+    import torchlsq  # noqa: F401
+    from torchlsq.quantized import LSQFakeQuantizer
+    drv = _driver()
+    with open(os.path.join(GOLDEN, "module_traces.json")) as f:
+        want_all = json.load(f)["extras"]["nan_in_the_batch"]
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    problems = []
+    try:
+        b = shard_bounds(4, world, False)
+        for kind, per_channel in (("per_tensor", False), ("per_channel", True)):
+            got = drv.nan_in_the_batch(LSQFakeQuantizer, per_channel, device=device, rows=(b[rank], b[rank + 1]),
+                                       sync_kwargs=dict(sync=True))
+            for g, w in zip(got, want_all[kind]):
+                tag = "%s call %d rank %d" % (kind, g["call"], rank)
+                for k in ("scale", "shift"):
+                    gv = np.array([float(v) for v in g[k]])
+                    wv = np.array([float(v) for v in w[k]])
+                    if not np.array_equal(np.isnan(gv), np.isnan(wv)):
+                        problems.append(tag + ": NaN pattern of %s %r, reference %r" % (k, g[k], w[k]))
+                    elif device == "cpu":
+                        if not np.array_equal(gv[~np.isnan(gv)], wv[~np.isnan(wv)]):
+                            problems.append(tag + ": %s %r, reference %r" % (k, g[k], w[k]))
+                    elif not np.allclose(gv[~np.isnan(gv)], wv[~np.isnan(wv)], rtol=3e-7, atol=1e-9):
+                        problems.append(tag + ": %s %r, reference %r" % (k, g[k], w[k]))
+                for k in ("observer_enabled", "current_batch"):
+                    if g[k] != w[k]:
+                        problems.append(tag + ": %s %r, reference %r" % (k, g[k], w[k]))
+            # replicas: the same bits everywhere (NaNs included: as text)
+            mine = json.dumps([(g["scale"], g["shift"]) for g in got])
+            everyone = [None] * world
+            dist.all_gather_object(everyone, mine)
+            if any(e != everyone[0] for e in everyone):
+                problems.append("%s: the replicas differ across ranks" % kind)
+        out_q.put((rank, problems))
+    except Exception as e:     # noqa: BLE001
+        import traceback
+        out_q.put((rank, problems + ["rank %d raised %r\n%s" % (rank, e, traceback.format_exc())]))
+    finally:
+        dist.destroy_process_group()

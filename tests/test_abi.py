@@ -23,7 +23,7 @@ def _declared():
 
 def test_header_symbols_are_exported():
     names = _declared()
-    assert len(names) == 24, names
+    assert len(names) == 32, names
     nm = subprocess.run(["nm", "-D", "--defined-only", LIB], capture_output=True, text=True, check=True).stdout
     exported = sorted(set(l.split()[-1] for l in nm.splitlines() if " T " in l and l.split()[-1].startswith("lsq_")))
     # exported == declared, not a superset: no `_ex` twin, no lsq_hip_debug_* knob, nothing else with C linkage
@@ -38,7 +38,7 @@ def test_tools_build_carries_the_internal_entry_points():
     """tools/_tune/liblsq_hip_tools.so (-DLSQ_TOOLS): include/lsq_hip.h plus csrc/lsq_internal.h, typed by tools/lsq_tools.py"""
     import lsq_tools
     lib = lsq_tools.load()
-    assert lib.lsq_hip_abi_version() == 4
+    assert lib.lsq_hip_abi_version() == 5
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "lsqfakequantize-pytorch_amd", "csrc", "lsq_internal.h")).read(), flags=re.S)
     internal = sorted(set(re.findall(r"\b(lsq_hip_\w+)\s*\(", text)))
     assert internal == sorted(lsq_tools.internal_abi()), (internal, sorted(lsq_tools.internal_abi()))
@@ -49,7 +49,7 @@ def test_tools_build_carries_the_internal_entry_points():
 def test_python_binding_table_matches_header():
     from torchlsq import extension as E
     assert sorted(E.C_ABI) == _declared()
-    assert E._HAS_OPS and E.library().lsq_hip_abi_version() == E.ABI_VERSION == 4
+    assert E._HAS_OPS and E.library().lsq_hip_abi_version() == E.ABI_VERSION == 5
     assert E.library().lsq_hip_runtime_version() > 0
     import torch
     assert torch.ops.torchlsq._cuda_version() == E.library().lsq_hip_runtime_version()

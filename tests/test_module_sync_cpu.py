@@ -70,6 +70,12 @@ def test_negative_control_without_sync_the_replicas_leave_the_reference_trace():
     assert any("grad" in m for m in problems)
 
 
+def test_a_nan_in_one_shard_gives_every_rank_the_reference_modules_answer():
+    """torch.aminmax semantics through the rank-synchronised observer (per tensor and per channel): a NaN in rank 1's shard
+    only, both ranks land on the reference module's whole-batch trace, replicas bit-identical"""
+    _run(sync_workers.nan_sync, 2, "cpu")
+
+
 @pytest.mark.parametrize("grads", ["mean", "ddp"])
 def test_ddp_replicas_stay_identical_and_follow_single_process_training(grads):
     """grads='mean': the quantizers all-reduce their own gradient sums (count in the collective); 'ddp': no collective of

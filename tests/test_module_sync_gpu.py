@@ -25,6 +25,13 @@ def test_synced_module_replays_the_reference_traces_on_the_gpu_world4_uneven():
     _run(sync_workers.replay, 4, True, "cuda:0", timeout=900)
 
 
+def test_a_nan_in_one_shard_on_the_gpu():
+    """the fused observer step (lsq_hip_minmax_* -> NaN-free packed MIN all-reduce -> lsq_hip_observer_update) with a NaN in one
+    rank's shard: the reference module's whole-batch answer on every rank"""
+    assert torch.cuda.is_available()
+    _run(sync_workers.nan_sync, 2, "cuda:0", timeout=600)
+
+
 @pytest.mark.parametrize("grads", ["mean", "ddp"])
 def test_ddp_on_the_gpu_replicas_identical(grads):
     assert torch.cuda.is_available()
