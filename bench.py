@@ -75,6 +75,12 @@ SECONDARY_RUNS = tuple((w, {}) for w in SECONDARY) + (
     ("cfg4_shard", {"shard_of": 8, "note": "BASELINE config 4's per-GPU shard [128,1024,14,14]: the step ONE rank of the 8-GPU job runs "
                                            "(lsq_backward_per_tensor_wide with the global element count, fp64 sums rounded; no collective) -- "
                                            "the 1-GPU denominator of the 8-GPU efficiency target"}),
+    ("cfg4_shard", {"name": "cfg4_shard_collective", "shard_of": 8, "collective": "native",
+                    "note": "the SAME shard step WITH its collective, exactly as the N > 1 loop issues it (sharded_backward(..., "
+                            "async_op=True), consumed one step later) in an RCCL world of ONE told it has a peer: every all-reduce "
+                            "is an identity, so this is the whole per-rank call path -- extra launches, the collective's enqueue, "
+                            "the stream hand-over -- without a transport between GPUs.  `collective`: native = the library's own "
+                            "RCCL communicator (lsq_hip_comm_all_reduce_begin / _end), c10d = torch.distributed.all_reduce"}),
     ("cfg3", {"name": "cfg3_x50_foreach", "multi": 50,
               "note": "50 x BASELINE config 3 ([512,512,3,3] qint8 weights) per step through the multi-tensor ops "
                       "(lsq_hip_*_per_channel_multi: one launch per 32 tensors each way) -- a model's weight quantizers together"}),
@@ -105,7 +111,11 @@ def parse_args(argv=None):
     ap.add_argument("--host-binding", default="auto", choices=["auto", "native", "ctypes"],
                     help="host layer above the C ABI: the C++ torch binding (_lsq_torch.so) or the Python/ctypes one")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the step from a HIP graph (GPU-side rate of latency-bound workloads; N = 1 only)")
+                    help="replay the step from a HIP graph (GPU-side rate of latency-bound workloads); at N > 1 the graph holds the "
+                         "sharded steps INCLUDING their all-reduces: a replay costs no per-step host time")
+    ap.add_argument("--collective", default="native", choices=["native", "c10d"],
+                    help="N > 1: the route of the one all-reduce per backward -- the library's own RCCL communicator "
+                         "(lsq_hip_comm_*, default; falls back to c10d when it cannot be created) or torch.distributed.all_reduce")
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)            # "gloo" + --single-device: smoke-test
     ap.add_argument("--single-device", action="store_true", help=argparse.SUPPRESS)  # the N>1 control flow on a 1-GPU box
     ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)     # tests: this rank raises before the timed region
@@ -306,12 +316,28 @@ def run_rank(a):
     ops = torch.ops.torchlsq_native if binding == "native" else torch.ops.torchlsq
     ops_of = {"native": getattr(torch.ops, "torchlsq_native", None), "ctypes": torch.ops.torchlsq}
 
-    def measure(workload, steps, warmup, graph=False, buffers=0, ops=ops, warm_ms=0.0, extra_blocks=0, shard_of=0, multi=0):
+    one = {"up": False}
+
+    def ensure_world_of_one():
+        """an RCCL process group of ONE rank for the single-GPU `*_collective` records (every all-reduce an identity)"""
+        if one["up"] or dist.is_initialized():
+            return
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(_free_port())
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+        one["up"] = True
+
+    def measure(workload, steps, warmup, graph=False, buffers=0, ops=ops, warm_ms=0.0, extra_blocks=0, shard_of=0, multi=0,
+                collective=None, inputs=None, shape_override=None):
         """Time `steps` steps (forward op + backward op) of one workload after `warmup` untimed ones; returns the raw
         measurements (K-step wall time bracketed by barrier + synchronize, max over ranks; per-op HIP-event times).
         shard_of = R (single rank only): the step ONE rank of an R-rank job runs on this shape -- the `*_wide` backward with
         the global element count (R x local) in the gradient scaler and the rounding of the fp64 sums, no collective.
-        multi = M (per-channel weights): M tensors of the shape per step through the multi-tensor ops (one launch per 32)."""
+        multi = M (per-channel weights): M tensors of the shape per step through the multi-tensor ops (one launch per 32).
+        collective = "native" | "c10d" (single rank, with shard_of): the N > 1 step itself -- sharded_backward(async_op=True) and
+        its drain -- with the process group told it has peers (torchlsq.distributed.assume_peers), over the named route.
+        inputs = (xs, gs, scale, shift) of an earlier measure() of the same workload: run on those very buffers.
+        shape_override: another shape for the same workload's operator (the host-cost probe on a tiny tensor)."""
         cfg_name, dtype_name, axis_override = WORKLOADS[workload]
         c = dict(synth.CONFIGS[cfg_name])
         if axis_override is not None:
@@ -332,9 +358,13 @@ def run_rank(a):
         if world > 1 and per_channel and c["axis"] == 0:
             raise SystemExit("workload %s quantises along dim 0, the sharded dim: a weight is replicated under data "
                              "parallelism, there is nothing to shard -- run it with --gpus 1" % workload)
-        if graph and world > 1:
-            raise SystemExit("--graph is a 1-GPU measurement")
-        x, g, scale, shift = synth.make_inputs(c, device=dev, dtype=dt, shape=shape)
+        if shape_override is not None:
+            shape = list(shape_override)
+        if inputs is not None:
+            xs_in, gs_in, scale, shift = inputs
+            x, g = xs_in[0], gs_in[0]
+        else:
+            x, g, scale, shift = synth.make_inputs(c, device=dev, dtype=dt, shape=shape)
         n_local = x.numel()
         # Small workloads re-using one set of buffers are partly served by the 256 MB Infinity Cache (config 5 streams 308 MB per
         # step in fp32, 154 MB in bf16), which is not the HBM rate the roofline is about: the steps rotate through `n_sets`
@@ -349,6 +379,9 @@ def run_rank(a):
             gs = [[g] + [g.clone() for _ in range(multi - 1)] for _ in range(n_sets)]
             scales, shifts, axes = [scale.clone() for _ in range(multi)], [shift.clone() for _ in range(multi)], [c["axis"]] * multi
             n_local *= multi
+        elif inputs is not None:
+            xs, gs = list(xs_in), list(gs_in)
+            n_sets = len(xs)
         else:
             xs, gs = [x], [g]
             for _ in range(n_sets - 1):
@@ -360,6 +393,9 @@ def run_rank(a):
             return (cur[0] + n_sets // 2) % n_sets
         n_global = n_local * world
         n_scaler = n_local * shard_of if shard_of else 0
+        if collective:
+            assert world == 1 and shard_of and not multi
+            ensure_world_of_one()
         q = (c["qmin"], c["qmax"], c["tmin"], c["tmax"])
         sym = not c["affine"]
         axis = c["axis"]
@@ -391,6 +427,12 @@ def run_rank(a):
                 if native_multi:
                     return ops.lsq_backward_per_channel_multi(gs[bset()], xs[bset()], scales, shifts, axes, *tail)
                 return extension.hip_backward_per_channel_multi(gs[bset()], xs[bset()], scales, shifts, axes, *tail)
+            if collective:      # ... and WITH it: the N > 1 branch below, in a world of one told it has peers
+                dx, wide, work = sharded_backward(gs[bset()], xs[bset()], scale, shift, *q, axis, True, 1.0, c["affine"], per_channel, False, False,
+                                                  None, n_scaler, async_op=True)
+                drain()
+                pending.append((wide, work))
+                return dx
             if shard_of:        # one rank's step of a shard_of-rank job: everything but the collective itself
                 if per_channel:
                     dx, wide = ops.lsq_backward_per_channel_wide(gs[bset()], xs[bset()], scale, shift, axis, *tail, n_scaler)
@@ -422,6 +464,11 @@ def run_rank(a):
                 ds_db = wide.to(torch.float32)                # the rounding to the parameter type
             return None
 
+        if collective or world > 1:
+            from torchlsq import distributed as D
+            D.set_native_collective((collective or a.collective) == "native")
+            if collective:
+                D.assume_peers(True)
         step_graphs = None
         graph_steps = 1
         if graph:
@@ -435,12 +482,14 @@ def run_rank(a):
                 for k in range(n_sets):
                     cur[0] = k
                     fwd(); bwd()
+                drain()
                 gr = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gr, stream=st):
                     for k in range(graph_steps):
                         cur[0] = k % n_sets
                         y = fwd()
                         r = bwd()
+                    drain()        # every collective begun inside the capture is consumed inside it (the side stream rejoins)
                 step_graphs = [gr]
             torch.cuda.synchronize()
 
@@ -550,11 +599,20 @@ def run_rank(a):
         bwd_ms = sorted(e[1].elapsed_time(e[2]) for e in ev if e is not None)
         fwd_avg = sum(fwd_ms) / len(fwd_ms)
         bwd_avg = sum(bwd_ms) / len(bwd_ms)
+        route = None
+        if collective or world > 1:
+            from torchlsq import distributed as D
+            comm = D.native_comm(None, dev, create=False)
+            route = "native" if comm is not None else "c10d"
+            if collective:
+                D.assume_peers(False)
+            D.set_native_collective(a.collective == "native")
 
         return dict(workload=workload, c=c, dtype_name=dtype_name, esz=esz, per_channel=per_channel, shape=shape, axis=axis,
                     scaling=scaling, n_local=n_local, n_global=n_global, n_sets=n_sets, set_bytes=set_bytes, steps=steps,
                     warmup=warmup, elapsed_max=elapsed_max, fwd_ms=fwd_ms, bwd_ms=bwd_ms, fwd_avg=fwd_avg, bwd_avg=bwd_avg,
-                    xs=xs, gs=gs, x=x, solo_ms=solo_ms, block_times=block_times, graph=bool(graph), graph_steps=graph_steps)
+                    xs=xs, gs=gs, x=x, scale=scale, shift=shift, solo_ms=solo_ms, block_times=block_times, graph=bool(graph),
+                    graph_steps=graph_steps, collective_route=route)
 
     # the non-headline workloads are small (20-100 us per step): W warm-up steps are over before the GPU's clocks have come up,
     # so they warm up for at least 60 ms of wall time (the headline workload, cfg2, does exactly its W steps)
@@ -641,6 +699,7 @@ def run_rank(a):
                          "step_reads_only_frac": round(step_gbs * 0.6 / HBM_PEAK_GBS, 4)},
         }
         if world > 1:
+            line["config"]["collective"] = m["collective_route"]
             # rank 0's shard step alone / the same step inside the N-rank job (barrier-bracketed, max over ranks): what the
             # collective and the co-running ranks cost one GPU.  1.0 = none.
             line["per_gpu_efficiency"] = round(m["solo_ms"] / (elapsed_max / a.steps * 1e3), 4)
@@ -671,12 +730,24 @@ def run_rank(a):
             # north_star describes Python host code over the thin C ABI; the timed region above ran the C++ host binding (same C
             # entry points, less host time per call).  The same workload through the Python / ctypes host layer, 20 steps:
             try:
-                pm = measure(a.workload, 20, 5, buffers=1 if set_bytes * 2 > (1 << 30) else a.buffers, ops=ops_of["ctypes"])
+                # ... on the SAME input buffers as the timed region (the placement of a fresh 822 MB allocation moves config 2's
+                # kernels by several % -- profiles/r04_buffer_offsets.txt -- which a host-layer comparison must not pick up), with
+                # per-op events, and then the C++ binding again on those buffers for the same 20 steps: A / B / A
+                same = (m["xs"], m["gs"], m["scale"], m["shift"])
+                pm = measure(a.workload, 20, 5, ops=ops_of["ctypes"], inputs=same)
+                nm = measure(a.workload, 20, 5, ops=ops_of["native"], inputs=same)
                 line["config"]["python_ctypes_host_layer"] = {
                     "ms_per_step": round(pm["elapsed_max"] / pm["steps"] * 1e3, 5),
                     "value": round(pm["n_global"] * pm["steps"] / pm["elapsed_max"] / 1e9, 3), "steps": pm["steps"],
-                    "note": "torch.ops.torchlsq.* (torch.library registration in Python -> ctypes -> the same C ABI and kernels)"}
-                del pm
+                    "fwd_ms": round(pm["fwd_avg"], 5), "bwd_ms": round(pm["bwd_avg"], 5),
+                    "native_binding_same_buffers_same_steps": {
+                        "ms_per_step": round(nm["elapsed_max"] / nm["steps"] * 1e3, 5),
+                        "value": round(nm["n_global"] * nm["steps"] / nm["elapsed_max"] / 1e9, 3),
+                        "fwd_ms": round(nm["fwd_avg"], 5), "bwd_ms": round(nm["bwd_avg"], 5)},
+                    "ctypes_over_native": round(pm["elapsed_max"] / nm["elapsed_max"], 4),
+                    "note": "torch.ops.torchlsq.* (torch.library registration in Python -> ctypes -> the same C ABI and kernels), "
+                            "on the timed region's own input buffers; then the C++ binding again the same way"}
+                del pm, nm, same
             except Exception as e:      # context only
                 line["config"]["python_ctypes_host_layer"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
@@ -692,7 +763,7 @@ def run_rank(a):
             for w, extra in SECONDARY_RUNS:
                 try:
                     name = extra.get("name", w)
-                    mkw = {k: v for k, v in extra.items() if k in ("graph", "shard_of", "multi")}
+                    mkw = {k: v for k, v in extra.items() if k in ("graph", "shard_of", "multi", "collective")}
                     sm = measure(w, a.secondary_steps if not extra.get("multi") else max(20, a.secondary_steps // 4), 20,
                                  warm_ms=60.0, extra_blocks=0 if mkw.get("graph") else 2, **mkw)
                     sb_f, sb_b = 2 * sm["esz"], 3 * sm["esz"]
@@ -713,6 +784,31 @@ def run_rank(a):
                         rec["steps_per_graph_launch"] = sm["graph_steps"]
                         rec["per_op_ms_from"] = "a second, un-timed pass of eager launches (the ops are nodes of one graph launch)"
                     n_small = sm["n_local"] < (1 << 23) and not mkw
+                    if mkw.get("collective"):
+                        rec["collective"] = sm["collective_route"]
+                        solo = next((r_ for r_ in sec if r_.get("workload") == "cfg4_shard" and "ms_per_step" in r_), None)
+                        if solo:
+                            rec["wall_over_solo_shard_step"] = round(rec["ms_per_step"] / solo["ms_per_step"], 4)
+                        del sm
+                        # the same step through torch.distributed.all_reduce, and the HOST time of each form alone: the step on a
+                        # tensor too small to keep the GPU busy ([1,16,14,14]: wall time per step = host time per step)
+                        sm = measure(w, a.secondary_steps, 20, warm_ms=30.0, extra_blocks=2, shard_of=mkw["shard_of"], collective="c10d")
+                        rec["ms_per_step_c10d"] = round(sm["elapsed_max"] / sm["steps"] * 1e3, 5)
+                        rec["c10d_route_was"] = sm["collective_route"]
+                        del sm
+                        host = {}
+                        for key, kw_ in (("shard_step_alone", {}), ("with_native_collective", {"collective": "native"}),
+                                         ("with_c10d_collective", {"collective": "c10d"})):
+                            hm = measure(w, a.secondary_steps, 20, warm_ms=20.0, extra_blocks=2, shard_of=mkw["shard_of"],
+                                         shape_override=(1, 16, 14, 14), buffers=2, **kw_)
+                            host[key] = round(hm["elapsed_max"] / hm["steps"] * 1e6, 2)
+                            del hm
+                        rec["host_us_per_step"] = host
+                        rec["host_us_per_step_is"] = ("wall time per step of the same calls on a [1,16,14,14] tensor (3136 elements: the GPU "
+                                                      "is never the bottleneck), eager, C++ host binding")
+                        gpu_us = (rec["fwd_ms"] + rec["bwd_ms"]) * 1e3
+                        rec["host_over_gpu_time"] = round(host["with_native_collective"] / gpu_us, 3) if gpu_us > 0 else None
+                        sm = None
                     del sm
                     if n_small and binding == "native":
                         # launch-bound sizes: the Python / ctypes host layer next to the C++ binding (same kernels)
@@ -741,13 +837,16 @@ def run_rank(a):
                       "ms_per_step": round(t4 * 1e3, 5), "fwd_ms": round(m4["fwd_avg"], 5), "bwd_ms": round(m4["bwd_avg"], 5),
                       "step_frac_per_gpu": round(20.0 * m4["n_local"] / ((m4["fwd_avg"] + m4["bwd_avg"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                       "rank0_shard_alone_ms_per_step": round(m4["solo_ms"], 5),
-                      "per_gpu_efficiency": round(m4["solo_ms"] / (t4 * 1e3), 4), "input_buffer_sets": m4["n_sets"]}
+                      "per_gpu_efficiency": round(m4["solo_ms"] / (t4 * 1e3), 4), "input_buffer_sets": m4["n_sets"],
+                      "collective": m4["collective_route"], "launch": "eager"}
         del m4
     if rank == 0:
         if strong is not None:
             line["strong_scaled"] = strong
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
+        from torchlsq import distributed as D
+        D.destroy_native_comms()
         dist.destroy_process_group()
     return 0
 

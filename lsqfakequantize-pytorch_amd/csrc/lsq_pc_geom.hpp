@@ -305,7 +305,10 @@ static inline OwnPlan plan_own_k(int64_t k, int64_t outer, int64_t C, int64_t in
     const int per_cu = static_cast<int>((owners + cus - 1) / cus);
     if (owners < (3 * static_cast<int64_t>(cus)) / 4 || per_cu > 4) return o;   // idle CUs / more than one round of fat workgroups
     // waves a CU can hold per owner: 16 of the 1024-lane launch bound, and the ring's LDS (dma_depth stages of 2 KiB per wave)
-    const int lds_waves = static_cast<int>(((160 * 1024) / per_cu - 2048) / (dma_depth * kDmaStageBytes));
+    // (the front area -- channel table, one pair of fp64 slots per channel and wave, staged raw parameters -- of a full
+    //  workgroup of this owner: 32 + 16 * 16 + 8 bytes per channel at most, rounded to 1 KiB like bwd_lds_front_bytes)
+    const int front = static_cast<int>((k * (32 + 16 * 16 + 8) + 1023) / 1024 * 1024);
+    const int lds_waves = static_cast<int>(((160 * 1024) / per_cu - front) / (dma_depth * kDmaStageBytes));
     const int max_lanes = std::min(block_limit, std::min(1024 / per_cu, lds_waves * 64)) / 64 * 64;
     const int r_max = static_cast<int>(std::min<int64_t>(max_lanes / lanes, outer));
     if (r_max < 2) return o;
@@ -381,9 +384,14 @@ __device__ __forceinline__ int64_t own_window(const PcGeom& g) {
 // windows (the ring starts at the next 1 KiB boundary).  Row-group windows have nothing in front: their combine buffer
 // is only used after the last row has been consumed and takes the ring's place (one barrier in between).
 // (+ 8 bytes per slot: the raw scale / shift of the window's channels, staged by LDS-DMA before the row copies are issued)
+// (owner windows keep one pair of fp64 slots per channel AND WAVE: their sums are final, so the waves' contributions are added
+//  in wave order at the end instead of by LDS atomics in arrival order -- bit-reproducible d_scale / d_shift / wide)
+static inline __host__ __device__ uint32_t bwd_lds_sum_sets(const PcGeom& g) {
+    return g.own ? static_cast<uint32_t>(g.block_threads) / 64u : 1u;
+}
 static inline __host__ __device__ uint32_t bwd_lds_front_bytes(const PcGeom& g, uint32_t slot_bytes) {
     if (g.ww_lanes) return 0u;
-    return (static_cast<uint32_t>(g.k_slots) * (slot_bytes + 16u + 8u) + 1023u) & ~1023u;
+    return (static_cast<uint32_t>(g.k_slots) * (slot_bytes + 16u * bwd_lds_sum_sets(g) + 8u) + 1023u) & ~1023u;
 }
 
 // Where a lane sits: position p0 of its first element, its row inside the tile, and whether it is live.

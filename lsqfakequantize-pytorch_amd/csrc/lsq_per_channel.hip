@@ -458,7 +458,12 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
     static_assert(BLOCK == kBlock || DMA > 0, "768/1024-lane workgroups: row-group and owner windows, on the ring only");
     static_assert(!OWN || (!EVAL && V > 1 && CPL <= 2), "owner windows: whole packets of one or two channels, training modes");
     QSlot<T>* table = reinterpret_cast<QSlot<T>*>(smem);
-    double* lds_s = reinterpret_cast<double*>(smem + static_cast<size_t>(g.k_slots) * sizeof(QSlot<T>));
+    // fp64 slots of the window's channels: [k_slots] d_scale sums, [k_slots] d_shift sums -- one such set per workgroup, added
+    // to with LDS atomics; owner windows (their sums are FINAL) keep one set per WAVE and add the sets in wave order at the
+    // end, so that d_scale / d_shift / wide come out the same bits launch after launch
+    const uint32_t sum_sets = OWN ? bwd_lds_sum_sets(g) : 1u;
+    double* lds_s0 = reinterpret_cast<double*>(smem + static_cast<size_t>(g.k_slots) * sizeof(QSlot<T>));
+    double* lds_s = lds_s0 + (OWN ? static_cast<size_t>(threadIdx.x >> 6) * 2u * g.k_slots : 0u);
     double* lds_b = lds_s + g.k_slots;
 
     // The window's raw scale / shift are requested FIRST: vector-memory operations retire in issue order, so a wait for loads
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
     //  * register-loop kernels: ordinary loads into registers (the compiler counts its own loads in issue order).
     constexpr bool STAGE = DMA > 0 && !WW && std::is_same<T, float>::value;
     const bool raw_first = !WW && DMA == 0 && g.k_slots <= kRawSlots * kBlock;
-    float* raw_stage = reinterpret_cast<float*>(smem + static_cast<size_t>(g.k_slots) * (sizeof(QSlot<T>) + 16));   // [k_slots] scale, [k_slots] shift
+    float* raw_stage = reinterpret_cast<float*>(smem + static_cast<size_t>(g.k_slots) * (sizeof(QSlot<T>) + 16 * sum_sets));   // [k_slots] scale, [k_slots] shift
     ChannelRaw<T> raw;
     if constexpr (STAGE) {
         const int64_t c_first = window_first_channel(g);
@@ -591,10 +596,7 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
             build_channel_table<T>(table, g.k_slots, site.c_lo, g.C, scale, shift, r);
         }
         if (!EVAL) {
-            for (int k = threadIdx.x; k < g.k_slots; k += kBlock) {
-                lds_s[k] = 0.0;
-                lds_b[k] = 0.0;
-            }
+            for (int k = threadIdx.x; k < static_cast<int>(2u * sum_sets) * g.k_slots; k += static_cast<int>(blockDim.x)) lds_s0[k] = 0.0;
         }
         __syncthreads();
         ch.init(table, site, g);
@@ -989,11 +991,15 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
     __syncthreads();
     if constexpr (OWN) {
         // every element of these channels went through this workgroup: the slots are the channels' totals
-        for (int k = threadIdx.x; k < g.k_slots; k += BLOCK) {
+        for (int k = threadIdx.x; k < g.k_slots; k += static_cast<int>(blockDim.x)) {
             const int64_t c = site.c_lo + k;
             if (c < g.C) {
-                const double ts = lds_s[k];
-                const double tb = direct.sym ? 0.0 + static_cast<double>(direct.sym_term) : lds_b[k];
+                double ts = 0.0, tb = 0.0;
+                for (uint32_t w = 0; w < sum_sets; ++w) {          // the waves' sums, in wave order
+                    ts += lds_s0[(2u * w) * g.k_slots + k];
+                    tb += lds_s0[(2u * w + 1u) * g.k_slots + k];
+                }
+                if (direct.sym) tb = 0.0 + static_cast<double>(direct.sym_term);
                 direct.ds[c] = static_cast<T>(ts);
                 direct.db[c] = static_cast<T>(tb);
                 if (direct.wide) {
@@ -1251,6 +1257,7 @@ constexpr int kBigBlockOf = ELEM_BYTES < 4 ? 768 : 1024;
 // channels = 224 bytes: 384 rows 21.2 -> 20.4 us, 512 rows 24.9 -> 25.5, 768 rows 32.2 -> 39.3); those only up to 5 * 2^20
 // elements ([256,2048,7] 17.0 -> 11.8 us, [292,2048,7] 18.2 -> 13.8, [192,2048,3,3] 15.5 -> 11.1).  profiles/r04_owner_short_runs.txt, r04_owner_min_run.txt.
 constexpr int kOwnBlock = 512;
+constexpr size_t kLdsBytesPerWorkgroup = 160 * 1024;      // gfx950: LDS a workgroup may allocate (the Makefile builds for gfx950 only)
 template <int ELEM_BYTES>
 constexpr int64_t kOwnMaxElemsOf = ELEM_BYTES < 4 ? int64_t{20} << 20 : (ELEM_BYTES == 4 ? int64_t{13} << 20 : int64_t{1} << 23);
 constexpr int64_t kOwnMaxElemsShortRun = int64_t{5} << 20;
@@ -1646,17 +1653,18 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
                 if (own != 1 && op.run_bytes < kOwnShortRunBytes && op.run_bytes % 128 != 0 && elems > kOwnMaxElemsShortRun) return false;
                 PcGeom g = make_geom_own(c.outer, c.C, c.inner, V, op);
                 g.ring_nt = ring_nt_for(bytes, true, false);
-                if (c.plan_need) {                       // no workspace
-                    if (c.plan_note)
-                        *c.plan_note = LaunchNote{static_cast<int>(g.n_windows), 1, op.per_cu, 0, 4, kDmaDepth, g.block_threads, g.ring_nt};
-                    return true;
-                }
                 g.own_prio = own_knob == 3 ? 0 : 1;
 #if defined(LSQ_TOOLS) && defined(LSQ_TIMELINE)
                 g.timeline = knob::timeline_buffer().load();
 #endif
                 const size_t lds = bwd_lds_front_bytes(g, sizeof(QSlot<T>)) +
                                    static_cast<size_t>(g.block_threads / 64) * kDmaDepth * kDmaStageBytes;
+                if (lds > kLdsBytesPerWorkgroup) return false;     // (cannot happen with plan_own's sizing on gfx950: the other families then)
+                if (c.plan_need) {                       // no workspace
+                    if (c.plan_note)
+                        *c.plan_note = LaunchNote{static_cast<int>(g.n_windows), 1, op.per_cu, 0, 4, kDmaDepth, g.block_threads, g.ring_nt};
+                    return true;
+                }
                 constexpr auto kern = bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, 1, true, true, false, false, kDmaDepth, OB>;
 #ifdef LSQ_TOOLS
                 last_launch_note() = LaunchNote{static_cast<int>(g.n_windows), 1, op.per_cu, registers_of(reinterpret_cast<const void*>(kern)),

@@ -69,7 +69,8 @@ def test_default_line_carries_the_per_channel_half():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     sec = {s["workload"]: s for s in out["secondary"]}
-    assert sorted(sec) == ["cfg1", "cfg1_graph", "cfg3", "cfg3_graph", "cfg3_x50_foreach", "cfg4_shard", "cfg5", "cfg5_bf16"]
+    assert sorted(sec) == ["cfg1", "cfg1_graph", "cfg3", "cfg3_graph", "cfg3_x50_foreach", "cfg4_shard", "cfg4_shard_collective", "cfg5",
+                           "cfg5_bf16"]
     for name, s in sec.items():
         assert "error" not in s and s["value"] > 0 and 0 < s["step_frac"] < 1, s
         assert s["launch"] == ("graph" if name.endswith("_graph") else "eager")
@@ -77,6 +78,14 @@ def test_default_line_carries_the_per_channel_half():
     # the headline workload through the Python / ctypes host layer north_star describes, next to the C++ binding's figure
     py = out["config"]["python_ctypes_host_layer"]
     assert out["config"]["host_binding"] == "native" and py["value"] > 0.9 * out["value"], (py, out["value"])
+    # ... measured on the timed region's own buffers, with the per-op split, next to the C++ binding run the same way
+    assert py["fwd_ms"] > 0 and py["bwd_ms"] > 0 and 0.9 < py["ctypes_over_native"] < 1.1, py
+    # one rank's config-4 step WITH its collective (RCCL world of one told it has a peer), over the library's own communicator
+    col = sec["cfg4_shard_collective"]
+    assert col["collective"] == "native" and col["c10d_route_was"] == "c10d" and col["shape"] == [128, 1024, 14, 14], col
+    assert col["ms_per_step"] <= 1.10 * sec["cfg4_shard"]["ms_per_step"], (col["ms_per_step"], sec["cfg4_shard"]["ms_per_step"])
+    host = col["host_us_per_step"]
+    assert 0 < host["shard_step_alone"] <= host["with_native_collective"] < host["with_c10d_collective"], host
     # BASELINE config 4's per-GPU shard: the step one rank of the 8-GPU job runs, the denominator of the 0.9x target
     assert sec["cfg4_shard"]["shape"] == [128, 1024, 14, 14] and "what" in sec["cfg4_shard"]
     # 50 weight quantizers in one launch each way stream far better than 50 latency-bound single calls

@@ -29,8 +29,17 @@ def counting(*a, **k):
     calls["n"] += 1
     return real(*a, **k)
 dist.all_reduce = counting
-D._world = lambda group: 2 if os.environ.get("PRETEND_PEERS") == "1" else 1     # communicate as if there were peers
-os.environ["PRETEND_PEERS"] = "1"
+from torchlsq import _hip_host as _HH
+for _name in ("all_reduce", "begin"):          # ... and the library's own communicator (the default route on the GPU)
+    def _wrap(_orig):
+        def f(self, *a, **k):
+            calls["n"] += 1
+            return _orig(self, *a, **k)
+        return f
+    setattr(_HH.HipComm, _name, _wrap(getattr(_HH.HipComm, _name)))
+D.assume_peers(True)                    # communicate as if there were peers
+assert D.native_comm(None, dev) is not None, "the library's RCCL communicator could not be created"   # (a collective call: id broadcast + agreement)
+calls["n"] = 0
 ok = True
 for per_channel in (False, True):
     for dtype in (torch.float32, torch.bfloat16):
@@ -98,6 +107,60 @@ for obs_cls, extra in ((MovingAverageMinMaxObserver, {}), (MovingAveragePerChann
             good = good and torch.allclose(a.scale.grad, p.scale.grad, rtol=2e-5, atol=1e-12) and torch.allclose(a.shift.grad, p.shift.grad, rtol=2e-5, atol=1e-10)
         ok = ok and good
         print("module", obs_cls.__name__, "call", i, good, "collectives", calls["n"] - before, flush=True)
+# ---- the library's own communicator (include/lsq_hip.h, lsq_hip_comm_*): everything above ran over it -- the default route
+# for GPU tensors over an RCCL group -- which the counter of torch.distributed.all_reduce calls cannot see: say so explicitly
+comm = D.native_comm(None, dev, create=False)
+ok = ok and comm is not None
+print("native communicator", comm.info() if comm is not None else None, flush=True)
+if comm is not None:
+    from torchlsq import extension as E
+    info = comm.info()
+    ok = ok and info["rank"] == 0 and info["nranks"] == 1 and info["rccl_version"] > 0
+    # in place, out of place, the three reductions, both element types, on a side stream of the caller's
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for dt in (torch.float64, torch.float32):
+            src = torch.arange(1, 9, dtype=dt, device=dev) * 0.37
+            for op in (E.LSQ_COMM_SUM, E.LSQ_COMM_MIN, E.LSQ_COMM_MAX):
+                a = src.clone()
+                comm.all_reduce(a, op=op)
+                out = torch.zeros_like(src)
+                comm.all_reduce(src, op=op, out=out)
+                t1 = comm.begin(src, op=op, out=out.zero_())
+                t2 = comm.begin(a, op=op)
+                comm.end(t1); comm.end(t2)
+                st.synchronize()
+                ok = ok and torch.equal(a, src) and torch.equal(out, src)
+    # the overlapped form inside a HIP-graph capture: every begin ended before the capture ends
+    gbuf = torch.full((3,), 2.5, dtype=torch.float64, device=dev)
+    gout = torch.zeros_like(gbuf)
+    with torch.cuda.stream(st):
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st):
+            gbuf.mul_(2.0)
+            tk = comm.begin(gbuf, out=gout)
+            gbuf2 = gbuf + 1.0                  # work that overlaps the reduction
+            comm.end(tk)
+            res = gout + gbuf2
+        gr.replay(); gr.replay()
+    torch.cuda.synchronize()
+    ok = ok and torch.equal(gbuf, torch.full((3,), 10.0, dtype=torch.float64, device=dev)) and torch.equal(res, gbuf + gbuf + 1.0)
+    print("native comm: reductions + capture", ok, flush=True)
+    # the same sharded calls over torch.distributed instead (TORCHLSQ_COLLECTIVE=c10d / set_native_collective(False)): counted
+    D.set_native_collective(False)
+    before = calls["n"]
+    xs, ss, bs = x.clone().requires_grad_(True), scale.clone().requires_grad_(True), shift.clone().requires_grad_(True)
+    D.lsq_sharded(xs, ss, bs, global_numel=D.COLLECTIVE, quant_min=-8, quant_max=7, type_min=-128, type_max=127, axis=1, is_perchannel=True).backward(g)
+    torch.cuda.synchronize()
+    ok = ok and calls["n"] - before == 1
+    D.set_native_collective(True)
+    # bad arguments are rejected with a message, not executed
+    try:
+        comm.all_reduce(torch.zeros(4, dtype=torch.int32, device=dev))
+        ok = False
+    except RuntimeError:
+        pass
+D.destroy_native_comms()
 dist.destroy_process_group()
 print("RESULT", "ok" if ok else "FAILED", flush=True)
 '''
