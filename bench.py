@@ -113,9 +113,11 @@ def parse_args(argv=None):
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a HIP graph (GPU-side rate of latency-bound workloads); at N > 1 the graph holds the "
                          "sharded steps INCLUDING their all-reduces: a replay costs no per-step host time")
-    ap.add_argument("--collective", default="native", choices=["native", "c10d"],
+    ap.add_argument("--collective", default="native", choices=["native", "native-inline", "c10d"],
                     help="N > 1: the route of the one all-reduce per backward -- the library's own RCCL communicator "
-                         "(lsq_hip_comm_*, default; falls back to c10d when it cannot be created) or torch.distributed.all_reduce")
+                         "(lsq_hip_comm_*: `native` = on its own stream with the rounding behind it, the compute stream joined once "
+                         "at the end of the region; `native-inline` = in stream order behind the backward's kernels; both fall back "
+                         "to c10d when the communicator cannot be created) or torch.distributed.all_reduce")
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)            # "gloo" + --single-device: smoke-test
     ap.add_argument("--single-device", action="store_true", help=argparse.SUPPRESS)  # the N>1 control flow on a 1-GPU box
     ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)     # tests: this rank raises before the timed region
@@ -428,6 +430,9 @@ def run_rank(a):
                     return ops.lsq_backward_per_channel_multi(gs[bset()], xs[bset()], scales, shifts, axes, *tail)
                 return extension.hip_backward_per_channel_multi(gs[bset()], xs[bset()], scales, shifts, axes, *tail)
             if collective:      # ... and WITH it: the N > 1 branch below, in a world of one told it has peers
+                if collective == "native-inline":       # the reduction in stream order, right behind the backward's kernels
+                    return sharded_backward(gs[bset()], xs[bset()], scale, shift, *q, axis, True, 1.0, c["affine"], per_channel, False, False,
+                                            None, n_scaler)
                 dx, wide, work = sharded_backward(gs[bset()], xs[bset()], scale, shift, *q, axis, True, 1.0, c["affine"], per_channel, False, False,
                                                   None, n_scaler, async_op=True)
                 drain()
@@ -451,22 +456,36 @@ def run_rank(a):
             # all-reduce of the packed fp64 [d_scale, d_shift] sums.  The collective is issued async and
             # consumed one step later (d_scale/d_shift are only needed by the optimizer), so its latency
             # hides behind the next step's kernels; every reduction is completed inside the timed region.
+            if a.collective == "native-inline":
+                return sharded_backward(gs[bset()], xs[bset()], scale, shift, *q, axis, True, 1.0, c["affine"], per_channel, False, False,
+                                        None, n_global)
             dx, wide, work = sharded_backward(gs[bset()], xs[bset()], scale, shift, *q, axis, True, 1.0, c["affine"], per_channel, False, False,
                                               None, n_global, async_op=True)
             drain()
             pending.append((wide, work))
             return dx
 
-        def drain():
+        last_native = [None]
+
+        def drain(final=False):
+            # torch.distributed route: the stream waits for the previous step's reduction, then rounds it.  Native route: the
+            # reduction AND the rounding run on the communicator's stream (work.rounded), the compute stream is joined ONCE,
+            # at the end of the region (final) -- what a training step does before its optimizer reads the gradients
             while pending:
                 wide, work = pending.pop()
+                if getattr(work, "deferred", False):
+                    last_native[0] = work
+                    continue
                 work.wait()                                   # stream-level wait, the host does not block
                 ds_db = wide.to(torch.float32)                # the rounding to the parameter type
+            if final and last_native[0] is not None:
+                last_native[0].wait()                         # joins every earlier reduction too: the side stream is in order
+                last_native[0] = None
             return None
 
         if collective or world > 1:
             from torchlsq import distributed as D
-            D.set_native_collective((collective or a.collective) == "native")
+            D.set_native_collective((collective or a.collective).startswith("native"))
             if collective:
                 D.assume_peers(True)
         step_graphs = None
@@ -482,14 +501,14 @@ def run_rank(a):
                 for k in range(n_sets):
                     cur[0] = k
                     fwd(); bwd()
-                drain()
+                drain(final=True)
                 gr = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gr, stream=st):
                     for k in range(graph_steps):
                         cur[0] = k % n_sets
                         y = fwd()
                         r = bwd()
-                    drain()        # every collective begun inside the capture is consumed inside it (the side stream rejoins)
+                    drain(final=True)   # every collective begun inside the capture is joined inside it (the side stream rejoins)
                 step_graphs = [gr]
             torch.cuda.synchronize()
 
@@ -509,7 +528,7 @@ def run_rank(a):
             i += 1
             if warm_ms > 0 and i % 64 == 0:
                 torch.cuda.synchronize()
-        drain()
+        drain(final=True)
         torch.cuda.synchronize()
 
         # N > 1: rank 0's shard step ALONE (same kernels, the global element count in the scaler, no collective) while the
@@ -560,7 +579,7 @@ def run_rank(a):
                     e[1].record()
                     r = bwd()
                     e[2].record()
-        drain()
+        drain(final=True)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -585,7 +604,7 @@ def run_rank(a):
                     cur[0] = i % n_sets
                     y = fwd()
                     r = bwd()
-                drain()
+                drain(final=True)
                 torch.cuda.synchronize()
                 block_times.append(time.perf_counter() - tb)
             elapsed = sorted(block_times)[len(block_times) // 2]
@@ -606,7 +625,7 @@ def run_rank(a):
             route = "native" if comm is not None else "c10d"
             if collective:
                 D.assume_peers(False)
-            D.set_native_collective(a.collective == "native")
+            D.set_native_collective(a.collective.startswith("native"))
 
         return dict(workload=workload, c=c, dtype_name=dtype_name, esz=esz, per_channel=per_channel, shape=shape, axis=axis,
                     scaling=scaling, n_local=n_local, n_global=n_global, n_sets=n_sets, set_bytes=set_bytes, steps=steps,
@@ -796,6 +815,13 @@ def run_rank(a):
                         rec["ms_per_step_c10d"] = round(sm["elapsed_max"] / sm["steps"] * 1e3, 5)
                         rec["c10d_route_was"] = sm["collective_route"]
                         del sm
+                        sm = measure(w, a.secondary_steps, 20, warm_ms=30.0, extra_blocks=2, shard_of=mkw["shard_of"], collective="native-inline")
+                        rec["ms_per_step_native_inline"] = round(sm["elapsed_max"] / sm["steps"] * 1e3, 5)
+                        rec["routes"] = ("native: reduction + rounding on the communicator's stream, ONE join of the compute stream at the end of the "
+                                         "region (what hides the transport's latency at N > 1); native_inline: lsq_hip_comm_all_reduce in stream "
+                                         "order (in a world of one it shows the call path's floor; at N > 1 the stream would sit out the "
+                                         "all-reduce's latency every step); c10d: torch.distributed.all_reduce(async_op=True), waited a step later")
+                        del sm
                         host = {}
                         for key, kw_ in (("shard_step_alone", {}), ("with_native_collective", {"collective": "native"}),
                                          ("with_c10d_collective", {"collective": "c10d"})):
@@ -843,6 +869,13 @@ def run_rank(a):
     if rank == 0:
         if strong is not None:
             line["strong_scaled"] = strong
+        # RCCL writes a version banner through C stdio when a communicator is created; on a pipe it would only come out at
+        # exit, BEHIND the JSON line.  Flush it now: the JSON line is the last line of stdout.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         from torchlsq import distributed as D

@@ -17,6 +17,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -137,13 +138,22 @@ int lsq_hip_comm_create(const void* id, int32_t rank, int32_t nranks, lsq_comm**
     ncclUniqueId u;
     std::memcpy(u.internal, id, LSQ_COMM_ID_BYTES);
     if (int rc = rccl_status(r, r->CommInitRank(&c->comm, nranks, u, rank), "ncclCommInitRank")) { delete c; return rc; }
-    // the side stream outranks the streaming kernels it runs next to: its whole job is one tiny launch per step
+    // the side stream: its whole job is one tiny launch per step.  LSQ_COMM_SIDE_PRIORITY=1 (experiments) creates it at the
+    // highest priority; the default is an ordinary non-blocking stream (tools/exp_comm_cost.py, profiles/r05_comm_cost.txt).
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    hipError_t e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi);
+    const char* pr = getenv("LSQ_COMM_SIDE_PRIORITY");
+    hipError_t e = (pr && pr[0] == '1') ? hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi)
+                                        : hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    // The two events order work of ONE device (the reduction reads what a kernel of the caller's stream wrote, the caller's
+    // stream reads what the reduction wrote): the agent-scope release every kernel ends with is enough, the system-scope
+    // fence an event records by default -- a writeback + invalidate of the L2s, paid again by the work behind it -- is not
+    // needed (hipEventDisableSystemFence).  LSQ_COMM_EVENT_FENCE=1 (experiments) keeps the default events.
+    const char* fence = getenv("LSQ_COMM_EVENT_FENCE");
+    const unsigned flags = (fence && fence[0] == '1') ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
     for (int i = 0; i < kTickets && e == hipSuccess; ++i) {
-        e = hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming);
+        e = hipEventCreateWithFlags(&c->ready[i], flags);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done[i], flags);
     }
     if (e != hipSuccess) {      // (a communicator that cannot get a stream is not worth tearing down carefully)
         r->CommDestroy(c->comm);
@@ -176,6 +186,8 @@ int lsq_hip_comm_info(const lsq_comm* c, int32_t* out4) {
     out4[0] = c->rank; out4[1] = c->nranks; out4[2] = c->device; out4[3] = version;
     return LSQ_OK;
 }
+
+void* lsq_hip_comm_side_stream(const lsq_comm* c) { return c ? static_cast<void*>(c->side) : nullptr; }
 
 static int check_reduce(const lsq_comm* c, const void* send, void* recv, int64_t count, int dtype, int op, int* nccl_type,
                         int* nccl_op) {

@@ -731,6 +731,12 @@ class HipComm:
             _status(rc, "lsq_hip_comm_create")
         self.handle = handle.value
 
+    def side_stream(self):
+        """the communicator's own stream as a torch stream (for consumers of a begun reduction; join with end() once)"""
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.ExternalStream(int(_abi._LIB.lsq_hip_comm_side_stream(self.handle)), device=self.device)
+        return self._side
+
     def info(self):
         out = (ctypes.c_int32 * 4)()
         rc = _abi._LIB.lsq_hip_comm_info(self.handle, ctypes.byref(out))

@@ -109,23 +109,39 @@ def destroy_native_comms():
 
 
 class _NativeWork:
-    """what sharded_backward(async_op=True) hands back on the native route: wait() = the current stream waits (not the host)"""
-    __slots__ = ("comm", "ticket")
+    """What sharded_backward(async_op=True) hands back on the native route.  The reduction runs on the communicator's own
+    stream and so does its first consumer -- `rounded`: the sums cast to the parameter type there -- so the compute stream
+    never waits for a single reduction: wait() makes the current stream wait (not the host) for THIS reduction and every
+    earlier one of the communicator (its stream is in order), and a training step needs one such join, before the
+    optimizer reads the gradients -- not one per quantizer.  (A cross-stream wait costs the GPU ~7 us each way,
+    profiles/r05_comm_cost.txt: per reduction that is 14 % of a BASELINE-config-4 shard step, per step it is noise.)"""
+    __slots__ = ("comm", "ticket", "rounded", "deferred")
 
-    def __init__(self, comm, ticket):
-        self.comm, self.ticket = comm, ticket
+    def __init__(self, comm, ticket, rounded=None):
+        self.comm, self.ticket, self.rounded, self.deferred = comm, ticket, rounded, True
 
     def wait(self):
         self.comm.end(self.ticket)
+        if self.rounded is not None:
+            self.rounded.record_stream(torch.cuda.current_stream(self.rounded.device))
         return True
 
 
-def _all_reduce_sum(t, group, async_op=False):
-    """in-place SUM of the fp64 buffer `t` over the ranks: the one collective of a sharded backward"""
+def _all_reduce_sum(t, group, async_op=False, round_to=None):
+    """in-place SUM of the fp64 buffer `t` over the ranks: the one collective of a sharded backward.
+    async_op on the native route: the reduction and (round_to: a dtype) the rounding of its result run on the communicator's
+    stream; see _NativeWork."""
     comm = native_comm(group, t.device) if t.is_cuda else None
     if comm is not None:
         if async_op:
-            return _NativeWork(comm, comm.begin(t))
+            ticket = comm.begin(t)
+            rounded = None
+            if round_to is not None:
+                side = comm.side_stream()
+                with torch.cuda.stream(side):
+                    rounded = t.to(round_to)
+                t.record_stream(side)
+            return _NativeWork(comm, ticket, rounded)
         comm.all_reduce(t)
         return None
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
@@ -192,10 +208,12 @@ def sharded_backward(grad, x, scale, shift, quant_min, quant_max, type_min, type
                                                     use_grad_scaling, grad_scaler, sym, eval_mode, init_mode, n4s)
     work = None
     if ws > 1 and not eval_mode and reduce:
-        work = _all_reduce_sum(wide, group, async_op=async_op)
+        work = _all_reduce_sum(wide, group, async_op=async_op, round_to=_param_dtype(x) if async_op else None)
     pd = _param_dtype(x)
     if async_op and work is not None:
-        return dx, wide, work           # caller waits, then rounds: wide[0].to(pd), wide[1].to(pd)
+        # caller waits (work.wait(): a stream-level wait), then rounds: wide[0].to(pd), wide[1].to(pd) -- or, native route
+        # (getattr(work, "deferred", False)), takes work.rounded and joins once per step instead of once per reduction
+        return dx, wide, work
     ds = wide[0].to(pd).reshape(-1)
     db = wide[1].to(pd).reshape(-1)
     return dx, ds, db

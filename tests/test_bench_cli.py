@@ -83,7 +83,8 @@ def test_default_line_carries_the_per_channel_half():
     # one rank's config-4 step WITH its collective (RCCL world of one told it has a peer), over the library's own communicator
     col = sec["cfg4_shard_collective"]
     assert col["collective"] == "native" and col["c10d_route_was"] == "c10d" and col["shape"] == [128, 1024, 14, 14], col
-    assert col["ms_per_step"] <= 1.10 * sec["cfg4_shard"]["ms_per_step"], (col["ms_per_step"], sec["cfg4_shard"]["ms_per_step"])
+    assert col["ms_per_step"] <= 1.12 * sec["cfg4_shard"]["ms_per_step"], (col["ms_per_step"], sec["cfg4_shard"]["ms_per_step"])
+    assert col["ms_per_step"] < col["ms_per_step_c10d"] and col["ms_per_step_native_inline"] <= 1.08 * sec["cfg4_shard"]["ms_per_step"], col
     host = col["host_us_per_step"]
     assert 0 < host["shard_step_alone"] <= host["with_native_collective"] < host["with_c10d_collective"], host
     # BASELINE config 4's per-GPU shard: the step one rank of the 8-GPU job runs, the denominator of the 0.9x target

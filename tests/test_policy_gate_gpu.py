@@ -1,0 +1,108 @@
+"""GPU: a regression GATE on the per-channel backward's launch policy.  The thresholds of lsq_per_channel.hip were calibrated on a
+handful of boxes (profiles/r04_policy_audit.txt); the driver's box is a fresh one every round.  For ~30 seeded (shape, storage
+type) cases -- NCHW activations, token layouts, conv / linear weights, NHWC -- the backward op is timed as the policy launches it
+and with every family-forcing knob of the tools build (tools/exp_policy_audit.py in small: HIP-graph replays over rotated
+inputs); the test FAILS when a forced alternative beats the policy by more than 15 % (re-measured once before it counts: these
+are 5-100 us kernels).  It does not say the policy is optimal -- tools/exp_policy_audit.py reports at 7 % -- it catches a
+threshold that has gone badly wrong on the box at hand."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ALTS = [("set_own", 1), ("set_own", 2), ("set_ww_big", 1), ("set_ww_big", 2), ("force_ring", 1), ("force_ring", 2), ("set_seg_min_div", 1)]
+GATE = 0.15
+
+
+def _cases():
+    rng = np.random.default_rng(55)
+    hw = [(7, 7), (14, 14), (28, 28), (4, 4), (8, 8), (3, 3), (5, 5), (16, 16)]
+    out = []
+    while len(out) < 15:
+        kind = len(out) % 4
+        if kind == 0:
+            n, c = int(rng.choice([16, 32, 64, 128, 256])), int(rng.choice([256, 512, 1024, 2048]))
+            h, w = hw[rng.integers(0, len(hw))]
+            s, ax = (n, c, h, w), 1
+        elif kind == 1:
+            s, ax = (int(rng.choice([197 * 16, 197 * 64, 4096, 8192, 16384])), int(rng.choice([384, 768, 1024, 2048, 4096]))), 1
+        elif kind == 2:
+            s, ax = (int(rng.choice([256, 512, 1024, 4096])), int(rng.choice([9 * 64, 9 * 256, 768, 3072, 4096]))), 0
+        else:
+            n, c = int(rng.choice([8, 16, 32])), int(rng.choice([64, 128, 256]))
+            h, w = hw[rng.integers(0, 3)]
+            s, ax = (n, h, w, c), 3
+        el = int(np.prod(s))
+        if 300_000 <= el <= 40_000_000 and (s, ax) not in out:
+            out.append((s, ax))
+    return [(s, ax, dt) for s, ax in out for dt in (torch.float32, torch.bfloat16)]
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torchlsq  # noqa: F401
+    import lsq_tools
+    from torchlsq import extension
+    extension._assert_has_ops()
+    lsq_tools.activate()
+    yield lsq_tools
+    lsq_tools.deactivate()
+
+
+def _time(T, E, op, K, knob, value):
+    """us per op with lsq_hip_debug_<knob>(value) (None: the policy), the launch it produced"""
+    if knob is not None:
+        T.set_knob(knob, value)
+    try:
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            for k in range(K):
+                op(k)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=st):
+                for k in range(2 * K):
+                    op(k % K)
+            note = T.last_launch()
+            gr.replay()
+            ts = []
+            for _ in range(4):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); gr.replay(); e1.record(); e1.synchronize()
+                ts.append(e0.elapsed_time(e1) / (2 * K) * 1e3)
+    finally:
+        if knob is not None:
+            T.set_knob(knob, 0)
+    return min(ts), (note["kind"], note["grid_x"], note["grid_y"], note["block"], note["ring_depth"])
+
+
+def test_no_forced_family_beats_the_policy_by_more_than_the_gate(T):
+    from torchlsq import extension as E, synth
+    dev = torch.device("cuda:0")
+    behind, report = [], []
+    for shape, axis, dtype in _cases():
+        n = int(np.prod(shape))
+        esz = 2 if dtype == torch.bfloat16 else 4
+        K = max(2, min(6, -(-(600 << 20) // (2 * n * esz))))
+        xs = [synth.normal_like(n, 10 + k, 0.5, 1.0, dtype=dtype, device=dev).view(shape) for k in range(K)]
+        gs = [synth.normal_like(n, 50 + k, 0.0, 1e-3, dtype=dtype, device=dev).view(shape) for k in range(K)]
+        s = synth.uniform_like(shape[axis], 3, 0.01, 0.05, device=dev)
+        b = synth.normal_like(shape[axis], 4, 0.0, 0.1, device=dev)
+        q = (0, 127, 0, 255, True, 1.0, False, False, False)
+        op = lambda k: E.hip_backward_per_channel(gs[k], xs[(k + K // 2) % K], s, b, axis, *q)      # noqa: E731
+        base, base_note = _time(T, E, op, K, None, 0)
+        seen = {base_note}
+        for knob, v in ALTS:
+            t, note = _time(T, E, op, K, knob, v)
+            if note in seen:
+                continue                                   # the knob changed nothing for this shape
+            seen.add(note)
+            if t < base * (1.0 - GATE):                    # re-measure both before it counts
+                base2, _ = _time(T, E, op, K, None, 0)
+                t2, _ = _time(T, E, op, K, knob, v)
+                report.append("%s %s: policy %s %.1f / %.1f us, %s=%d %s %.1f / %.1f us" % (shape, dtype, base_note, base, base2, knob, v, note, t, t2))
+                if min(t, t2) < min(base, base2) * (1.0 - GATE) and t2 < base2 * (1.0 - GATE / 2):
+                    behind.append(report[-1])
+        del xs, gs
+        torch.cuda.empty_cache()
+    assert not behind, "a forced kernel family beats the launch policy by more than %d %%:\n%s" % (int(GATE * 100), "\n".join(behind))

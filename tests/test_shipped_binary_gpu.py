@@ -178,8 +178,9 @@ def test_the_plan_is_what_the_tools_build_launches(E):
 
 def test_tools_build_and_product_give_the_same_bits(E):
     """20 seeded shapes across the kernel families, forward and backward, on the product and on the tools build (same sources,
-    -DLSQ_TOOLS, all knobs 0): every output bit-identical.  (Owner windows add their waves' sums in a fixed order; the
-    256-lane windows' LDS atomics can only move an fp64 rounding, 1e-9 odds of reaching an fp32 bit.)"""
+    -DLSQ_TOOLS, all knobs 0): every output bit-identical -- fp64 d_scale / d_shift to an fp64 rounding.  (Owner windows add their
+    waves' sums in a fixed order; the 256-lane windows' LDS atomics can only move an fp64 rounding, 1e-9 odds of reaching an
+    fp32 bit.)"""
     import lsq_tools
     rng = np.random.RandomState(20251003)
     dev = torch.device("cuda:0")
@@ -227,4 +228,10 @@ def test_tools_build_and_product_give_the_same_bits(E):
     names = ("y", "dx", "ds", "db", "y (per tensor)", "dx (per tensor)", "ds (per tensor)", "db (per tensor)")
     for case, a, b in zip(cases, product, tools):
         for n, u, v in zip(names, a, b):
-            assert u.dtype == v.dtype and torch.equal(u.view(torch.uint8), v.view(torch.uint8)), (case, n)
+            assert u.dtype == v.dtype and u.shape == v.shape, (case, n)
+            if u.dtype == torch.float64 and n in ("ds", "db"):
+                # fp64 sums of the 256-lane windows: the four waves' LDS atomics land in arrival order, two LAUNCHES of one
+                # binary agree to an fp64 rounding only -- so do two binaries
+                assert torch.allclose(u, v, rtol=1e-13, atol=0, equal_nan=True), (case, n)
+            else:
+                assert torch.equal(u.view(torch.uint8), v.view(torch.uint8)), (case, n)
