@@ -234,13 +234,10 @@ LSQ_EX_LINKAGE int lsq_hip_backward_per_channel_ex(int dtype, const void* grad, 
     if (!grad || !x || !dx || !ds || !db || !scale || !shift) return fail(LSQ_EINVAL, "backward_per_channel: NULL buffer");
     if (!workspace) return fail(LSQ_EWORKSPACE, "backward_per_channel: NULL workspace");
     if (reinterpret_cast<uintptr_t>(workspace) & 15u) return fail(LSQ_EWORKSPACE, "workspace must be 16-byte aligned");
-    // lsq_bwd_extras.ticket: used by the kernel families that can finish d_scale / d_shift themselves with it (row-group
-    // windows in column blocks), ignored by the others (include/lsq_hip.h)
-    uint32_t* ticket = extras ? static_cast<uint32_t*>(extras->ticket) : nullptr;
-    if (reinterpret_cast<uintptr_t>(ticket) & 3u) return fail(LSQ_EINVAL, "ticket must be 4-byte aligned");
+    (void)extras;      // lsq_bwd_extras.ticket: accepted and ignored by the per-channel backward (include/lsq_hip.h)
     hipError_t e = hipSuccess;
     LSQ_DISPATCH_IO(dtype, e = lsq::backward_per_channel<IO>(grad, x, dx, ds, db, dsdb_wide, outer, channels, inner,
-                                                              scale, shift, *p, workspace, workspace_bytes, ticket, variant,
+                                                              scale, shift, *p, workspace, workspace_bytes, nullptr, variant,
                                                               static_cast<hipStream_t>(stream)));
     if (e == hipErrorInvalidValue)
         return fail(LSQ_EWORKSPACE, "backward_per_channel: workspace of %zu bytes is too small (ask "
@@ -351,7 +348,6 @@ void lsq_hip_debug_set_seg_no_up_front(int v) { lsq::knob::set(lsq::knob::kSegNo
 void lsq_hip_debug_set_fin_ch(int v) { lsq::knob::set(lsq::knob::kFinCh, v); }
 void lsq_hip_debug_set_own_min_run(int v) { lsq::knob::set(lsq::knob::kOwnMinRun, v < 0 ? 0 : v); }
 void lsq_hip_debug_set_own_fat(int v) { lsq::knob::set(lsq::knob::kOwnFat, v < 0 || v > 2 ? 0 : v); }
-void lsq_hip_debug_set_ww_cb(int v) { lsq::knob::set(lsq::knob::kWwCb, v < 0 || v > 256 ? 0 : v); }
 void lsq_hip_debug_set_own(int v) { lsq::knob::set(lsq::knob::kOwn, v < 0 || v > 3 ? 0 : v); }
 
 #ifdef LSQ_TIMELINE

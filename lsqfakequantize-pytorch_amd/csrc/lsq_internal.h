@@ -44,9 +44,6 @@ void lsq_hip_debug_set_seg_min_div(int v);  /* forward / backward: segment mode 
 void lsq_hip_debug_set_fwd_direct(int v);   /* last-axis forward: 0 / 3 = policy (lanes read their own scale / shift), 1 = the same on the usual grid, 2 = LDS table */
 void lsq_hip_debug_set_seg_no_up_front(int v); /* segment kernels: 1 = always the loop form, never the one-group short walk */
 void lsq_hip_debug_set_fin_ch(int v);
-/* row-group windows in COLUMN BLOCKS (narrow windows + in-kernel fold): 0 = the policy, 1 = never, w > 1 = blocks of w lanes
-   wherever w divides the row's lanes */
-void lsq_hip_debug_set_ww_cb(int v);
 /* owner windows of the per-channel backward: 0 = the policy, 1 = wherever the shape allows, 2 = never,
    3 = like 1 but without the waves' turns at the higher issue priority (A/B) */
 void lsq_hip_debug_set_own(int v);

@@ -57,7 +57,7 @@ constexpr int kDefaultPcSegNarrowVariant = encode_variant(1, true, true, 16);   
 // constant 0 ("no override"), the policy code that consults it folds away, no lsq_hip_debug_* symbol is exported, and the
 // library keeps no mutable global state (include/lsq_hip.h).
 namespace knob {
-enum Id { kForceRing, kWwMinRows, kWwSplit64, kWwBig, kRingNt, kFinCh, kObserveWgPerCu, kWwMaxLog2, kSegMinDiv, kFwdDirect, kSegNoUpFront, kOwn, kOwnMinRun, kOwnFat, kWwCb, kCount };
+enum Id { kForceRing, kWwMinRows, kWwSplit64, kWwBig, kRingNt, kFinCh, kObserveWgPerCu, kWwMaxLog2, kSegMinDiv, kFwdDirect, kSegNoUpFront, kOwn, kOwnMinRun, kOwnFat, kCount };
 #ifdef LSQ_TOOLS
 inline std::atomic<int>& slot(Id id) {
     static std::atomic<int> v[kCount];
@@ -77,7 +77,7 @@ inline std::atomic<unsigned long long*>& timeline_buffer() {     // lsq_hip_debu
 // all geometry knobs as one key (the workspace memo of lsq_capi.hip)
 inline int geometry_key() {
     unsigned k = 0;
-    for (Id id : {kWwMinRows, kWwSplit64, kWwBig, kRingNt, kWwMaxLog2, kSegMinDiv, kOwn, kOwnMinRun, kOwnFat, kWwCb}) k = k * 41u + static_cast<unsigned>(get(id));
+    for (Id id : {kWwMinRows, kWwSplit64, kWwBig, kRingNt, kWwMaxLog2, kSegMinDiv, kOwn, kOwnMinRun, kOwnFat}) k = k * 41u + static_cast<unsigned>(get(id));
     return static_cast<int>(k & 0x7fffffffu);
 }
 }  // namespace knob

@@ -232,14 +232,8 @@ static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec,
 // 256-lane window's ([8192, 4096] bf16: 768 workgroups write 6 MB of partials instead of 25 MB).  The lane's V channels
 // are its own: their constants live in registers, there is no LDS table, and the epilogue is a fixed-order sum of the
 // row groups through LDS.
-// COLUMN BLOCKS (round 5, cb_lanes > 0 dividing the row's lanes): a window is cb_lanes lanes of the row (16 lanes = 256 bytes)
-// instead of the whole row, the workgroup's lanes are block / cb_lanes row groups over it.  The access pattern streams like
-// whole rows do (tools/exp_colblock_probe.py, profiles/r05_colblock_probe.txt: [12608,768] bf16 12.0 us either way, ATen add
-// 11.1), but a workgroup's partial row is cb_lanes x V channels instead of the row's -- [64,197,768] bf16: 0.5 MB of partials
-// instead of 3.1 MB -- and few enough per window for the window's last-arriving workgroup to fold them itself
-// (bwd_pc_kernel, fold_window_cb): one launch, no finalize.
 static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_blocks, int min_rows, int resident_blocks,
-                                  bool split64 = false, int block = kBlock, int cb_lanes = 0) {
+                                  bool split64 = false, int block = kBlock) {
     PcGeom g;
     g.ring_nt = 0;
     g.direct = 0;
@@ -252,11 +246,7 @@ static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_
     g.fits32 = (g.L + static_cast<int64_t>(kBlock) * vec) < 0x7fffffffLL ? 1 : 0;
     const int64_t lanes_per_row = g.L / vec;
     // (block > kBlock: the 1024-lane workgroups of mid-sized tensors -- more row groups per workgroup, never narrower windows)
-    if (cb_lanes > 0 && cb_lanes <= block && lanes_per_row % cb_lanes == 0 && lanes_per_row > cb_lanes) {
-        g.ww_lanes = cb_lanes;
-        g.R = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(block / cb_lanes, outer)));
-        g.n_windows = lanes_per_row / cb_lanes;
-    } else if (lanes_per_row <= kBlock && !(block == kBlock && split64 && lanes_per_row >= 128 && lanes_per_row % 64 == 0)) {
+    if (lanes_per_row <= kBlock && !(block == kBlock && split64 && lanes_per_row >= 128 && lanes_per_row % 64 == 0)) {
         g.ww_lanes = static_cast<int32_t>(lanes_per_row);
         g.R = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(block / lanes_per_row, outer)));
         g.n_windows = 1;

@@ -118,55 +118,7 @@ struct PcDirect {
     double* wide;
     T sym_term;         // the constant per-element d_shift term of the symmetric case, 0 * grad_scaler (lsq_kernel.h:118,122)
     int32_t sym;
-    uint32_t* ticket;   // row-group windows: arrival counters, one per window (zeroed, self-resetting) -- the workgroup that
-                        // publishes a window's LAST partial row folds them all and stores d_scale / d_shift: no finalize launch
 };
-
-// Row-group windows, narrow form (column blocks: a window is w lanes of the row, k_slots = w x V channels): fold the `splits`
-// partial rows of window `win` in a FIXED order and store its channels' d_scale / d_shift (the reference's
-// `ds_buffer.sum(axes != axis)`, lsq_cpu.cpp:287-292).  One workgroup of `nthr` >= k_slots threads: thread t sums the partial
-// rows part, part + P, ... of slot t % k_slots (P = nthr / k_slots independent strided walks), the P walks of a slot are then
-// added in walk order through LDS.  Shared by the last-arriving workgroup of the backward kernel (AGENT: the rows were written
-// by other workgroups of this launch, read past the non-coherent caches) and by finalize_cb_kernel, so the one-launch route
-// and the two-launch route give the same bits.
-template <typename T, bool AGENT>
-__device__ __forceinline__ void fold_window_cb(const double2* __restrict__ partials, const PcGeom& g, int64_t win, int splits,
-                                               const PcDirect<T>& d, double2* scratch /* LDS: nthr double2 */) {
-    const int k_slots = g.k_slots, nthr = static_cast<int>(blockDim.x), t = static_cast<int>(threadIdx.x);
-    const int P = nthr / k_slots;
-    const int slot = t % k_slots, part = t / k_slots;
-    const int64_t stride = g.n_windows * static_cast<int64_t>(k_slots);
-    double s = 0.0, b = 0.0;
-    if (part < P) {
-        const double2* col = partials + win * k_slots + slot;
-#pragma unroll 4
-        for (int sy = part; sy < splits; sy += P) {
-            const double2 v = AGENT ? load_partial_agent(col + static_cast<int64_t>(sy) * stride) : col[static_cast<int64_t>(sy) * stride];
-            s += v.x;
-            b += v.y;
-        }
-        scratch[part * k_slots + slot] = make_double2(s, b);
-    }
-    __syncthreads();
-    if (t < k_slots) {
-        double ts = scratch[t].x, tb = scratch[t].y;
-        for (int q = 1; q < P; ++q) {
-            ts += scratch[q * k_slots + t].x;
-            tb += scratch[q * k_slots + t].y;
-        }
-        const int w = g.ww_lanes, comp = t / w, lane = t - comp * w;
-        const int64_t c = win * k_slots + static_cast<int64_t>(lane) * g.vec + comp;
-        if (c < g.C) {
-            if (d.sym) tb = 0.0 + static_cast<double>(d.sym_term);
-            d.ds[c] = static_cast<T>(ts);
-            d.db[c] = static_cast<T>(tb);
-            if (d.wide) {
-                d.wide[c] = ts;
-                d.wide[g.C + c] = tb;
-            }
-        }
-    }
-}
 
 // CPL = channels a lane can touch: 1 (inner % V == 0), 2 (inner >= V), V (anything).
 template <typename T, int V, int CPL>
@@ -990,11 +942,7 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
         __syncthreads();
         const int64_t block_linear = static_cast<int64_t>(blockIdx.y) * g.n_windows + blockIdx.x;
         double2* out = partials + block_linear * k_slots;
-        const bool fold = direct.ticket != nullptr;
-        auto publish = [&](int slot, double ts, double tb) {
-            if (fold) store_partial_agent(out + slot, ts, tb);       // written through: another workgroup will read it
-            else out[slot] = make_double2(ts, tb);
-        };
+        auto publish = [&](int slot, double ts, double tb) { out[slot] = make_double2(ts, tb); };
         if (k_slots >= nthr) {
             for (int slot = t; slot < k_slots; slot += nthr) {
                 double ts = comb[slot].x, tb = comb[slot].y;
@@ -1027,16 +975,6 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
                 }
                 publish(t, ts, tb);
             }
-        }
-        if (fold) {
-            // the workgroup that publishes the window's last partial row folds them all (fold_window_cb): this thread's
-            // write-through stores are complete, the workgroup's are after the barrier, then ONE arrival per workgroup
-            __shared__ int is_last;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (t == 0) is_last = ticket_arrive_is_last(direct.ticket + blockIdx.x, gridDim.y) ? 1 : 0;
-            __syncthreads();
-            if (is_last) fold_window_cb<T, true>(partials, g, static_cast<int64_t>(blockIdx.x), static_cast<int>(gridDim.y), direct, comb);
         }
 #ifdef LSQ_TIMELINE
         tl_record();
@@ -1241,14 +1179,6 @@ __global__ __launch_bounds__(kBlock) void finalize_ww_kernel(const double2* __re
     }
 }
 
-// Finalize (row-group windows, narrow form) when the backward kernel did not fold (no ticket: a launch captured into a HIP
-// graph): one workgroup per window runs the very fold the kernel's last-arriving workgroup would have run.
-template <typename T>
-__global__ void finalize_cb_kernel(const double2* __restrict__ partials, PcGeom g, int splits, PcDirect<T> d) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    fold_window_cb<T, false>(partials, g, static_cast<int64_t>(blockIdx.x), splits, d, reinterpret_cast<double2*>(smem));
-}
-
 // =================================================================================================
 // SEGMENT mode: one channel per workgroup
 // =================================================================================================
@@ -1360,7 +1290,6 @@ template <int ELEM_BYTES>
 constexpr int64_t kOwnMaxElemsOf = ELEM_BYTES < 4 ? int64_t{20} << 20 : (ELEM_BYTES == 4 ? int64_t{13} << 20 : int64_t{1} << 23);
 constexpr int64_t kOwnMaxElemsShortRun = int64_t{5} << 20;
 constexpr int kOwnShortRunBytes = 512;
-constexpr int kWwCbLanes = 16;            // column blocks of the row-group windows: 16 lanes = 256-byte runs (make_geom_ww)
 constexpr int kWwBwdBlocksPerCU = 4;     // row-group windows: one full round for every storage type (3-4 resident per CU)
 // Rows a forward workgroup walks at least, per unit of its per-workgroup overhead (make_geom): that overhead is only
 // the channel-table build -- VEC channels per lane when the quantized axis is the last one, so twice as heavy per
@@ -1616,7 +1545,6 @@ struct BwdPcCall {
     bool whole_rounds;     // size the grid in whole rounds of what the chip holds at once (make_geom)
     Variant v;
     hipStream_t stream;
-    uint32_t* ticket;      // arrival counters (LSQ_TICKET_BYTES of zeroed device memory) or null: kernel + finalize launch
     size_t* plan_need;     // not null: PLAN only -- record the workspace bytes the launch would need, launch nothing
     LaunchNote* plan_note; // PLAN only, may be null: what the launch would look like (lsq_hip_plan_backward_per_channel)
 };
@@ -1656,13 +1584,13 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
     // here, where the kernel is known, together with the launch and the finalize.
     // returns false (nothing launched) when `min_tiles` is asked for and a workgroup would walk fewer row tiles than that
     auto run = [&](auto kern, int dma_depth, int target_blocks, int64_t min_tiles, int64_t max_tiles = INT64_MAX,
-                   int block = kBlock, int cb_lanes = 0) -> bool {
+                   int block = kBlock) -> bool {
         const DeviceInfo& dev = device_info();
         auto geom = [&](int resident) {
             // rows of 128 / 192 / 256 lanes: 4- and 8-byte storage cuts them into 64-lane windows of four row groups
             // ([65536,1024] fp32 backward 157 -> 140 us, profiles/r02_ww_split64_ab.txt); 16-bit storage gains nothing
             const bool split64 = sizeof(typename IO::elem) >= 4 ? knob::get(knob::kWwSplit64) != 2 : knob::get(knob::kWwSplit64) == 1;
-            return WW ? make_geom_ww(c.outer, c.C, V, target_blocks, ww_min_rows<IO>(), resident, split64, block, cb_lanes)
+            return WW ? make_geom_ww(c.outer, c.C, V, target_blocks, ww_min_rows<IO>(), resident, split64, block)
                       : make_geom(c.outer, c.C, c.inner, V, target_blocks, 27, resident);
         };
         auto lds_of = [&](const PcGeom& gg) {
@@ -1709,23 +1637,12 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
         last_launch_note() = LaunchNote{static_cast<int>(g.n_windows), g.splits, per_cu, registers_of(reinterpret_cast<const void*>(kern)),
                                         WW ? 2 : 1, dma_depth, g.block_threads, g.ring_nt};
 #endif
-        // column blocks: the window's last-arriving workgroup folds its partial rows itself when the caller gave a ticket
-        // (one counter per window; not for a captured launch) -- otherwise finalize_cb_kernel runs the same fold
-        const bool cb = WW && !EVAL && cb_lanes > 0 && g.ww_lanes == cb_lanes && g.n_windows > 1 && g.k_slots <= g.block_threads;
-        const bool fold = cb && c.ticket != nullptr && g.n_windows <= static_cast<int64_t>(LSQ_TICKET_BYTES / sizeof(uint32_t)) &&
-                          static_cast<size_t>(g.splits) * g.k_slots * sizeof(double2) <= (size_t{256} << 10);
-        const PcDirect<T> fin{c.ds, c.db, c.wide, c.sym_term, p.sym ? 1 : 0, nullptr};
         hipLaunchKernelGGL(kern, grid, dim3(g.block_threads), lds, c.stream, c.grad, c.x, c.dx, g, static_cast<const T*>(c.scale),
-                           static_cast<const T*>(c.shift), r, c.gs, c.partials,
-                           fold ? PcDirect<T>{c.ds, c.db, c.wide, c.sym_term, p.sym ? 1 : 0, c.ticket}
-                                : PcDirect<T>{nullptr, nullptr, nullptr, c.sym_term, 0, nullptr});
+                           static_cast<const T*>(c.shift), r, c.gs, c.partials, PcDirect<T>{nullptr, nullptr, nullptr, c.sym_term, 0});
         result = hipGetLastError();
-        if (result != hipSuccess || fold) return true;
+        if (result != hipSuccess) return true;
         const int fin_ch = fin_channels(c.C);
-        if (cb) {
-            hipLaunchKernelGGL((finalize_cb_kernel<T>), dim3(static_cast<unsigned>(g.n_windows)), dim3(g.block_threads),
-                               static_cast<size_t>(g.block_threads) * sizeof(double2), c.stream, c.partials, g, g.splits, fin);
-        } else if (WW) {
+        if (WW) {
             const unsigned fgrid = static_cast<unsigned>((g.n_windows * g.k_slots + fin_ch - 1) / fin_ch);
             hipLaunchKernelGGL((finalize_ww_kernel<T>), dim3(fgrid), dim3(kBlock), 0, c.stream, c.partials, g, fin_ch,
                                p.eval_mode ? 1 : 0, p.sym ? 1 : 0, c.sym_term, c.ds, c.db, c.wide);
@@ -1784,7 +1701,7 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
 #endif
                 hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(g.n_windows)), dim3(g.block_threads), lds, c.stream, c.grad, c.x,
                                    c.dx, g, static_cast<const T*>(c.scale), static_cast<const T*>(c.shift), r, c.gs, c.partials,
-                                   PcDirect<T>{c.ds, c.db, c.wide, c.sym_term, p.sym ? 1 : 0, nullptr});
+                                   PcDirect<T>{c.ds, c.db, c.wide, c.sym_term, p.sym ? 1 : 0});
                 result = hipGetLastError();
                 return true;
             };
@@ -1829,13 +1746,9 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
                 const bool use_big = big == 1 || (big == 0 && c.default_variant && c.C / V <= kBlock && c.C / V >= 64 && fits &&
                                                   elems >= (int64_t{1} << 23) && elems < (int64_t{5} << 24));
                 constexpr int kBigBlock = kBigBlockOf<sizeof(typename IO::elem)>;
-                // ... in COLUMN BLOCKS of 16 lanes (256-byte runs) where 16 divides the row's lanes: a sixth of the partial
-                // bytes and the fold inside the kernel (make_geom_ww; tools knob kWwCb: 1 = whole rows, w = blocks of w lanes)
-                const int cbk = knob::get(knob::kWwCb);
-                const int cb_lanes = cbk == 1 ? 0 : (cbk > 1 ? cbk : kWwCbLanes);
                 if (use_big &&
                     run(bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, 1, true, true, false, WW, kDmaDepth, kBigBlock>, kDmaDepth,
-                        device_info().cu_count, big == 1 ? 0 : 2, INT64_MAX, kBigBlock, cb_lanes))
+                        device_info().cu_count, big == 1 ? 0 : 2, INT64_MAX, kBigBlock))
                     return result;
             }
             // The tiles-per-workgroup floor of the ring (as many as it is deep) does not hold for 16-bit row groups: there the
@@ -1943,6 +1856,7 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
                                 const void* shift, const lsq_params& p, void* workspace, size_t workspace_bytes,
                                 uint32_t* ticket, int variant, hipStream_t stream, size_t* plan_need, LaunchNote* plan_note) {
     using T = typename IO::arith;
+    (void)ticket;
     const DeviceInfo& dev = device_info();
     const bool aligned = is_aligned16(grad) && is_aligned16(x) && is_aligned16(dx);
     const int vec = pick_vec(IO::VEC, channels * inner, aligned);
@@ -1995,13 +1909,13 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
         // the chip holds (variant: workgroups per CU requested, rounded to whole rounds)
         BwdPcCall<T> call{grad, x, dx, static_cast<T*>(ds), static_cast<T*>(db), wide, outer, channels, inner, scale, shift, &p,
                           gs, sym_term, partials, workspace_bytes, variant == 0 ? dev.cu_count * kWwBwdBlocksPerCU : target,
-                          /*default_variant=*/variant == 0, /*whole_rounds=*/true, v, stream, ticket, plan_need, plan_note};
+                          /*default_variant=*/variant == 0, /*whole_rounds=*/true, v, stream, plan_need, plan_note};
         return bwd_pc_modes<IO, VB, VB, true>(call);
     }
     const int target_w = (variant == 0 && last_axis) ? dev.cu_count * kLastAxisBwdBlocksPerCU : target;
     BwdPcCall<T> call{grad, x, dx, static_cast<T*>(ds), static_cast<T*>(db), wide, outer, channels, inner, scale, shift, &p,
                       gs, sym_term, partials, workspace_bytes, target_w, /*default_variant=*/variant == 0,
-                      /*whole_rounds=*/!last_axis, v, stream, ticket, plan_need, plan_note};
+                      /*whole_rounds=*/!last_axis, v, stream, plan_need, plan_note};
     if (vecw == 1) return bwd_pc_modes<IO, 1, 1>(call);
     if (cpl == 1) return bwd_pc_modes<IO, VB, 1>(call);
     if (cpl == 2) return bwd_pc_modes<IO, VB, 2>(call);

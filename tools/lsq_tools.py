@@ -33,7 +33,7 @@ def internal_abi():
            ("lsq_hip_forward_per_tensor", "lsq_hip_backward_per_tensor", "lsq_hip_forward_per_channel",
             "lsq_hip_backward_per_channel")}
     for n in ("force_ring", "set_ww_min_rows", "set_ww_split64", "set_ww_big", "set_ring_nt", "set_fin_ch",
-              "set_observe_wg_per_cu", "set_ww_max_log2", "set_seg_min_div", "set_fwd_direct", "set_seg_no_up_front", "set_own", "set_own_min_run", "set_own_fat", "set_ww_cb"):
+              "set_observe_wg_per_cu", "set_ww_max_log2", "set_seg_min_div", "set_fwd_direct", "set_seg_no_up_front", "set_own", "set_own_min_run", "set_own_fat"):
         tab["lsq_hip_debug_" + n] = (None, [_int])
     tab["lsq_hip_debug_last_launch"] = (None, [ctypes.POINTER(ctypes.c_int * 8)])
     return tab
@@ -94,7 +94,7 @@ def reset_knobs():
     lib = _state["lib"]
     if lib is not None:
         for n in ("force_ring", "set_ww_min_rows", "set_ww_split64", "set_ww_big", "set_ring_nt", "set_fin_ch",
-                  "set_observe_wg_per_cu", "set_ww_max_log2", "set_seg_min_div", "set_fwd_direct", "set_seg_no_up_front", "set_own", "set_own_min_run", "set_own_fat", "set_ww_cb"):
+                  "set_observe_wg_per_cu", "set_ww_max_log2", "set_seg_min_div", "set_fwd_direct", "set_seg_no_up_front", "set_own", "set_own_min_run", "set_own_fat"):
             getattr(lib, "lsq_hip_debug_" + n)(0)
         _drop_memos()
 
