@@ -121,6 +121,9 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)            # "gloo" + --single-device: smoke-test
     ap.add_argument("--single-device", action="store_true", help=argparse.SUPPRESS)  # the N>1 control flow on a 1-GPU box
     ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)     # tests: this rank raises before the timed region
+    ap.add_argument("--assume-peers", action="store_true",
+                    help="N = 1, workload cfg4_shard: time the shard step WITH its collective over --collective, in an RCCL world of one "
+                         "told it has a peer (the `cfg4_shard_collective` record of the default run as a workload of its own: for profilers)")
     ap.add_argument("--variant-fwd", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--variant-bwd", type=int, default=0, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
@@ -638,7 +641,12 @@ def run_rank(a):
     warm_floor_ms = 0.0 if (a.workload == "cfg2" or world > 1) else 60.0      # (N > 1: every rank must run the same steps)
     # ... and they report the median of three blocks of K steps (the headline: exactly its K steps, once)
     extra_blocks = 0 if (a.workload == "cfg2" or world > 1 or a.graph) else 2
-    m = measure(a.workload, a.steps, a.warmup, a.graph, a.buffers, warm_ms=warm_floor_ms, extra_blocks=extra_blocks)
+    head_kw = {}
+    if a.assume_peers:
+        if world != 1 or a.workload != "cfg4_shard":
+            raise SystemExit("--assume-peers is for --gpus 1 --workload cfg4_shard")
+        head_kw = dict(shard_of=8, collective=a.collective)
+    m = measure(a.workload, a.steps, a.warmup, a.graph, a.buffers, warm_ms=warm_floor_ms, extra_blocks=extra_blocks, **head_kw)
     c, dtype_name, esz, per_channel, shape, axis = m["c"], m["dtype_name"], m["esz"], m["per_channel"], m["shape"], m["axis"]
     scaling, n_local, n_global, n_sets, set_bytes = m["scaling"], m["n_local"], m["n_global"], m["n_sets"], m["set_bytes"]
     elapsed_max, fwd_ms, bwd_ms, fwd_avg, bwd_avg = m["elapsed_max"], m["fwd_ms"], m["bwd_ms"], m["fwd_avg"], m["bwd_avg"]
@@ -717,8 +725,9 @@ def run_rank(a):
                          "step_reads_only_achieved": round(step_gbs * 0.6, 1),
                          "step_reads_only_frac": round(step_gbs * 0.6 / HBM_PEAK_GBS, 4)},
         }
+        if world > 1 or a.assume_peers:
+            line["config"]["collective"] = m["collective_route"] + (" (" + a.collective + ")" if a.assume_peers else "")
         if world > 1:
-            line["config"]["collective"] = m["collective_route"]
             # rank 0's shard step alone / the same step inside the N-rank job (barrier-bracketed, max over ranks): what the
             # collective and the co-running ranks cost one GPU.  1.0 = none.
             line["per_gpu_efficiency"] = round(m["solo_ms"] / (elapsed_max / a.steps * 1e3), 4)

@@ -283,7 +283,10 @@ enum lsq_comm_op { LSQ_COMM_SUM = 0, LSQ_COMM_MIN = 1, LSQ_COMM_MAX = 2 };
 int lsq_hip_comm_unique_id(void* id /* LSQ_COMM_ID_BYTES, host memory */);
 int lsq_hip_comm_create(const void* id, int32_t rank, int32_t nranks, lsq_comm** out);
 int lsq_hip_comm_destroy(lsq_comm* comm);
-/* out4 = [rank, nranks, device, RCCL version code] */
+/* out4 = [rank, nranks, device | side-stream choice << 16, RCCL version code]; side-stream choice: 0 = not made yet, 2 = no
+ * candidate stream ran apart from the caller's (the first is used), 2 + k = candidate k - 1 was chosen (see
+ * lsq_hip_comm_all_reduce_begin: the stream of the overlapped form is picked, by measurement, so that it does not share a
+ * hardware queue with the stream of the first begin) */
 int lsq_hip_comm_info(const lsq_comm* comm, int32_t* out4);
 /* The communicator's own stream (a hipStream_t), for work that CONSUMES a reduction begun with lsq_hip_comm_all_reduce_begin
  * without making the caller's stream wait for it: enqueue the consumer (lsq_hip_sharded_finish, a cast) on this stream behind

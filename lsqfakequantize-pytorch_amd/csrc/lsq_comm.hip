@@ -14,6 +14,7 @@
 // loads and every other entry point works on a box without RCCL.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
@@ -106,14 +107,72 @@ constexpr int kTickets = 8;      // begin / end pairs that may be outstanding at
 
 }  // namespace
 
+constexpr int kCandidates = 6;   // streams the side stream is picked from (see pick_side_stream)
+
 struct lsq_comm {
     ncclComm_t comm;
     int rank, nranks, device;
     hipStream_t side;                      // the stream the overlapped reductions run on
+    hipStream_t cand[kCandidates];         // ... chosen among these at the first lsq_hip_comm_all_reduce_begin
+    int n_cand;
+    std::atomic<int> picked;               // 0: `side` is still cand[0], not yet checked against a caller's stream
     hipEvent_t ready[kTickets];            // recorded on the caller's stream: the buffer's producer has been enqueued
     hipEvent_t done[kTickets];             // recorded on `side` behind the reduction
     std::atomic<uint32_t> next;
 };
+
+namespace {
+
+// A HARDWARE queue of its own for the side stream.  HIP multiplexes its streams onto GPU_MAX_HW_QUEUES (4) hardware queues
+// per priority level, PyTorch's pool of 32 streams has filled them long before a communicator is created, and a cross-stream
+// wait parked in the SAME hardware queue as the compute stream stalls that stream's next kernel behind it: a BASELINE-config-4
+// shard step went 89 -> 106 us that way (profiles/r05_comm_cost.txt), exactly like with torch.distributed's own stream, and
+// 94 us with GPU_MAX_HW_QUEUES=8, where the streams happened to land apart.  A stream at another PRIORITY gets another queue
+// pool, but the streaming kernels next to a high- or low-priority queue ran 1.4-2.6 x slower (same file).  There is no API
+// that tells which queue a stream is on, so it is MEASURED, once, against the stream of the first begin: a long fill on the
+// caller's stream, a 4-byte fill on a candidate right behind it -- a candidate whose little fill finishes before the long one
+// does is on another queue.  ~1 ms, eager calls only (never while the caller's stream is capturing).
+void pick_side_stream(lsq_comm* c, hipStream_t caller) {
+    int expected = 0;
+    if (!c->picked.compare_exchange_strong(expected, 1)) return;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(caller, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        c->picked.store(0);          // decided at a later, eager begin
+        return;
+    }
+    const char* skip = getenv("LSQ_COMM_PICK_STREAM");          // experiments: 0 = keep the first candidate
+    if (skip && skip[0] == '0') return;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
+    const size_t bytes = std::min<size_t>(size_t{256} << 20, free_b / 8);
+    if (bytes < (size_t{32} << 20)) return;
+    char* scratch = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&scratch), bytes + 256) != hipSuccess) { (void)hipGetLastError(); return; }
+    hipEvent_t long_done = nullptr, small_done = nullptr;
+    bool ok = hipEventCreate(&long_done) == hipSuccess && hipEventCreate(&small_done) == hipSuccess;
+    int best = -1;
+    for (int i = 0; ok && i < c->n_cand && best < 0; ++i) {
+        int apart = 0;
+        for (int rep = 0; ok && rep < 2; ++rep) {
+            ok = hipStreamSynchronize(caller) == hipSuccess && hipStreamSynchronize(c->cand[i]) == hipSuccess &&
+                 hipMemsetAsync(scratch + 256, rep, bytes, caller) == hipSuccess && hipEventRecord(long_done, caller) == hipSuccess &&
+                 hipMemsetAsync(scratch, rep, 4, c->cand[i]) == hipSuccess && hipEventRecord(small_done, c->cand[i]) == hipSuccess &&
+                 hipEventSynchronize(long_done) == hipSuccess && hipEventSynchronize(small_done) == hipSuccess;
+            float ms = 0.0f;
+            if (ok && hipEventElapsedTime(&ms, small_done, long_done) == hipSuccess && ms > 0.002f) ++apart;   // the small fill ended first
+        }
+        if (apart == 2) best = i;
+    }
+    (void)hipGetLastError();
+    if (long_done) (void)hipEventDestroy(long_done);
+    if (small_done) (void)hipEventDestroy(small_done);
+    (void)hipFree(scratch);
+    if (best > 0) c->side = c->cand[best];
+    c->picked.store(2 + (best < 0 ? 0 : best + 1));             // (lsq_hip_comm_info reports it)
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -138,13 +197,16 @@ int lsq_hip_comm_create(const void* id, int32_t rank, int32_t nranks, lsq_comm**
     ncclUniqueId u;
     std::memcpy(u.internal, id, LSQ_COMM_ID_BYTES);
     if (int rc = rccl_status(r, r->CommInitRank(&c->comm, nranks, u, rank), "ncclCommInitRank")) { delete c; return rc; }
-    // the side stream: its whole job is one tiny launch per step.  LSQ_COMM_SIDE_PRIORITY=1 (experiments) creates it at the
-    // highest priority; the default is an ordinary non-blocking stream (tools/exp_comm_cost.py, profiles/r05_comm_cost.txt).
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    const char* pr = getenv("LSQ_COMM_SIDE_PRIORITY");
-    hipError_t e = (pr && pr[0] == '1') ? hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi)
-                                        : hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    // The side stream is an ordinary non-blocking stream -- but WHICH one matters (pick_side_stream): a few candidates now,
+    // the choice at the first begin, against the stream the caller actually computes on.
+    hipError_t e = hipSuccess;
+    c->n_cand = 0;
+    c->picked.store(0);
+    for (int i = 0; i < kCandidates && e == hipSuccess; ++i) {
+        e = hipStreamCreateWithFlags(&c->cand[i], hipStreamNonBlocking);
+        if (e == hipSuccess) c->n_cand = i + 1;
+    }
+    c->side = c->n_cand > 0 ? c->cand[0] : nullptr;
     // The two events order work of ONE device (the reduction reads what a kernel of the caller's stream wrote, the caller's
     // stream reads what the reduction wrote): the agent-scope release every kernel ends with is enough, the system-scope
     // fence an event records by default -- a writeback + invalidate of the L2s, paid again by the work behind it -- is not
@@ -172,7 +234,11 @@ int lsq_hip_comm_destroy(lsq_comm* c) {
         (void)hipEventDestroy(c->ready[i]);
         (void)hipEventDestroy(c->done[i]);
     }
-    (void)hipStreamDestroy(c->side);
+    // The side stream itself is NOT destroyed: the host layer may have handed it to its allocator as a consumer of buffers
+    // (torch: record_stream), which records an event on it when such a buffer is freed -- possibly long after this call
+    // (seen: a segmentation fault at interpreter exit).  One idle stream per communicator ever created stays behind.
+    for (int i = 0; i < c->n_cand; ++i)
+        if (c->cand[i] && c->cand[i] != c->side) (void)hipStreamDestroy(c->cand[i]);
     int rc = r ? rccl_status(r, r->CommDestroy(c->comm), "ncclCommDestroy") : LSQ_OK;
     delete c;
     return rc;
@@ -183,7 +249,7 @@ int lsq_hip_comm_info(const lsq_comm* c, int32_t* out4) {
     int version = 0;
     const Rccl* r = rccl();
     if (r && r->GetVersion) (void)r->GetVersion(&version);
-    out4[0] = c->rank; out4[1] = c->nranks; out4[2] = c->device; out4[3] = version;
+    out4[0] = c->rank; out4[1] = c->nranks; out4[2] = c->device | (c->picked.load() << 16); out4[3] = version;
     return LSQ_OK;
 }
 
@@ -214,8 +280,9 @@ int lsq_hip_comm_all_reduce_begin(lsq_comm* c, const void* send, void* recv, int
     if (int rc = check_reduce(c, send, recv, count, dtype, op, &t, &o)) return rc;
     if (!ticket) return fail(LSQ_EINVAL, "comm_all_reduce_begin: NULL ticket");
     const Rccl* r = rccl();
-    const uint32_t k = c->next.fetch_add(1) % kTickets;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (c->picked.load(std::memory_order_relaxed) == 0) pick_side_stream(c, s);
+    const uint32_t k = c->next.fetch_add(1) % kTickets;
     if (int rc = hip_status(hipEventRecord(c->ready[k], s), "comm_all_reduce_begin: hipEventRecord")) return rc;
     if (int rc = hip_status(hipStreamWaitEvent(c->side, c->ready[k], 0), "comm_all_reduce_begin: hipStreamWaitEvent")) return rc;
     if (int rc = rccl_status(r, r->AllReduce(send, recv, static_cast<size_t>(count), t, o, c->comm, c->side), "ncclAllReduce")) return rc;

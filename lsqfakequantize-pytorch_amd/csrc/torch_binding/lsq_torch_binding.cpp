@@ -18,6 +18,7 @@
 #include <ATen/ATen.h>
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPCachingAllocator.h>
+#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
@@ -320,6 +321,48 @@ BackwardOut backward_impl(const Tensor& grad, const Tensor& x, const Tensor& sca
                                        &extras, ws_ptr, ws_bytes, stream),
            "lsq_hip_backward_per_tensor");
     return {dx, ds, db, wide};
+}
+
+// ---- the batch-sharded backward in ONE host call (torchlsq.distributed.sharded_backward(async_op=True), native route) ------------
+// backward (`*_wide`: the global element count in the scaler, the un-rounded fp64 sums out) + lsq_hip_comm_all_reduce_begin of
+// those sums on the communicator's own stream + their rounding to the parameter type BEHIND the reduction on that stream: the
+// compute stream never waits for a single reduction (the caller joins once per step, lsq_hip_comm_all_reduce_end on the
+// returned ticket).  `comm` is the lsq_comm* the Python layer created (torchlsq._hip_host.HipComm.handle).
+// Returns (dx, wide, rounded, ticket): wide [2] / [2, C] fp64 (all-reduced in place once the side stream gets there),
+// rounded = wide in the parameter type (valid on the caller's stream after the join).
+std::tuple<Tensor, Tensor, Tensor, int64_t> backward_sharded(const Tensor& grad, const Tensor& x, const Tensor& scale, const Tensor& shift,
+                                                             bool per_channel, int64_t axis, const Scalars& s, int64_t numel_for_scaler,
+                                                             int64_t comm) {
+    TORCH_CHECK(comm != 0, "lsq_backward_*_sharded: no communicator");
+    BackwardOut o = backward_impl(grad, x, scale, shift, per_channel, axis, s, numel_for_scaler, /*want_wide=*/true);
+    lsq_comm* const c = reinterpret_cast<lsq_comm*>(static_cast<intptr_t>(comm));
+    const c10::Device dev = o.wide.device();
+    c10::DeviceGuard guard(dev);
+    int32_t ticket = -1;
+    status(lsq_hip_comm_all_reduce_begin(c, o.wide.data_ptr(), o.wide.data_ptr(), o.wide.numel(), LSQ_F64, LSQ_COMM_SUM, stream_of(o.wide), &ticket),
+           "lsq_hip_comm_all_reduce_begin");
+    Tensor rounded;
+    {
+        const c10::hip::HIPStream side = c10::hip::getStreamFromExternal(static_cast<hipStream_t>(lsq_hip_comm_side_stream(c)), dev.index());
+        c10::hip::HIPStreamGuard on_side(side);
+        rounded = o.wide.to(param_type(x.scalar_type()));
+        c10::hip::HIPCachingAllocator::recordStream(o.wide.storage().data_ptr(), side);   // `wide` is read over there
+    }
+    return {o.dx, o.wide, rounded, static_cast<int64_t>(ticket)};
+}
+
+std::tuple<Tensor, Tensor, Tensor, int64_t> backward_per_tensor_sharded(const Tensor& grad, const Tensor& x, const Tensor& scale,
+                                                                        const Tensor& shift, int64_t qmin, int64_t qmax, int64_t tmin,
+                                                                        int64_t tmax, bool use_gs, double gs, bool sym, bool eval_mode,
+                                                                        bool init_mode, int64_t numel_for_scaler, int64_t comm) {
+    return backward_sharded(grad, x, scale, shift, false, 0, {qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode}, numel_for_scaler, comm);
+}
+
+std::tuple<Tensor, Tensor, Tensor, int64_t> backward_per_channel_sharded(const Tensor& grad, const Tensor& x, const Tensor& scale,
+                                                                         const Tensor& shift, int64_t axis, int64_t qmin, int64_t qmax,
+                                                                         int64_t tmin, int64_t tmax, bool use_gs, double gs, bool sym,
+                                                                         bool eval_mode, bool init_mode, int64_t numel_for_scaler, int64_t comm) {
+    return backward_sharded(grad, x, scale, shift, true, axis, {qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode}, numel_for_scaler, comm);
 }
 
 Tensor backward_from_mask(const Tensor& grad, const Tensor& mask) {
@@ -685,6 +728,10 @@ TORCH_LIBRARY(torchlsq_native, m) {
           ", int numel_for_scaler) -> (Tensor, Tensor)");
     m.def("lsq_backward_per_channel_wide(Tensor grad, Tensor x, Tensor scale, Tensor shift, int axis, " LSQ_TAIL
           ", int numel_for_scaler) -> (Tensor, Tensor)");
+    m.def("lsq_backward_per_tensor_sharded(Tensor grad, Tensor x, Tensor scale, Tensor shift, " LSQ_TAIL
+          ", int numel_for_scaler, int comm) -> (Tensor, Tensor, Tensor, int)");
+    m.def("lsq_backward_per_channel_sharded(Tensor grad, Tensor x, Tensor scale, Tensor shift, int axis, " LSQ_TAIL
+          ", int numel_for_scaler, int comm) -> (Tensor, Tensor, Tensor, int)");
     m.def("lsq_backward_from_mask(Tensor grad, Tensor mask) -> Tensor");
     // composite (autograd handled by the node inside), like the reference's front op
     m.def("lsq(Tensor x, Tensor scale, Tensor shift, int quant_min, int quant_max, int type_min, int type_max, int axis, "
@@ -716,6 +763,8 @@ TORCH_LIBRARY_IMPL(torchlsq_native, CUDA, m) {  // PyTorch-ROCm dispatches HIP t
     m.impl("lsq_backward_per_channel", &backward_per_channel);
     m.impl("lsq_backward_per_tensor_wide", &backward_per_tensor_wide);
     m.impl("lsq_backward_per_channel_wide", &backward_per_channel_wide);
+    m.impl("lsq_backward_per_tensor_sharded", &backward_per_tensor_sharded);
+    m.impl("lsq_backward_per_channel_sharded", &backward_per_channel_sharded);
     m.impl("lsq_backward_from_mask", &backward_from_mask);
     m.impl("lsq_forward_per_channel_multi", &forward_per_channel_multi);
     m.impl("lsq_backward_per_channel_multi", &backward_per_channel_multi);

@@ -733,16 +733,18 @@ class HipComm:
 
     def side_stream(self):
         """the communicator's own stream as a torch stream (for consumers of a begun reduction; join with end() once)"""
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.ExternalStream(int(_abi._LIB.lsq_hip_comm_side_stream(self.handle)), device=self.device)
-        return self._side
+        ptr = int(_abi._LIB.lsq_hip_comm_side_stream(self.handle))     # (chosen at the first begin: ask every time)
+        hit = getattr(self, "_side", None)
+        if hit is None or hit[0] != ptr:
+            hit = self._side = (ptr, torch.cuda.ExternalStream(ptr, device=self.device))
+        return hit[1]
 
     def info(self):
         out = (ctypes.c_int32 * 4)()
         rc = _abi._LIB.lsq_hip_comm_info(self.handle, ctypes.byref(out))
         if rc:
             _status(rc, "lsq_hip_comm_info")
-        return dict(rank=out[0], nranks=out[1], device=out[2], rccl_version=out[3])
+        return dict(rank=out[0], nranks=out[1], device=out[2] & 0xffff, side_stream_choice=out[2] >> 16, rccl_version=out[3])
 
     def _args(self, t, out, op):
         _check(t.is_cuda and t.device.index == self.index and t.is_contiguous() and t.dtype in _COMM_DTYPES,

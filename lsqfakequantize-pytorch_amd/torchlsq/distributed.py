@@ -199,6 +199,20 @@ def sharded_backward(grad, x, scale, shift, quant_min, quant_max, type_min, type
     # GPU tensors go through the C++ host binding when it is loaded (same C ABI, same kernels; ~4x less host time per
     # call than the Python-registered op, which matters when a rank's shard is only tens of microseconds of GPU work)
     ops = torch.ops.torchlsq_native if (x.is_cuda and _E._NATIVE_LSQ is not None) else torch.ops.torchlsq
+    if async_op and ws > 1 and reduce and not eval_mode and ops is not torch.ops.torchlsq and x.numel() > 0:
+        # native collective + native host binding: backward, reduction on the communicator's stream and the rounding behind it
+        # in ONE host call (csrc/torch_binding: lsq_backward_*_sharded)
+        comm = native_comm(group, x.device)
+        if comm is not None:
+            if is_perchannel:
+                dx, wide, rounded, ticket = ops.lsq_backward_per_channel_sharded(grad, x, scale, shift, axis, quant_min, quant_max, type_min,
+                                                                                 type_max, use_grad_scaling, grad_scaler, sym, eval_mode,
+                                                                                 init_mode, n4s, comm.handle)
+            else:
+                dx, wide, rounded, ticket = ops.lsq_backward_per_tensor_sharded(grad, x, scale, shift, quant_min, quant_max, type_min, type_max,
+                                                                                use_grad_scaling, grad_scaler, sym, eval_mode, init_mode, n4s,
+                                                                                comm.handle)
+            return dx, wide, _NativeWork(comm, ticket, rounded)
     if is_perchannel:
         dx, wide = ops.lsq_backward_per_channel_wide(grad, x, scale, shift, axis, quant_min, quant_max, type_min,
                                                      type_max, use_grad_scaling, grad_scaler, sym, eval_mode, init_mode,

@@ -75,6 +75,17 @@ for step in range(4):
 pending[1].wait()
 torch.cuda.synchronize()
 ok = ok and torch.isfinite(pending[0]).all().item()
+# native route: the reduction's first consumer -- the rounding to the parameter type -- ran on the communicator's stream (one host
+# call through the C++ binding: lsq_backward_*_sharded; through Python otherwise); after the join it equals the cast of the sums
+ok = ok and getattr(pending[1], "deferred", False) and torch.equal(pending[1].rounded, pending[0].to(torch.float32))
+from torchlsq import extension as _E2
+_E2.set_host_binding("ctypes")
+dx_c, wide_c, work_c = D.sharded_backward(g, x, scale, shift, -8, 7, -128, 127, 1, True, 1.0, True, True, False, False, None, n, async_op=True)
+work_c.wait()
+torch.cuda.synchronize()
+ok = ok and torch.equal(wide_c, pending[0]) and torch.equal(work_c.rounded, pending[1].rounded) and torch.equal(dx_c, dx)
+_E2.set_host_binding("native")
+print("deferred consumer: fused op == python route", ok, flush=True)
 # the observer statistics' packed MIN all-reduce
 lo, hi = torch.tensor([-1.5, 0.25], device=dev), torch.tensor([2.0, 0.75], device=dev)
 a, b = D.all_reduce_minmax(lo, hi, None)
