@@ -189,9 +189,12 @@ def lsq_quantize(x: Tensor, scale: Tensor, shift: Tensor,
     """The REAL quantized tensor behind `lsq`'s fake-quantized output (an addition of this build): a `torch.quint8` /
     `torch.qint8` tensor whose integer representation holds the levels x_q of the forward (lsq_kernel.h:13) and whose
     quantizer carries s = max(|scale|, eps) and the integer zero point zp = round(clamp(-shift / s, type_min, type_max)) the
-    kernels use -- so `lsq_quantize(...).dequantize()` equals `lsq(...)` bit for bit ((x_q - zp) * s, the same two
-    operations).  One pass that reads x and writes ONE byte per element (no fake-quantized output: 5 instead of 9 bytes per
-    fp32 element on the GPU).  The step after the path: reference quantized/modules/observers.py:378-422 hands scale and
+    kernels use -- so for FLOAT32 x `lsq_quantize(...).dequantize()` equals `lsq(...)` bit for bit ((x_q - zp) * s, the same
+    two fp32 operations; torch's quantizer dequantizes in fp32, so a float64 x agrees only to fp32 precision and a 16-bit x
+    gets fp32 where `lsq` returns the value rounded to 16 bits -- the integer levels are the forward's in every case).  The
+    per-tensor form reads scale / zero point back to the host once per call (torch's per-tensor quantizer holds host numbers):
+    a conversion-time function, not one for a training loop.  One pass that reads x and writes ONE byte per element (no
+    fake-quantized output: 5 instead of 9 bytes per fp32 element on the GPU).  The step after the path: reference quantized/modules/observers.py:378-422 hands scale and
     zero_point to torch's converter, which quantizes again with its own rounding; here the trained quantizer emits them.
     """
     _assert_has_ops()

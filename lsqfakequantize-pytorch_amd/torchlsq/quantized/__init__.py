@@ -79,6 +79,12 @@ def prepare_ddp(model, process_group=None, grads="mean"):
         if id(mod) in synced:
             if grads != "ddp":           # ('ddp': the module leaves the reduction of its gradients to DDP)
                 ignore += [prefix + "scale", prefix + "shift"]
+            elif getattr(mod, "scale", None) is None or getattr(mod, "shift", None) is None:
+                # the quantizer creates its parameters at its FIRST call: a DDP built before that never learns of them, nobody
+                # reduces their gradients in this mode, and the replicas drift apart without a sound
+                import warnings
+                warnings.warn("prepare_ddp(grads='ddp'): quantizer %r has not created scale / shift yet -- run one batch through the "
+                              "model BEFORE wrapping it in DistributedDataParallel, or DDP will not reduce their gradients" % (name or "<root>"))
             if mod.activation_post_process is not None:
                 ignore += [prefix + "activation_post_process." + b for b, _ in mod.activation_post_process.named_buffers()]
     model._ddp_params_and_buffers_to_ignore = sorted(set(ignore))

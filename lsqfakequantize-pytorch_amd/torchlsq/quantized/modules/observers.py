@@ -33,6 +33,8 @@ from functools import partial
 from math import ceil, copysign, log
 from typing import Tuple
 
+import warnings
+
 import torch
 from torch.ao.quantization.observer import ObserverBase as _TorchObserverBase
 
@@ -163,6 +165,8 @@ class LSQFakeQuantizer(ObserverBase):
     # rank sync off unless switched on (class-level defaults: a module pickled by an earlier build has no such attributes)
     _sync = False
     _sync_grads = 'sum'
+    _ddp_numel = None       # sync_grads='ddp': the shard size the equal-shards shortcut was first used with
+    _ddp_warned = False
     _group_ref = _GroupRef(None)
 
     @staticmethod
@@ -574,6 +578,19 @@ class LSQFakeQuantizer(ObserverBase):
                 # the input is this rank's shard of the batch: one all-reduce per backward, scaler from the global count
                 from torchlsq.distributed import COLLECTIVE, lsq_sharded
                 ddp = self._sync_grads == 'ddp'       # the wrapper averages the gradients: no collective of our own
+                if ddp:
+                    # ... with the GLOBAL count taken as local numel x world size: right for equal shards only, and this rank
+                    # cannot know the others' sizes without the collective this mode exists to avoid (nor may it enter one on
+                    # its own: the other ranks would not).  A shard unlike the first one (the last batch of an epoch) gets a
+                    # gradient scaler that is off by sqrt(its share): say so, once.
+                    if self._ddp_numel is None:
+                        self._ddp_numel = x.numel()
+                    elif x.numel() != self._ddp_numel and not self._ddp_warned:
+                        self._ddp_warned = True
+                        warnings.warn("LSQFakeQuantizer(sync_grads='ddp') assumes equal shards on every rank: this call's shard has %d "
+                                      "elements, the first one had %d -- the gradient scaler 1/sqrt(numel * quant_max) of this step uses "
+                                      "%d x world size as the batch's element count.  Use sync_grads='mean' (prepare_ddp's default: the "
+                                      "count travels in the collective) or drop the ragged last batch." % (x.numel(), self._ddp_numel, x.numel()))
                 gs = self.grad_scaler / sync_ws if self._sync_grads == 'mean' else self.grad_scaler
                 return lsq_sharded(x, self.scale, self.shift, quant_min=self.quant_min, quant_max=self.quant_max,
                                    type_min=tmin, type_max=tmax, axis=self.ch_axis, use_grad_scaling=self.use_grad_scaling,
