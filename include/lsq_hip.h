@@ -290,9 +290,12 @@ int lsq_hip_comm_destroy(lsq_comm* comm);
 int lsq_hip_comm_info(const lsq_comm* comm, int32_t* out4);
 /* The communicator's own stream (a hipStream_t), for work that CONSUMES a reduction begun with lsq_hip_comm_all_reduce_begin
  * without making the caller's stream wait for it: enqueue the consumer (lsq_hip_sharded_finish, a cast) on this stream behind
- * the begin, and join the caller's stream once per training step -- lsq_hip_comm_all_reduce_end on the LAST ticket -- instead
+ * the begin, and join the caller's stream once per training step -- lsq_hip_comm_join -- instead
  * of once per reduction (a cross-stream wait costs the GPU ~7 us each way, profiles/r05_comm_cost.txt). */
 void* lsq_hip_comm_side_stream(const lsq_comm* comm);
+/* `stream` waits for EVERYTHING enqueued on the communicator's stream so far -- the reductions begun and whatever consumers
+ * the caller put behind them there: the once-per-step join of the pattern above. */
+int lsq_hip_comm_join(lsq_comm* comm, void* stream);
 int lsq_hip_comm_all_reduce(lsq_comm* comm, const void* send, void* recv, int64_t count, int dtype, int op, void* stream);
 int lsq_hip_comm_all_reduce_begin(lsq_comm* comm, const void* send, void* recv, int64_t count, int dtype, int op,
                                   void* stream, int32_t* ticket);

@@ -118,6 +118,8 @@ struct lsq_comm {
     std::atomic<int> picked;               // 0: `side` is still cand[0], not yet checked against a caller's stream
     hipEvent_t ready[kTickets];            // recorded on the caller's stream: the buffer's producer has been enqueued
     hipEvent_t done[kTickets];             // recorded on `side` behind the reduction
+    hipEvent_t joined[kTickets];           // lsq_hip_comm_join: recorded on `side` at the time of the join
+    std::atomic<uint32_t> next_join;
     std::atomic<uint32_t> next;
 };
 
@@ -216,7 +218,9 @@ int lsq_hip_comm_create(const void* id, int32_t rank, int32_t nranks, lsq_comm**
     for (int i = 0; i < kTickets && e == hipSuccess; ++i) {
         e = hipEventCreateWithFlags(&c->ready[i], flags);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done[i], flags);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->joined[i], flags);
     }
+    c->next_join.store(0);
     if (e != hipSuccess) {      // (a communicator that cannot get a stream is not worth tearing down carefully)
         r->CommDestroy(c->comm);
         delete c;
@@ -233,6 +237,7 @@ int lsq_hip_comm_destroy(lsq_comm* c) {
     for (int i = 0; i < kTickets; ++i) {
         (void)hipEventDestroy(c->ready[i]);
         (void)hipEventDestroy(c->done[i]);
+        (void)hipEventDestroy(c->joined[i]);
     }
     // The side stream itself is NOT destroyed: the host layer may have handed it to its allocator as a consumer of buffers
     // (torch: record_stream), which records an event on it when such a buffer is freed -- possibly long after this call
@@ -289,6 +294,13 @@ int lsq_hip_comm_all_reduce_begin(lsq_comm* c, const void* send, void* recv, int
     if (int rc = hip_status(hipEventRecord(c->done[k], c->side), "comm_all_reduce_begin: hipEventRecord")) return rc;
     *ticket = static_cast<int32_t>(k);
     return LSQ_OK;
+}
+
+int lsq_hip_comm_join(lsq_comm* c, void* stream) {
+    if (!c) return fail(LSQ_EINVAL, "comm_join: NULL communicator");
+    const uint32_t k = c->next_join.fetch_add(1) % kTickets;
+    if (int rc = hip_status(hipEventRecord(c->joined[k], c->side), "comm_join: hipEventRecord")) return rc;
+    return hip_status(hipStreamWaitEvent(static_cast<hipStream_t>(stream), c->joined[k], 0), "comm_join: hipStreamWaitEvent");
 }
 
 int lsq_hip_comm_all_reduce_end(lsq_comm* c, int32_t ticket, void* stream) {

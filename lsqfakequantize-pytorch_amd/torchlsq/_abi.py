@@ -86,6 +86,7 @@ C_ABI = {
     "lsq_hip_comm_destroy": (_int, [_vp]),
     "lsq_hip_comm_info": (_int, [_vp, ctypes.POINTER(ctypes.c_int32 * 4)]),
     "lsq_hip_comm_side_stream": (_vp, [_vp]),
+    "lsq_hip_comm_join": (_int, [_vp, _vp]),
     "lsq_hip_comm_all_reduce": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
     "lsq_hip_comm_all_reduce_begin": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, ctypes.POINTER(ctypes.c_int32)]),
     "lsq_hip_comm_all_reduce_end": (_int, [_vp, ctypes.c_int32, _vp]),

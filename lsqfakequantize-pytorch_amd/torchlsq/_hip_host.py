@@ -778,6 +778,13 @@ class HipComm:
         if rc:
             _status(rc, "lsq_hip_comm_all_reduce_end")
 
+    def join(self):
+        """the device's current stream waits for everything enqueued on the communicator's stream so far (reductions begun,
+        consumers placed behind them): the once-per-step join"""
+        rc = _on_device(self.index, _abi._LIB.lsq_hip_comm_join, self.handle, _stream_of(self.index))
+        if rc:
+            _status(rc, "lsq_hip_comm_join")
+
     def destroy(self):
         if self.handle:
             h, self.handle = self.handle, None

@@ -121,9 +121,11 @@ class _NativeWork:
         self.comm, self.ticket, self.rounded, self.deferred = comm, ticket, rounded, True
 
     def wait(self):
-        self.comm.end(self.ticket)
         if self.rounded is not None:
+            self.comm.join()             # the reduction AND the rounding behind it (and everything earlier on that stream)
             self.rounded.record_stream(torch.cuda.current_stream(self.rounded.device))
+        else:
+            self.comm.end(self.ticket)
         return True
 
 
