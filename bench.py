@@ -18,7 +18,7 @@ packed fp64 [d_scale, d_shift] sums per step -- inside the timed region.
 Workloads that stream less than 1 GiB per step (everything but config 2 and a config-4 shard at small N) rotate through
 `config.input_buffer_sets` copies of (x, grad), more than 1 GiB of inputs in total, the backward working on a set the
 forward last touched half a rotation ago: otherwise the part's 256 MB Infinity Cache serves a config-5-sized step and the
-"HBM" fraction is not one.  `--buffers 1` re-uses one set.
+"HBM" fraction is not one (DESIGN_HISTORY.md section 7).  `--buffers 1` re-uses one set.
 
 Rank 0 prints ONE JSON line; `value` is the whole-job aggregate: (elements of all ranks * K) / time,
 time = max over ranks of the K-step wall time bracketed by barrier + synchronize.

@@ -110,7 +110,7 @@ typedef struct lsq_fwd_extras {
  * takes the two-launch route -- or a single launch where one workgroup owns a whole channel, e.g. conv / linear weights):
  * measured on MI355X the folded finalize is not faster than the finalize launch -- for the per-tensor kernel (DESIGN.md
  * section 4; the host layers still use it for small tensors, where the saved launch is host time) and for a per-window fold
- * built for the window kernels (profiles/r03_pc_fused_fold_ab.txt) -- so the per-channel kernels have none. */
+ * built for the window kernels (DESIGN_HISTORY.md section 7, profiles/r03_pc_fused_fold_ab.txt) -- so the per-channel kernels have none. */
 #define LSQ_TICKET_BYTES 4096
 typedef struct lsq_bwd_extras {
     void* ticket;
@@ -141,7 +141,7 @@ double lsq_hip_grad_scaler(int dtype, int per_channel, int64_t numel, int32_t qu
  *
  * lsq_hip_policy_ticket: should this backward be given a ticket (one launch instead of kernel + finalize launch)?
  *   mode 0 never, 1 always, 2 "auto": per-tensor tensors of at most 8 MB -- host-bound in eager mode, where one launch less is
- *   11-15 % of a forward + backward step, while on the GPU the one-launch route is never faster.  The
+ *   11-15 % of a forward + backward step, while on the GPU the one-launch route is never faster (DESIGN_HISTORY.md section 4).  The
  *   per-channel entry point ignores tickets, so auto never asks for one there.  Captured launches take none whatever the
  *   answer (the caller knows whether its stream is capturing).
  * lsq_hip_policy_saves_mask: does the forward of an autograd node save the one-byte inside mask (aux_kind 1) instead of x?

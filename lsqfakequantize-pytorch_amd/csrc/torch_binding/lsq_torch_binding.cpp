@@ -14,7 +14,7 @@
 //
 // torchlsq.functional.lsq uses torchlsq_native::lsq for GPU tensors when this library is present: one
 // dispatcher call and a C++ autograd node instead of a Python autograd.Function (host cost per
-// forward+backward of a small layer: see DESIGN.md section 7).
+// forward+backward of a small layer: see DESIGN_HISTORY.md section 7).
 #include <ATen/ATen.h>
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPCachingAllocator.h>

@@ -1,4 +1,4 @@
-"""GPU: OWNER windows of the per-channel backward (lsq_pc_geom.hpp plan_own) held to the CPU oracle on the
+"""GPU: OWNER windows of the per-channel backward (lsq_pc_geom.hpp plan_own; DESIGN_HISTORY.md section 4) held to the CPU oracle on the
 production library's default policy: the shapes here are the ones the policy sends there (NCHW-style activations of at most
 13 M (fp32) / 20 M (16-bit) elements with at least ~200 owners), across storage types, channel-row lengths (1 or 2 channels per lane, 1..8 channels
 per owner), row counts that do and do not divide into the row slots (stand-in lanes / the generic loop), training modes, and the

@@ -231,7 +231,7 @@ def test_tools_build_and_product_give_the_same_bits(E):
             assert u.dtype == v.dtype and u.shape == v.shape, (case, n)
             if u.dtype == torch.float64 and n in ("ds", "db"):
                 # fp64 sums of the 256-lane windows: the four waves' LDS atomics land in arrival order, two LAUNCHES of one
-                # binary agree to an fp64 rounding only -- so do two binaries
+                # binary agree to an fp64 rounding only (DESIGN_HISTORY.md section 4) -- so do two binaries
                 assert torch.allclose(u, v, rtol=1e-13, atol=0, equal_nan=True), (case, n)
             else:
                 assert torch.equal(u.view(torch.uint8), v.view(torch.uint8)), (case, n)

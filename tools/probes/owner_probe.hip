@@ -1,5 +1,5 @@
 // tools/probes/owner_probe.hip -- can a workgroup OWN its channels for all rows (so that the per-channel backward needs no
-// partials and no finalize launch) and still stream at the HBM rate?  (round-4 experiment (c))
+// partials and no finalize launch) and still stream at the HBM rate?  (round-4 experiment (c), DESIGN_HISTORY.md section 7.)
 // No-arithmetic 2R:1W (y = g + x on 16-byte packets) kernel with that access pattern on the [rows][L] view of an NCHW
 // activation quantized on axis 1 (L = C * inner): workgroup j owns `run` consecutive 16-byte packets of every row -- k whole
 // channels when run * 16 = k * inner * elem_size -- and its `waves` waves deal the (row, packet) pairs of those runs among
