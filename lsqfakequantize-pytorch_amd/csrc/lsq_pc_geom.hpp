@@ -137,6 +137,7 @@ struct PcGeom {
     int32_t direct;          // forward, a lane's components are different channels: no LDS table, the lane reads its own scale / shift
     int32_t own;             // OWNER windows (make_geom_own): lanes per row of the owner's run; 0 otherwise
     int32_t own_prio;        // owner windows: the waves of a SIMD take turns at the higher issue priority (bwd_pc_kernel)
+    int32_t xcds;            // owner windows: XCDs the owners are dealt over (workgroups go to the XCDs round-robin by blockIdx.x)
 #ifdef LSQ_TIMELINE
     unsigned long long* timeline;   // experiment build (tools/exp_timeline.py): 8 x u64 per wave of the window backward
 #endif
@@ -198,6 +199,7 @@ static inline PcGeom make_geom(int64_t outer, int64_t C, int64_t inner, int vec,
     g.direct = 0;
     g.own = 0;
     g.own_prio = 0;
+    g.xcds = 1;
 #ifdef LSQ_TIMELINE
     g.timeline = nullptr;
 #endif
@@ -239,6 +241,7 @@ static inline PcGeom make_geom_ww(int64_t outer, int64_t C, int vec, int target_
     g.direct = 0;
     g.own = 0;
     g.own_prio = 0;
+    g.xcds = 1;
 #ifdef LSQ_TIMELINE
     g.timeline = nullptr;
 #endif
@@ -366,17 +369,20 @@ static inline PcGeom make_geom_own(int64_t outer, int64_t C, int64_t inner, int 
     g.direct = 0;
     g.own = o.lanes_per_row;
     g.own_prio = 1;
+    // HIP does not expose the XCD count; gfx950 parts have 32 CUs per XCD (MI355X: 256 CUs = 8 XCDs).  A wrong guess only
+    // costs the shared-cache-line benefit of dealing neighbouring owners to one XCD, never correctness.
+    g.xcds = std::max(1, std::min(8, device_info().cu_count / 32));
 #ifdef LSQ_TIMELINE
     g.timeline = nullptr;
 #endif
     return g;
 }
-// the owner a workgroup serves: blockIdx.x dealt XCD-major (workgroups go to the 8 XCDs round-robin: blockIdx.x % 8 is the
+// the owner a workgroup serves: blockIdx.x dealt XCD-major (workgroups go to the XCDs round-robin: blockIdx.x % xcds is the
 // XCD), so that owners j and j + 1 -- whose runs share a cache line -- sit on the same XCD
 __device__ __forceinline__ int64_t own_window(const PcGeom& g) {
-    (void)g;
-    const uint32_t n = gridDim.x, x = blockIdx.x & 7u, i = blockIdx.x >> 3;
-    const uint32_t per = n >> 3, rem = n & 7u;
+    const uint32_t n = gridDim.x, k = static_cast<uint32_t>(g.xcds);
+    const uint32_t x = blockIdx.x % k, i = blockIdx.x / k;
+    const uint32_t per = n / k, rem = n % k;
     return static_cast<int64_t>(x * per + (x < rem ? x : rem) + i);
 }
 

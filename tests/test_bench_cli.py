@@ -61,6 +61,12 @@ def test_default_line_has_secondary_records_declared():
     assert b.SECONDARY == ("cfg1", "cfg3", "cfg5", "cfg5_bf16")
     a = b.parse_args([])
     assert a.workload == "cfg2" and a.gpus == 1 and not a.no_secondary
+    # the sharded step's collective: the library's own RCCL communicator by default, the record of the default run declared
+    assert a.collective == "native" and not a.assume_peers
+    assert b.parse_args(["--collective", "native-inline"]).collective == "native-inline"
+    assert b.parse_args(["--workload", "cfg4_shard", "--assume-peers", "--collective", "c10d"]).assume_peers
+    names = [extra.get("name", w) for w, extra in b.SECONDARY_RUNS]
+    assert "cfg4_shard" in names and names.index("cfg4_shard_collective") == names.index("cfg4_shard") + 1
 
 
 @pytest.mark.gpu

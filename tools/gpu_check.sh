@@ -1,0 +1,17 @@
+#!/bin/bash
+export TMPDIR=/tmp
+O=gpurun_out/r5z
+mkdir -p $O
+python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -4 $O/smoke.txt | cut -c1-200
+timeout 2400 python3 -m pytest tests -m gpu -q > $O/tests_all.txt 2>&1
+tail -4 $O/tests_all.txt | cut -c1-300
+timeout 900 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
+python3 - <<'PY'
+import json
+lines=[l for l in open("gpurun_out/r5z/bench_default.json").read().splitlines()]
+print("stdout lines:", len(lines), "last is json:", lines[-1].startswith("{"))
+d=json.loads([l for l in lines if l.startswith("{")][-1])
+print("value", d["value"], "ms", d["ms_per_step"], "frac", d["roofline"]["frac"], "step_frac", d["roofline"]["step_frac"], "secondary_wall_s", d.get("secondary_wall_s"))
+for s in d.get("secondary", []):
+    print(s["workload"], s.get("value"), s.get("ms_per_step"), s.get("error", ""), s.get("wall_over_solo_shard_step", ""))
+PY
