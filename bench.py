@@ -281,6 +281,11 @@ def run_rank(a):
     # multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise); the
     # launcher normally exports it already
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # stdout carries ONE line, the JSON record: native libraries write there too (RCCL prints a five-line version banner
+    # through C stdio whenever a communicator is created), so file descriptor 1 points at stderr until the record is printed
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     import torchlsq  # noqa: F401
@@ -878,14 +883,15 @@ def run_rank(a):
     if rank == 0:
         if strong is not None:
             line["strong_scaled"] = strong
-        # RCCL writes a version banner through C stdio when a communicator is created; on a pipe it would only come out at
-        # exit, BEHIND the JSON line.  Flush it now: the JSON line is the last line of stdout.
-        try:
+        try:                                   # whatever C stdio still holds goes where fd 1 points now: stderr
             import ctypes
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)                  # the real stdout, for exactly one line
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if dist.is_initialized():
         from torchlsq import distributed as D
         D.destroy_native_comms()
