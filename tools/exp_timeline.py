@@ -26,7 +26,7 @@ def build():
     os.makedirs(OUT, exist_ok=True)
     flags = ["-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-DLSQ_TOOLS", "-DLSQ_TIMELINE"]
     jobs, objs = [], []
-    for src, extra in (("lsq_capi.hip", []), ("lsq_per_tensor.hip", []), ("lsq_observe.hip", []), ("lsq_multi.hip", []),
+    for src, extra in (("lsq_capi.hip", []), ("lsq_per_tensor.hip", []), ("lsq_observe.hip", []), ("lsq_multi.hip", []), ("lsq_comm.hip", []),
                        ("lsq_per_channel.hip", ["-DLSQ_PC_IO=io_f32"]), ("lsq_per_channel.hip", ["-DLSQ_PC_IO=io_f64"]),
                        ("lsq_per_channel.hip", ["-DLSQ_PC_IO=io_bf16"]), ("lsq_per_channel.hip", ["-DLSQ_PC_IO=io_f16"])):
         obj = os.path.join("/tmp", "tl_%s_%s.o" % (src.replace(".hip", ""), extra[0][-4:] if extra else "x"))
