@@ -184,3 +184,42 @@ def test_cpp_torch_binding_uses_only_the_public_abi():
     assert E.host_binding() == "ctypes" and E.native_lsq() is None
     E.set_host_binding("native")
     assert E.host_binding() == "native"
+
+
+def test_comm_entry_points_validate_before_anything_else():
+    """lsq_hip_comm_*: RCCL is resolved lazily with dlopen (no link dependency: the library loaded above), a unique id can be
+    made without a GPU, and bad arguments come back as LSQ_EINVAL with a message -- nothing is launched here."""
+    from torchlsq import extension as E
+    lib = E.library()
+    needed = subprocess.run(["readelf", "-d", LIB], capture_output=True, text=True, check=True).stdout
+    assert "rccl" not in needed.lower() and "nccl" not in needed.lower()
+    uid = E.HipComm.unique_id()
+    assert len(uid) == E.LSQ_COMM_ID_BYTES and any(uid)
+    assert lib.lsq_hip_comm_unique_id(None) == -1 and b"NULL" in lib.lsq_hip_last_error()
+    out = ctypes.c_void_p()
+    buf = (ctypes.c_ubyte * E.LSQ_COMM_ID_BYTES).from_buffer_copy(uid)
+    assert lib.lsq_hip_comm_create(ctypes.cast(buf, ctypes.c_void_p), 3, 2, ctypes.byref(out)) == -1      # rank 3 of 2
+    assert b"rank 3 of 2" in lib.lsq_hip_last_error() and not out.value
+    assert lib.lsq_hip_comm_all_reduce(None, None, None, 1, E.LSQ_F64, E.LSQ_COMM_SUM, None) == -1
+    assert lib.lsq_hip_comm_all_reduce_end(None, 0, None) == -1 and lib.lsq_hip_comm_join(None, None) == -1
+    assert lib.lsq_hip_comm_destroy(None) == 0 and not lib.lsq_hip_comm_side_stream(None)
+
+
+def test_plan_query_answers_without_launching_anything():
+    """lsq_hip_plan_backward_per_channel on a box without a GPU: the CU count falls back to MI355X's 256, the kernel families
+    come out as on the GPU (tests/test_shipped_binary_gpu.py asserts them there together with the results)"""
+    from torchlsq import extension as E
+    lib = E.library()
+    p = E.LsqParams(0, 127, 0, 255, 1, 0, 0, 0, 1.0, 0)
+
+    def kind(code, outer, C, inner, aligned=1):
+        out = (ctypes.c_int32 * 8)()
+        assert lib.lsq_hip_plan_backward_per_channel(code, outer, C, inner, aligned, ctypes.byref(p), ctypes.byref(out)) == 0
+        return out[4], out[6]
+    assert kind(E.LSQ_BF16, 64, 2048, 49)[0] == 4 and kind(E.LSQ_F32, 33, 2048, 49)[0] == 4          # owner windows
+    assert kind(E.LSQ_F32, 320, 256, 196)[0] == 1                                                       # 256-lane windows
+    assert kind(E.LSQ_BF16, 12608, 768, 1) == (2, 768) and kind(E.LSQ_F32, 12608, 768, 1) == (2, 256)   # row groups, fat / usual
+    assert kind(E.LSQ_F32, 1, 512, 4608)[0] == 3                                                        # segment walk (config 3)
+    assert kind(E.LSQ_BF16, 64, 2048, 49, aligned=0)[0] == 1                                            # unaligned: element-wise windows
+    out = (ctypes.c_int32 * 8)()
+    assert lib.lsq_hip_plan_backward_per_channel(E.LSQ_F32, 0, 8, 8, 1, ctypes.byref(p), ctypes.byref(out)) == -1
