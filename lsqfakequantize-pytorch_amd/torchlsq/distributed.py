@@ -299,21 +299,19 @@ def all_reduce_minmax(cur_min, cur_max, group=None):
     n = cur_min.numel()
     # torch.aminmax (what the reference's observers see, quantized/modules/observers.py:446-449) makes BOTH results NaN when
     # the batch holds a NaN; what MIN does with a NaN is the backend's business (RCCL and gloo differ, and ranks could end up
-    # with different parameters exactly when the data is bad).  So NaNs do not travel: a third slot per value carries
-    # "this rank saw a NaN" (-1, else 0) through the same MIN, the values themselves go in with NaN replaced by +inf, and
-    # every rank poisons its result where any rank raised the flag -- the aminmax answer on the whole batch, on every rank.
+    # with different parameters exactly when the data is bad).  So a third slot per value carries "this rank saw a NaN" (-1,
+    # else 0: NaN-free, the same on every rank after the MIN) and every rank overwrites its result with NaN where any rank
+    # raised it -- whatever the backend made of the NaN slots themselves: the aminmax answer on the whole batch, everywhere.
+    # (cur_min / cur_max come from aminmax-style reductions: one is NaN exactly when the other is.)
     lo, hi = cur_min.reshape(-1), cur_max.reshape(-1)
-    bad = torch.isnan(lo) | torch.isnan(hi)
-    inf = torch.full_like(lo, float("inf"))
-    packed = torch.cat([torch.where(bad, inf, lo), torch.where(bad, inf, -hi), -bad.to(lo.dtype)])
+    packed = torch.cat([lo, -hi, -(torch.isnan(lo).to(lo.dtype))])
     if _world(group) > 1:
         comm = native_comm(group, packed.device) if (packed.is_cuda and packed.dtype in (torch.float32, torch.float64)) else None
         if comm is not None:
             comm.all_reduce(packed, op=_E.LSQ_COMM_MIN)
         else:
             dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=group)
-    nan = torch.full_like(lo, float("nan"))
     poisoned = packed[2 * n:] < 0
-    gmin = torch.where(poisoned, nan, packed[:n])
-    gmax = torch.where(poisoned, nan, -packed[n:2 * n])
+    gmin = packed[:n].masked_fill(poisoned, float("nan"))
+    gmax = (-packed[n:2 * n]).masked_fill(poisoned, float("nan"))
     return gmin.reshape(cur_min.shape), gmax.reshape(cur_max.shape)

@@ -3,7 +3,8 @@
 backward per step, eager, wall clock -- with the collectives executed by RCCL in a world of ONE (every all-reduce an identity,
 so the numbers contain the call path, the extra launches and RCCL's enqueue + kernel, not a transport between GPUs) and the
 module told it has peers.  Observer-driven init step (statistics -> packed MIN all-reduce -> one-launch tail -> eval-mode
-fake-quant) and LSQ step (forward, sharded backward with the count in the collective).  Output: profiles/r04_module_sync_cost.txt"""
+fake-quant) and LSQ step (forward, sharded backward with the count in the collective).  Output: profiles/r0x_module_sync_cost.txt (round 5: the collectives go through the library's own RCCL communicator;
+TORCHLSQ_COLLECTIVE=c10d for torch.distributed)"""
 import os
 import sys
 import time
@@ -18,7 +19,7 @@ os.environ.setdefault("MASTER_PORT", "29671")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torchlsq  # noqa: E402,F401
 from torch.ao.quantization.observer import MovingAverageMinMaxObserver, MovingAveragePerChannelMinMaxObserver  # noqa: E402
-from torchlsq import synth  # noqa: E402
+from torchlsq import synth, distributed as D  # noqa: E402
 from torchlsq.quantized import LSQFakeQuantizer  # noqa: E402
 from torchlsq.quantized.modules import observers as OBS  # noqa: E402
 
@@ -65,6 +66,7 @@ def main():
                 times = {}
                 for sync in (False, True):
                     OBS._dist_world = (lambda group: 2) if sync else (lambda group: 1)
+                    D.assume_peers(sync)          # ... and torchlsq.distributed issues its collectives as if the group had peers
                     m = LSQFakeQuantizer(obs_cls, "activation", init_batches=(10 ** 9 if phase.startswith("observer") else 0), sync=sync, **extra).train()
                     m(xs[0])
                     m.to(dev)
@@ -73,6 +75,8 @@ def main():
             print("%-20s %-12s %s" % ("x".join(str(d) for d in shape), name, "   |   ".join(row)), flush=True)
         del xs, ws
         torch.cuda.empty_cache()
+    D.assume_peers(False)
+    D.destroy_native_comms()
     dist.destroy_process_group()
 
 
