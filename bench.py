@@ -880,6 +880,23 @@ def run_rank(a):
                       "per_gpu_efficiency": round(m4["solo_ms"] / (t4 * 1e3), 4), "input_buffer_sets": m4["n_sets"],
                       "collective": m4["collective_route"], "launch": "eager"}
         del m4
+        # the same strong-scaled step over the OTHER routes of the collective (every rank runs the same sequence): which one the
+        # transport between the GPUs favours is the one thing a single GPU cannot tell
+        chosen = a.collective
+        others = {}
+        for route in ("native", "native-inline", "c10d"):
+            if route == chosen:
+                continue
+            a.collective = route
+            mr = measure("cfg4", a.steps, a.warmup)
+            if rank == 0:
+                tr = mr["elapsed_max"] / mr["steps"]
+                others[route] = {"ms_per_step": round(tr * 1e3, 5), "per_gpu_efficiency": round(mr["solo_ms"] / (tr * 1e3), 4),
+                                 "collective": mr["collective_route"]}
+            del mr
+        a.collective = chosen
+        if rank == 0:
+            strong["other_routes"] = others
     if rank == 0:
         if strong is not None:
             line["strong_scaled"] = strong

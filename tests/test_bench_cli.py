@@ -50,6 +50,8 @@ def test_default_multi_rank_line_carries_the_strong_scaled_config_too():
     s4 = out["strong_scaled"]
     assert s4["scaling"] == "strong" and s4["global_elements"] == 1024 * 1024 * 14 * 14 and s4["elements_per_gpu"] * 2 == s4["global_elements"]
     assert s4["value"] > 0 and 0 < s4["per_gpu_efficiency"] and 0 < out["per_gpu_efficiency"]
+    # ... and over the other routes of the collective (over gloo every route ends in torch.distributed: the control flow)
+    assert sorted(s4["other_routes"]) == ["c10d", "native-inline"] and all(r["ms_per_step"] > 0 for r in s4["other_routes"].values())
 
 
 def test_default_line_has_secondary_records_declared():
