@@ -266,7 +266,8 @@ struct BackwardOut {
 };
 
 BackwardOut backward_impl(const Tensor& grad, const Tensor& x, const Tensor& scale, const Tensor& shift, bool per_channel,
-                          int64_t axis, const Scalars& s, int64_t numel_for_scaler = 0, bool want_wide = false) {
+                          int64_t axis, const Scalars& s, int64_t numel_for_scaler = 0, bool want_wide = false,
+                          const Tensor* wide_out = nullptr /* caller's fp64 buffer of at least 2 C (or 2) elements */) {
     check_backward_types(grad, x, scale, shift);
     if (per_channel) check_channel_args(x, scale, shift, axis);
     if (x.numel() <= 0) {   // lsq_cpu.cpp:76-78,221-223 return (x, scale, shift) themselves
@@ -294,7 +295,7 @@ BackwardOut backward_impl(const Tensor& grad, const Tensor& x, const Tensor& sca
     if (per_channel) {
         const Geometry g = geometry(xd, axis);
         Tensor ds = at::empty({g.channels}, popt), db = at::empty({g.channels}, popt);
-        if (want_wide) wide = at::empty({2, g.channels}, x.options().dtype(at::kDouble));
+        if (want_wide) wide = wide_out ? *wide_out : at::empty({2, g.channels}, x.options().dtype(at::kDouble));
         const Tensor ws = byte_workspace(x, lsq_hip_backward_per_channel_workspace(code, g.outer, g.channels, g.inner));
         status(lsq_hip_backward_per_channel(code, gd.data_ptr(), xd.data_ptr(), dx.data_ptr(), ds.data_ptr(), db.data_ptr(),
                                             want_wide ? wide.data_ptr<double>() : nullptr, g.outer, g.channels, g.inner,
@@ -304,7 +305,7 @@ BackwardOut backward_impl(const Tensor& grad, const Tensor& x, const Tensor& sca
         return {dx, ds, db, wide};
     }
     Tensor ds = at::empty({1}, popt), db = at::empty({1}, popt);
-    if (want_wide) wide = at::empty({2}, x.options().dtype(at::kDouble));
+    if (want_wide) wide = wide_out ? *wide_out : at::empty({2}, x.options().dtype(at::kDouble));
     Tensor ws;                                   // with a ticket: the slot's own workspace, no allocation
     void* ws_ptr = nullptr;
     size_t ws_bytes = 0;
@@ -363,6 +364,39 @@ std::tuple<Tensor, Tensor, Tensor, int64_t> backward_per_channel_sharded(const T
                                                                          int64_t tmin, int64_t tmax, bool use_gs, double gs, bool sym,
                                                                          bool eval_mode, bool init_mode, int64_t numel_for_scaler, int64_t comm) {
     return backward_sharded(grad, x, scale, shift, true, axis, {qmin, qmax, tmin, tmax, use_gs, gs, sym, eval_mode, init_mode}, numel_for_scaler, comm);
+}
+
+// ---- the sharded backward when no rank knows the global element count (torchlsq.distributed, global_numel=COLLECTIVE) ----------
+// lsq_backward_packed: the local backward with UNSCALED terms into packed = [sum ds terms (C), sum db terms (C), this shard's
+// element count] -- the buffer of the ONE all-reduce; lsq_sharded_finish: d_scale / d_shift from the all-reduced buffer, the
+// gradient scaler derived from the summed count on the device (lsq_hip_sharded_finish).  The collective in between is the
+// caller's (the library's communicator or torch.distributed).
+std::tuple<Tensor, Tensor> backward_packed(const Tensor& grad, const Tensor& x, const Tensor& scale, const Tensor& shift, bool per_channel,
+                                           int64_t axis, int64_t qmin, int64_t qmax, int64_t tmin, int64_t tmax, bool sym, bool init_mode) {
+    const int64_t C = per_channel ? scale.numel() : 1;
+    Tensor packed = at::full({2 * C + 1}, static_cast<double>(x.numel()), x.options().dtype(at::kDouble));
+    if (x.numel() <= 0) {
+        packed.narrow(0, 0, 2 * C).zero_();
+        return {x.clone(), packed};
+    }
+    BackwardOut o = backward_impl(grad, x, scale, shift, per_channel, axis, {qmin, qmax, tmin, tmax, false, 1.0, sym, false, init_mode}, 0,
+                                  /*want_wide=*/true, &packed);
+    return {o.dx, packed};
+}
+
+std::tuple<Tensor, Tensor> sharded_finish(const Tensor& packed, int64_t channels, bool per_channel, int64_t x_dtype_code, int64_t qmax,
+                                          bool use_gs, double gs) {
+    require_gpu("lsq_sharded_finish", {&packed});
+    TORCH_CHECK(packed.scalar_type() == at::kDouble && packed.is_contiguous() && packed.numel() == 2 * channels + 1,
+                "lsq_sharded_finish: packed must be a contiguous float64 tensor of 2 * channels + 1 elements");
+    const auto ptype = x_dtype_code == LSQ_F64 ? at::kDouble : at::kFloat;
+    Tensor ds = at::empty({channels}, packed.options().dtype(ptype)), db = at::empty({channels}, packed.options().dtype(ptype));
+    const lsq_params p = pack({0, qmax, 0, qmax, use_gs, gs, false, false, false});
+    c10::DeviceGuard guard(packed.device());
+    status(lsq_hip_sharded_finish(static_cast<int>(x_dtype_code), packed.data_ptr<double>(), channels, per_channel ? 1 : 0, &p,
+                                  ds.data_ptr(), db.data_ptr(), stream_of(packed)),
+           "lsq_hip_sharded_finish");
+    return {ds, db};
 }
 
 Tensor backward_from_mask(const Tensor& grad, const Tensor& mask) {
@@ -732,6 +766,10 @@ TORCH_LIBRARY(torchlsq_native, m) {
           ", int numel_for_scaler, int comm) -> (Tensor, Tensor, Tensor, int)");
     m.def("lsq_backward_per_channel_sharded(Tensor grad, Tensor x, Tensor scale, Tensor shift, int axis, " LSQ_TAIL
           ", int numel_for_scaler, int comm) -> (Tensor, Tensor, Tensor, int)");
+    m.def("lsq_backward_packed(Tensor grad, Tensor x, Tensor scale, Tensor shift, bool per_channel, int axis, int quant_min, "
+          "int quant_max, int type_min, int type_max, bool sym, bool init_mode) -> (Tensor, Tensor)");
+    m.def("lsq_sharded_finish(Tensor packed, int channels, bool per_channel, int x_dtype_code, int quant_max, bool use_grad_scaling, "
+          "float grad_scaler) -> (Tensor, Tensor)");
     m.def("lsq_backward_from_mask(Tensor grad, Tensor mask) -> Tensor");
     // composite (autograd handled by the node inside), like the reference's front op
     m.def("lsq(Tensor x, Tensor scale, Tensor shift, int quant_min, int quant_max, int type_min, int type_max, int axis, "
@@ -765,6 +803,8 @@ TORCH_LIBRARY_IMPL(torchlsq_native, CUDA, m) {  // PyTorch-ROCm dispatches HIP t
     m.impl("lsq_backward_per_channel_wide", &backward_per_channel_wide);
     m.impl("lsq_backward_per_tensor_sharded", &backward_per_tensor_sharded);
     m.impl("lsq_backward_per_channel_sharded", &backward_per_channel_sharded);
+    m.impl("lsq_backward_packed", &backward_packed);
+    m.impl("lsq_sharded_finish", &sharded_finish);
     m.impl("lsq_backward_from_mask", &backward_from_mask);
     m.impl("lsq_forward_per_channel_multi", &forward_per_channel_multi);
     m.impl("lsq_backward_per_channel_multi", &backward_per_channel_multi);
