@@ -2,8 +2,8 @@
 handful of boxes (profiles/r04_policy_audit.txt); the driver's box is a fresh one every round.  For ~30 seeded (shape, storage
 type) cases -- NCHW activations, token layouts, conv / linear weights, NHWC -- the backward op is timed as the policy launches it
 and with every family-forcing knob of the tools build (tools/exp_policy_audit.py in small: HIP-graph replays over rotated
-inputs); the test FAILS when a forced alternative beats the policy by more than 15 % (re-measured once before it counts: these
-are 5-100 us kernels).  It does not say the policy is optimal -- tools/exp_policy_audit.py reports at 7 % -- it catches a
+inputs); the test FAILS when a forced alternative beats the policy by more than 15 % in three paired measurements out of three (these
+are 5-100 us kernels on a shared box).  It does not say the policy is optimal -- tools/exp_policy_audit.py reports at 7 % -- it catches a
 threshold that has gone badly wrong on the box at hand."""
 import numpy as np
 import pytest
@@ -97,11 +97,15 @@ def test_no_forced_family_beats_the_policy_by_more_than_the_gate(T):
             if note in seen:
                 continue                                   # the knob changed nothing for this shape
             seen.add(note)
-            if t < base * (1.0 - GATE):                    # re-measure both before it counts
-                base2, _ = _time(T, E, op, K, None, 0)
-                t2, _ = _time(T, E, op, K, knob, v)
-                report.append("%s %s: policy %s %.1f / %.1f us, %s=%d %s %.1f / %.1f us" % (shape, dtype, base_note, base, base2, knob, v, note, t, t2))
-                if min(t, t2) < min(base, base2) * (1.0 - GATE) and t2 < base2 * (1.0 - GATE / 2):
+            if t < base * (1.0 - GATE):                    # two more PAIRED measurements before it counts: all three must agree
+                pairs = [(base, t)]
+                for _ in range(2):
+                    b_, _n = _time(T, E, op, K, None, 0)
+                    t_, _n = _time(T, E, op, K, knob, v)
+                    pairs.append((b_, t_))
+                report.append("%s %s: policy %s / %s=%d %s, us (policy, forced): %s" % (shape, dtype, base_note, knob, v, note,
+                                                                                     ", ".join("%.1f / %.1f" % p_ for p_ in pairs)))
+                if all(t_ < b_ * (1.0 - GATE) for b_, t_ in pairs):
                     behind.append(report[-1])
         del xs, gs
         torch.cuda.empty_cache()
