@@ -130,6 +130,17 @@ class _NativeWork:
         return True
 
 
+def join(group=None, device=None):
+    """The once-per-step join of the native route: the current stream of `device` waits (the host does not) for every
+    reduction begun on the library's communicator of (group, device) and for the rounding placed behind it -- call it before
+    the optimizer reads gradients that came from `sharded_backward(..., async_op=True)`.  A no-op when the group reduces
+    through torch.distributed (its Work handles are waited individually)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    comm = native_comm(group, dev, create=False)
+    if comm is not None:
+        comm.join()
+
+
 def _all_reduce_sum(t, group, async_op=False, round_to=None):
     """in-place SUM of the fp64 buffer `t` over the ranks: the one collective of a sharded backward.
     async_op on the native route: the reduction and (round_to: a dtype) the rounding of its result run on the communicator's

@@ -86,6 +86,10 @@ torch.cuda.synchronize()
 ok = ok and torch.equal(wide_c, pending[0]) and torch.equal(work_c.rounded, pending[1].rounded) and torch.equal(dx_c, dx)
 _E2.set_host_binding("native")
 print("deferred consumer: fused op == python route", ok, flush=True)
+dx_j, wide_j, work_j = D.sharded_backward(g, x, scale, shift, -8, 7, -128, 127, 1, True, 1.0, True, True, False, False, None, n, async_op=True)
+D.join(None, dev)                       # the module-level form of work.wait(): everything begun on the communicator so far
+torch.cuda.synchronize()
+ok = ok and torch.equal(work_j.rounded, pending[1].rounded)
 # the observer statistics' packed MIN all-reduce
 lo, hi = torch.tensor([-1.5, 0.25], device=dev), torch.tensor([2.0, 0.75], device=dev)
 a, b = D.all_reduce_minmax(lo, hi, None)
