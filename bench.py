@@ -327,6 +327,7 @@ def run_rank(a):
     ops_of = {"native": getattr(torch.ops, "torchlsq_native", None), "ctypes": torch.ops.torchlsq}
 
     one = {"up": False}
+    route_info = [None]        # lsq_hip_comm_info of the library's communicator, once one exists (which side stream was picked)
 
     def ensure_world_of_one():
         """an RCCL process group of ONE rank for the single-GPU `*_collective` records (every all-reduce an identity)"""
@@ -631,6 +632,11 @@ def run_rank(a):
             from torchlsq import distributed as D
             comm = D.native_comm(None, dev, create=False)
             route = "native" if comm is not None else "c10d"
+            if comm is not None:
+                try:
+                    route_info[0] = comm.info()
+                except Exception:
+                    pass
             if collective:
                 D.assume_peers(False)
             D.set_native_collective(a.collective.startswith("native"))
@@ -819,6 +825,7 @@ def run_rank(a):
                     n_small = sm["n_local"] < (1 << 23) and not mkw
                     if mkw.get("collective"):
                         rec["collective"] = sm["collective_route"]
+                        rec["communicator"] = route_info[0]
                         solo = next((r_ for r_ in sec if r_.get("workload") == "cfg4_shard" and "ms_per_step" in r_), None)
                         if solo:
                             rec["wall_over_solo_shard_step"] = round(rec["ms_per_step"] / solo["ms_per_step"], 4)

@@ -71,9 +71,33 @@ def test_default_line_has_secondary_records_declared():
     assert "cfg4_shard" in names and names.index("cfg4_shard_collective") == names.index("cfg4_shard") + 1
 
 
+def _timing_bounds(out, sec):
+    """the loose timing bounds of the default line (a shared box: the host CPU serves other tenants' jobs too, and the sharded
+    step with its collective has the most host time per step of all records -- 40-60 us -- so it is the first to go host-bound)"""
+    py, col = out["config"]["python_ctypes_host_layer"], sec["cfg4_shard_collective"]
+    problems = []
+    if not py["value"] > 0.9 * out["value"]:
+        problems.append(("ctypes layer", py["value"], out["value"]))
+    if not 0.85 < py["ctypes_over_native"] < 1.15:
+        problems.append(("ctypes / native", py["ctypes_over_native"]))
+    # typically 1.05-1.07 x the solo step for `native`, 1.02-1.04 x in stream order, 1.2 x through torch.distributed
+    if not col["ms_per_step"] <= 1.25 * sec["cfg4_shard"]["ms_per_step"]:
+        problems.append(("collective step / solo", col["ms_per_step"], sec["cfg4_shard"]["ms_per_step"], col.get("communicator")))
+    if not col["ms_per_step"] <= 1.05 * col["ms_per_step_c10d"]:
+        problems.append(("native / c10d", col["ms_per_step"], col["ms_per_step_c10d"]))
+    if not col["ms_per_step_native_inline"] <= 1.15 * sec["cfg4_shard"]["ms_per_step"]:
+        problems.append(("inline / solo", col["ms_per_step_native_inline"], sec["cfg4_shard"]["ms_per_step"]))
+    if not sec["cfg3_x50_foreach"]["step_frac"] > sec["cfg3"]["step_frac"]:
+        problems.append(("foreach", sec["cfg3_x50_foreach"]["step_frac"], sec["cfg3"]["step_frac"]))
+    if not sec["cfg1_graph"]["ms_per_step"] < sec["cfg1"]["ms_per_step"]:
+        problems.append(("graph", sec["cfg1_graph"]["ms_per_step"], sec["cfg1"]["ms_per_step"]))
+    return problems
+
+
 @pytest.mark.gpu
 def test_default_line_carries_the_per_channel_half():
-    r = _run(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-measure-traffic", "--secondary-steps", "20"])
+    args = ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-measure-traffic", "--secondary-steps", "20"]
+    r = _run(args)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     sec = {s["workload"]: s for s in out["secondary"]}
@@ -83,25 +107,25 @@ def test_default_line_carries_the_per_channel_half():
         assert "error" not in s and s["value"] > 0 and 0 < s["step_frac"] < 1, s
         assert s["launch"] == ("graph" if name.endswith("_graph") else "eager")
     assert "ms_per_step_ctypes_binding" in sec["cfg1"] and sec["cfg5_bf16"]["storage"] == "bfloat16"
-    # the headline workload through the Python / ctypes host layer north_star describes, next to the C++ binding's figure
+    # the headline workload through the Python / ctypes host layer north_star describes, next to the C++ binding's figure,
+    # measured on the timed region's own buffers with the per-op split
     py = out["config"]["python_ctypes_host_layer"]
-    assert out["config"]["host_binding"] == "native" and py["value"] > 0.9 * out["value"], (py, out["value"])
-    # ... measured on the timed region's own buffers, with the per-op split, next to the C++ binding run the same way
-    assert py["fwd_ms"] > 0 and py["bwd_ms"] > 0 and 0.85 < py["ctypes_over_native"] < 1.15, py
+    assert out["config"]["host_binding"] == "native" and py["fwd_ms"] > 0 and py["bwd_ms"] > 0, py
     # one rank's config-4 step WITH its collective (RCCL world of one told it has a peer), over the library's own communicator
     col = sec["cfg4_shard_collective"]
     assert col["collective"] == "native" and col["c10d_route_was"] == "c10d" and col["shape"] == [128, 1024, 14, 14], col
-    # (loose bounds: this is a test on a shared box, the record itself carries the numbers -- typically 1.05-1.07 x the solo step
-    #  for `native`, 1.02-1.04 x in stream order, 1.2 x through torch.distributed; host time 0.4-0.5 of the GPU time)
-    assert col["ms_per_step"] <= 1.25 * sec["cfg4_shard"]["ms_per_step"], (col["ms_per_step"], sec["cfg4_shard"]["ms_per_step"])
-    assert col["ms_per_step"] <= 1.05 * col["ms_per_step_c10d"] and col["ms_per_step_native_inline"] <= 1.15 * sec["cfg4_shard"]["ms_per_step"], col
     host = col["host_us_per_step"]
     assert min(host["shard_step_alone"], host["with_native_collective"], host["with_c10d_collective"]) > 0, host
     # BASELINE config 4's per-GPU shard: the step one rank of the 8-GPU job runs, the denominator of the 0.9x target
     assert sec["cfg4_shard"]["shape"] == [128, 1024, 14, 14] and "what" in sec["cfg4_shard"]
-    # 50 weight quantizers in one launch each way stream far better than 50 latency-bound single calls
-    assert sec["cfg3_x50_foreach"]["step_frac"] > sec["cfg3"]["step_frac"]
-    assert sec["cfg1_graph"]["ms_per_step"] < sec["cfg1"]["ms_per_step"]
+    # timing relations (20-step blocks on a shared box): one more run before they count
+    problems = _timing_bounds(out, sec)
+    if problems:
+        r2 = _run(args)
+        assert r2.returncode == 0, r2.stderr[-2000:]
+        out2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][-1])
+        again = _timing_bounds(out2, {s["workload"]: s for s in out2["secondary"]})
+        assert not again, ("twice in a row", problems, again)
 
 
 @pytest.mark.gpu
