@@ -1,0 +1,202 @@
+"""A timed parity SOAK of the shipped library (liblsq_hip.so + the C++ torch binding, no tools build, no knobs) against the CPU
+oracle at the sizes the launch policy was written for.
+
+    python3 tools/soak_parity.py --minutes 15 [--seed 1] > profiles/rNN_soak.txt
+
+tests/test_fuzz_gpu.py draws shapes of at most 600 000 elements (the oracle has to keep a test fast), where only the
+256-lane windows and the segment walk are the policy's own choice and the other families are reached by forcing them.  Here
+the draws are 0.3-24 M elements in the layouts a network produces -- NCHW / NHWC activations, token matrices, conv / linear
+weights, [B, C, L] sequences -- with awkward extents on purpose (channel counts that are no multiple of a packet, odd inner
+sizes, prime row counts, one-element-offset storage), all four storage types, all mode combinations; every case runs the
+forward and the backward through `torchlsq.functional.lsq` as a model does and is held to the bars of the parity tests (y, dx
+bit-exact; d_scale / d_shift within 1e-6 of sum|terms|).  The report counts the cases per kernel family as the plan query
+(lsq_hip_plan_backward_per_channel) names it, so that "0 mismatches" says which code it covers.  A mismatch is printed with
+everything needed to replay it (seed, case number) and the run goes on; exit code 1 if there was any.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "lsqfakequantize-pytorch_amd"))
+
+from helpers import assert_bits_equal, assert_reduction_close  # noqa: E402
+from oracle import lsq_oracle as O  # noqa: E402
+
+RANGES = [(0, 127, 0, 255), (-64, 63, -128, 127), (-128, 127, -128, 127), (0, 255, 0, 255), (-8, 7, -128, 127), (0, 15, 0, 255)]
+ODD = [3, 5, 7, 9, 11, 13, 14, 17, 19, 23, 28, 31, 49, 56]
+CH = [3, 24, 48, 64, 96, 100, 128, 160, 192, 197, 256, 320, 384, 512, 640, 768, 1000, 1024, 1280, 2048, 3072, 4096]
+ROWS = [197, 577, 1009, 1024, 3152, 4096, 6151, 8192, 12608, 16384, 16400, 25216, 32768]
+
+
+def draw_shape(rng):
+    """(shape, axis, label); 0.3-24 M elements"""
+    for _ in range(1000):
+        kind = int(rng.integers(0, 7))
+        if kind == 0:       # NCHW activation
+            hw = int(rng.choice(ODD))
+            s, ax, lab = (int(rng.choice([1, 2, 8, 16, 32, 33, 64, 128, 256])), int(rng.choice(CH)), hw, hw), 1, "nchw"
+        elif kind == 1:     # tokens x features, quantized along the features
+            s, ax, lab = (int(rng.choice(ROWS)), int(rng.choice(CH))), 1, "tokens"
+        elif kind == 2:     # [B, T, F]
+            s, ax, lab = (int(rng.choice([8, 16, 64])), int(rng.choice([49, 197, 256, 577])), int(rng.choice(CH))), 2, "btf"
+        elif kind == 3:     # conv weight, per output channel
+            k = int(rng.choice([1, 3, 5, 7]))
+            s, ax, lab = (int(rng.choice(CH)), int(rng.choice(CH)), k, k), 0, "conv-w"
+        elif kind == 4:     # linear weight, per output row
+            s, ax, lab = (int(rng.choice(CH)), int(rng.choice([576, 768, 1000, 2304, 3072, 4096, 9216]))), 0, "linear-w"
+        elif kind == 5:     # NHWC
+            hw = int(rng.choice(ODD))
+            s, ax, lab = (int(rng.choice([1, 8, 16, 32])), hw, hw, int(rng.choice(CH))), 3, "nhwc"
+        else:               # [B, C, L]
+            s, ax, lab = (int(rng.choice([4, 16, 64])), int(rng.choice(CH)), int(rng.choice([100, 1000, 1023, 4096, 16000]))), 1, "bcl"
+        n = int(np.prod(s))
+        if 300_000 <= n <= 24_000_000:
+            return s, ax, lab
+    raise RuntimeError("no shape drawn")
+
+
+def narrow_equal(got, want, x, what):
+    """16-bit storage: bit patterns, a mismatch names its first element.  A NaN matches any NaN: the payload is not part of
+    the bar (torch's own fp32 -> bf16 conversion on the CPU writes 0xffff or 0x7fc0 depending on whether the element went
+    through its vector or its scalar loop; v_cvt_pk_bf16_f32 writes 0x7fc0) -- it shows where init_mode hands a NaN of x
+    through as y."""
+    a, b = got.contiguous().view(torch.int16).reshape(-1), want.contiguous().view(torch.int16).reshape(-1)
+    if not torch.equal(a, b):
+        both_nan = torch.isnan(got.reshape(-1).float()) & torch.isnan(want.reshape(-1).float())
+        bad = torch.nonzero((a != b) & ~both_nan).reshape(-1)
+        if bad.numel() == 0:
+            return
+        i = int(bad[0])
+        raise AssertionError("%s: %d of %d elements differ; first at %d: got 0x%04x want 0x%04x (x there %r)" % (
+            what, bad.numel(), a.numel(), i, int(a[i]) & 0xffff, int(b[i]) & 0xffff, float(x.reshape(-1)[i])))
+
+
+def one_case(rng, dev, lsq, E, counts):
+    shape, axis, lab = draw_shape(rng)
+    n = int(np.prod(shape))
+    dtype = [torch.float32, torch.float32, torch.bfloat16, torch.bfloat16, torch.float16, torch.float64][int(rng.integers(0, 6))]
+    if dtype == torch.float64 and n > 6_000_000:
+        dtype = torch.float32
+    npdt = np.float64 if dtype == torch.float64 else np.float32
+    narrow = dtype in (torch.bfloat16, torch.float16)
+    per_channel = rng.random() < 0.85
+    C = shape[axis] if per_channel else 1
+    qmin, qmax, tmin, tmax = RANGES[int(rng.integers(0, len(RANGES)))]
+    affine = bool(rng.random() < 0.6) or not (qmin <= 0 <= qmax)
+    eval_mode = bool(rng.random() < 0.1)
+    init_mode = bool(rng.random() < 0.1)
+    use_gs = bool(rng.random() < 0.8)
+    gs = float(rng.choice([1.0, 0.5, 3.0]))
+    step = float(rng.choice([0.003, 0.05, 0.4]))
+    offset = bool(rng.random() < 0.12)
+    tag = "%s %s %s pc=%s axis=%d q=(%d,%d,%d,%d) affine=%s eval=%s init=%s gs=(%s,%s) offset=%s" % (
+        lab, shape, str(dtype).replace("torch.", ""), per_channel, axis, qmin, qmax, tmin, tmax, affine, eval_mode, init_mode, use_gs, gs, offset)
+
+    x = rng.standard_normal(n, dtype=np.float32).astype(npdt) * npdt(step * (qmax - qmin) * 0.4) + npdt(step * (qmax + qmin) * 0.5)
+    k = min(n, 64)
+    x[rng.integers(0, n, size=k)] = rng.choice(np.array([0.0, step * qmin, step * qmax, step * (qmin - 0.5), step * (qmax + 0.5),
+                                                         step * 0.5, -step * 0.5, np.inf, -np.inf, np.nan], dtype=npdt), size=k)
+    g = rng.standard_normal(n, dtype=np.float32).astype(npdt) * npdt(1e-2)
+    if narrow:
+        x = torch.from_numpy(x).to(dtype).to(torch.float32).numpy()
+        g = torch.from_numpy(g).to(dtype).to(torch.float32).numpy()
+    scale = (rng.uniform(0.5, 1.5, size=C) * step).astype(npdt)
+    if rng.random() < 0.3:
+        scale[int(rng.integers(0, C))] *= -1.0
+    if rng.random() < 0.1:
+        scale[int(rng.integers(0, C))] = 0.0
+    shift = (rng.standard_normal(C) * step * (2.0 if affine else 0.0)).astype(npdt)
+    xs, gsh = x.reshape(shape), g.reshape(shape)
+
+    def on_gpu(a):
+        t = torch.from_numpy(a).to(dev).to(dtype)
+        if offset:          # the same values one element into their storage: 2/4/8-byte aligned only
+            flat = torch.empty(t.numel() + 1, dtype=dtype, device=dev)[1:]
+            flat.copy_(t.reshape(-1))
+            t = flat.view(t.shape)
+        return t
+
+    xt = on_gpu(xs).requires_grad_(True)
+    gt = on_gpu(gsh)
+    st = torch.from_numpy(scale).to(dev).requires_grad_(True)
+    bt = torch.from_numpy(shift).to(dev).requires_grad_(True)
+    family = "per-tensor"
+    if per_channel:
+        plan = E.hip_plan_backward_per_channel(xt.detach(), axis, not affine, eval_mode, init_mode)
+        family = "%s/%d" % (plan["kind"], plan["block"]) + ("/ring" if plan["ring_depth"] else "")
+    counts[family] = counts.get(family, 0) + 1
+    y = lsq(xt, st, bt, qmin, qmax, tmin, tmax, axis, use_gs, gs, affine, per_channel, eval_mode, init_mode)
+    y.backward(gt)
+    torch.cuda.synchronize()
+
+    if per_channel:
+        outer, C_, inner = O.axis_to_ocl(shape, axis)
+        oy = O.fwd_pc(xs, scale, shift, outer, C_, inner, qmin, qmax, tmin, tmax, init_mode)
+        r = O.bwd_pc(gsh, xs, scale, shift, outer, C_, inner, qmin, qmax, tmin, tmax, use_gs, gs, not affine, eval_mode, init_mode)
+    else:
+        oy = O.fwd_pt(xs, scale[0], shift[0], qmin, qmax, tmin, tmax, init_mode)
+        r = O.bwd_pt(gsh, xs, scale[0], shift[0], qmin, qmax, tmin, tmax, use_gs, gs, not affine, eval_mode, init_mode)
+    tag = "[%s] %s" % (family, tag)
+    if narrow:
+        want_y = torch.from_numpy(np.ascontiguousarray(oy)).to(dtype)
+        want_dx = torch.from_numpy(np.ascontiguousarray(r.dx)).to(dtype)
+        narrow_equal(y.detach().cpu(), want_y, xs, tag + " y")
+        narrow_equal(xt.grad.cpu(), want_dx, xs, tag + " dx")
+    else:
+        assert_bits_equal(y.detach().cpu().numpy(), oy, tag + " y")
+        assert_bits_equal(xt.grad.cpu().numpy(), r.dx, tag + " dx")
+    ds = st.grad.cpu().numpy() if st.grad is not None else np.zeros(C, npdt)
+    db = bt.grad.cpu().numpy() if bt.grad is not None else np.zeros(C, npdt)
+    assert_reduction_close(ds, r.ds_wide, r.abs_ds, tag + " ds")
+    assert_reduction_close(db, r.db_wide, r.abs_db, tag + " db")
+    return n, tag
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=10.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", type=int, default=-1, help="replay: run this case number of the seed only")
+    a = ap.parse_args()
+    import torchlsq  # noqa: F401
+    from torchlsq import extension as E
+    from torchlsq.functional import lsq
+    E._assert_has_ops()
+    assert E.host_binding() == "native", "the soak is of the shipped stack: C++ binding over liblsq_hip.so"
+    dev = torch.device("cuda:0")
+    counts, failures, elements, case = {}, [], 0, 0
+    t_end = time.time() + a.minutes * 60.0
+    while time.time() < t_end:
+        rng = np.random.default_rng([a.seed, case])       # a case replays from (seed, case) alone
+        if a.only >= 0 and case != a.only:
+            case += 1
+            continue
+        try:
+            n, _tag = one_case(rng, dev, lsq, E, counts)
+            elements += n
+        except AssertionError as e:
+            failures.append("seed %d case %d: %s" % (a.seed, case, str(e)[:600]))
+            print("MISMATCH " + failures[-1], flush=True)
+        case += 1
+        if a.only >= 0:
+            break
+    print("# tools/soak_parity.py --minutes %g --seed %d on %s: the shipped library through torchlsq.functional.lsq against oracle/lsq_oracle.c"
+          % (a.minutes, a.seed, torch.cuda.get_device_name(0)))
+    print("# bars: y, dx bit-exact (16-bit storage: the fp32 result rounded to the storage type); d_scale, d_shift within 1e-6 of sum|terms|")
+    print("cases %d   elements %.3g   mismatches %d" % (case if a.only < 0 else 1, elements, len(failures)))
+    for fam in sorted(counts, key=lambda f: -counts[f]):
+        print("  %-28s %5d cases" % (fam, counts[fam]))
+    for f in failures:
+        print("MISMATCH " + f)
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
