@@ -159,10 +159,83 @@ def one_case(rng, dev, lsq, E, counts):
     return n, tag
 
 
+def side_case(rng, dev, lsq, E, counts):
+    """the ops beside the reference's four (tests/test_fuzz_gpu.py::test_random_cases_of_the_side_outputs at these sizes):
+    integer levels, the eval-mode mask + backward_from_mask, one-pass min / max (exact) and mean / std (1e-6)"""
+    ops = torch.ops.torchlsq
+    shape, axis, lab = draw_shape(rng)
+    n = int(np.prod(shape))
+    dtype = torch.float64 if (rng.random() < 0.25 and n <= 6_000_000) else torch.float32
+    npdt = np.float64 if dtype == torch.float64 else np.float32
+    per_channel = rng.random() < 0.8
+    C = shape[axis] if per_channel else 1
+    qmin, qmax, tmin, tmax = RANGES[int(rng.integers(0, len(RANGES)))]
+    step = float(rng.choice([0.003, 0.05, 0.4]))
+    offset = bool(rng.random() < 0.12)
+    tag = "[side] %s %s %s pc=%s axis=%d q=(%d,%d,%d,%d) offset=%s" % (lab, shape, str(dtype).replace("torch.", ""), per_channel, axis,
+                                                                      qmin, qmax, tmin, tmax, offset)
+    x = (rng.standard_normal(n, dtype=np.float32).astype(npdt) * npdt(step * (qmax - qmin) * 0.4) + npdt(step * (qmax + qmin) * 0.5)).reshape(shape)
+    g = (rng.standard_normal(n, dtype=np.float32).astype(npdt) * npdt(1e-2)).reshape(shape)
+    scale = (rng.uniform(0.5, 1.5, size=C) * step).astype(npdt)
+    shift = (rng.standard_normal(C) * step * 2.0).astype(npdt)
+
+    def on_gpu(a):
+        t = torch.from_numpy(a).to(dev)
+        if offset:
+            flat = torch.empty(t.numel() + 1, dtype=dtype, device=dev)[1:]
+            flat.copy_(t.reshape(-1))
+            t = flat.view(t.shape)
+        return t
+
+    xt, gt = on_gpu(x), on_gpu(g)
+    st, bt = torch.from_numpy(scale).to(dev), torch.from_numpy(shift).to(dev)
+    bias = 128 if qmax > 127 else 0
+    counts["side/" + ("per-channel" if per_channel else "per-tensor")] = counts.get("side/" + ("per-channel" if per_channel else "per-tensor"), 0) + 1
+    if per_channel:
+        outer, C_, inner = O.axis_to_ocl(shape, axis)
+        want_q = O.levels_pc(x, scale, shift, outer, C_, inner, qmin, qmax, tmin, tmax)
+        want_y = O.fwd_pc(x, scale, shift, outer, C_, inner, qmin, qmax, tmin, tmax)
+        r = O.bwd_pc(g, x, scale, shift, outer, C_, inner, qmin, qmax, tmin, tmax, True, 1.0, False, True, False)
+        y, q = ops.lsq_quantize_per_channel(xt, st, bt, axis, qmin, qmax, tmin, tmax, bias)
+        y2, mask = E.hip_forward_per_channel(xt, st, bt, axis, qmin, qmax, tmin, tmax, True, 1.0, False, True, False, want_mask=True)
+        mn, mx = ops.lsq_minmax_per_channel(xt, axis)
+        mu, sd = ops.lsq_meanstd_per_channel(xt, axis)
+        moved = np.moveaxis(x, axis, 0).reshape(C, -1)
+        want_mu, want_sd = O.meanstd(x, outer, C_, inner)
+    else:
+        want_q = O.levels_pt(x, scale[0], shift[0], qmin, qmax, tmin, tmax)
+        want_y = O.fwd_pt(x, scale[0], shift[0], qmin, qmax, tmin, tmax)
+        r = O.bwd_pt(g, x, scale[0], shift[0], qmin, qmax, tmin, tmax, True, 1.0, False, True, False)
+        y, q = ops.lsq_quantize_per_tensor(xt, st, bt, qmin, qmax, tmin, tmax, bias)
+        y2, mask = E.hip_forward_per_tensor(xt, st, bt, qmin, qmax, tmin, tmax, True, 1.0, False, True, False, want_mask=True)
+        mn, mx = ops.lsq_minmax_per_tensor(xt)
+        mu, sd = ops.lsq_meanstd_per_tensor(xt)
+        moved = x.reshape(1, -1)
+        want_mu, want_sd = O.meanstd(x, 1, 1, n)
+    assert q.dtype == torch.int8 and q.shape == xt.shape, tag + " levels type / shape"
+    assert np.array_equal(q.cpu().numpy().astype(np.int32) + bias, want_q.reshape(shape)), tag + " levels"
+    assert_bits_equal(y.cpu().numpy(), want_y, tag + " y (quantize op)")
+    assert_bits_equal(y2.cpu().numpy(), want_y, tag + " y (masked forward)")
+    dx = ops.lsq_backward_from_mask(gt, mask)
+    assert_bits_equal(dx.cpu().numpy(), r.dx, tag + " dx from mask")
+    assert np.array_equal(mn.cpu().numpy().reshape(-1), moved.min(axis=1)), tag + " min"
+    assert np.array_equal(mx.cpu().numpy().reshape(-1), moved.max(axis=1)), tag + " max"
+    rtol = 1e-12 if dtype == torch.float64 else 1e-6
+    spread = float(np.abs(moved).max()) + 1e-30
+    try:
+        np.testing.assert_allclose(mu.cpu().numpy().reshape(-1), want_mu, rtol=rtol, atol=rtol * spread, err_msg=tag + " mean")
+        np.testing.assert_allclose(sd.cpu().numpy().reshape(-1), want_sd, rtol=rtol, atol=0, equal_nan=True, err_msg=tag + " std")
+    except AssertionError as e:
+        raise AssertionError(tag + " moments: " + str(e).replace("\n", " ")[:300])
+    return n, tag
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=10.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--ops", choices=["lsq", "side"], default="lsq", help="lsq: forward + backward through functional.lsq; "
+                    "side: levels, mask backward, min / max, mean / std")
     ap.add_argument("--only", type=int, default=-1, help="replay: run this case number of the seed only")
     a = ap.parse_args()
     import torchlsq  # noqa: F401
@@ -179,7 +252,7 @@ def main():
             case += 1
             continue
         try:
-            n, _tag = one_case(rng, dev, lsq, E, counts)
+            n, _tag = (one_case if a.ops == 'lsq' else side_case)(rng, dev, lsq, E, counts)
             elements += n
         except AssertionError as e:
             failures.append("seed %d case %d: %s" % (a.seed, case, str(e)[:600]))
@@ -187,9 +260,13 @@ def main():
         case += 1
         if a.only >= 0:
             break
-    print("# tools/soak_parity.py --minutes %g --seed %d on %s: the shipped library through torchlsq.functional.lsq against oracle/lsq_oracle.c"
-          % (a.minutes, a.seed, torch.cuda.get_device_name(0)))
-    print("# bars: y, dx bit-exact (16-bit storage: the fp32 result rounded to the storage type); d_scale, d_shift within 1e-6 of sum|terms|")
+    print("# tools/soak_parity.py --minutes %g --seed %d --ops %s on %s: the shipped library %s against oracle/lsq_oracle.c"
+          % (a.minutes, a.seed, a.ops, torch.cuda.get_device_name(0),
+             "through torchlsq.functional.lsq" if a.ops == "lsq" else "(quantize ops, masked forward + backward_from_mask, observer statistics)"))
+    if a.ops == "lsq":
+        print("# bars: y, dx bit-exact (16-bit storage: the fp32 result rounded to the storage type); d_scale, d_shift within 1e-6 of sum|terms|")
+    else:
+        print("# bars: int8 levels, y, dx-from-mask, min, max exact; mean / std within 1e-6 (fp32), 1e-12 (fp64)")
     print("cases %d   elements %.3g   mismatches %d" % (case if a.only < 0 else 1, elements, len(failures)))
     for fam in sorted(counts, key=lambda f: -counts[f]):
         print("  %-28s %5d cases" % (fam, counts[fam]))
