@@ -230,12 +230,83 @@ def side_case(rng, dev, lsq, E, counts):
     return n, tag
 
 
+def foreach_case(rng, dev, lsq, E, counts):
+    """`lsq_foreach` over a random list of weight-like tensors (fusable and not, mixed shapes, one or two storage types)
+    against the same tensors through N single `lsq` calls: outputs and all three gradients bit for bit, as its docstring
+    says; the single calls are what --ops lsq holds to the oracle"""
+    from torchlsq.functional import lsq_foreach
+    n_t = int(rng.choice([2, 3, 5, 8, 31, 32, 33, 50, 70]))
+    dtypes = [[torch.float32], [torch.bfloat16], [torch.float16], [torch.float32, torch.bfloat16]][int(rng.integers(0, 4))]
+    qmin, qmax, tmin, tmax = RANGES[int(rng.integers(0, len(RANGES)))]
+    affine = bool(rng.random() < 0.5) or not (qmin <= 0 <= qmax)
+    eval_mode = bool(rng.random() < 0.1)
+    init_mode = bool(rng.random() < 0.1)
+    use_gs = bool(rng.random() < 0.8)
+    gs = float(rng.choice([1.0, 0.5, 3.0]))
+    step = 0.05
+    xs, gts, scs, shs, axes, total = [], [], [], [], [], 0
+    for _ in range(n_t):
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            k = int(rng.choice([1, 3, 5]))
+            shape, ax = (int(rng.choice([16, 24, 64, 100, 128, 256, 512])), int(rng.choice([3, 16, 64, 128, 256])), k, k), 0
+        elif kind == 1:
+            shape, ax = (int(rng.choice([10, 64, 100, 256, 768, 1000])), int(rng.choice([64, 100, 257, 576, 768, 1024, 3072]))), 0
+        elif kind == 2:     # quantized along the input features
+            shape, ax = (int(rng.choice([64, 256, 768])), int(rng.choice([64, 256, 768, 1000]))), 1
+        elif kind == 3:     # tiny
+            shape, ax = (int(rng.choice([1, 2, 8])), int(rng.choice([1, 3, 9, 27]))), 0
+        else:               # depthwise-like: short channel rows
+            shape, ax = (int(rng.choice([32, 96, 384])), 1, 3, 3), 0
+        dt = dtypes[int(rng.integers(0, len(dtypes)))]
+        n = int(np.prod(shape))
+        total += n
+        x = torch.from_numpy((rng.standard_normal(n, dtype=np.float32) * np.float32(step * (qmax - qmin) * 0.4)
+                              + np.float32(step * (qmax + qmin) * 0.5)).reshape(shape)).to(dev).to(dt)
+        g = torch.from_numpy((rng.standard_normal(n, dtype=np.float32) * np.float32(1e-2)).reshape(shape)).to(dev).to(dt)
+        C = shape[ax]
+        xs.append(x); gts.append(g); axes.append(ax)
+        scs.append(torch.from_numpy((rng.uniform(0.5, 1.5, size=C) * step).astype(np.float32)).to(dev))
+        shs.append(torch.from_numpy((rng.standard_normal(C) * step * (2.0 if affine else 0.0)).astype(np.float32)).to(dev))
+    unused = set(int(i) for i in rng.integers(0, n_t, size=int(rng.integers(0, 3))))     # outputs nobody uses: no gradient at all
+    tag = "[foreach] %d tensors %s q=(%d,%d,%d,%d) affine=%s eval=%s init=%s gs=(%s,%s) unused=%s" % (
+        n_t, "+".join(str(d).replace("torch.", "") for d in dtypes), qmin, qmax, tmin, tmax, affine, eval_mode, init_mode, use_gs, gs, sorted(unused))
+    counts["foreach/%s" % ("+".join(str(d).replace("torch.", "") for d in dtypes))] = counts.get(
+        "foreach/%s" % ("+".join(str(d).replace("torch.", "") for d in dtypes)), 0) + 1
+
+    def leaves(ts):
+        return [t.detach().clone().requires_grad_(True) for t in ts]
+
+    fused = sum(1 for i in range(n_t) if E.hip_multi_eligible(xs[i], axes[i]))
+    counts["  tensors the multi-tensor kernels take"] = counts.get("  tensors the multi-tensor kernels take", 0) + fused
+    counts["  tensors that go through single calls"] = counts.get("  tensors that go through single calls", 0) + n_t - fused
+    xa, sa, ba = leaves(xs), leaves(scs), leaves(shs)
+    ys = lsq_foreach(xa, sa, ba, qmin, qmax, tmin, tmax, axes, use_gs, gs, affine, eval_mode, init_mode)
+    live = [i for i in range(n_t) if i not in unused]
+    torch.autograd.backward([ys[i] for i in live], [gts[i] for i in live])
+    xb, sb, bb = leaves(xs), leaves(scs), leaves(shs)
+    for i in range(n_t):
+        y1 = lsq(xb[i], sb[i], bb[i], qmin, qmax, tmin, tmax, axes[i], use_gs, gs, affine, True, eval_mode, init_mode)
+        if i in live:
+            y1.backward(gts[i])
+        what = tag + " tensor %d %s axis %d" % (i, tuple(xs[i].shape), axes[i])
+        assert torch.equal(ys[i].detach().view(torch.uint8), y1.detach().view(torch.uint8)), what + " y"
+        for name, a, b in (("dx", xa[i].grad, xb[i].grad), ("d_scale", sa[i].grad, sb[i].grad), ("d_shift", ba[i].grad, bb[i].grad)):
+            assert (a is None) == (b is None), what + " %s: one route has a gradient, the other none" % name
+            if a is not None:
+                same = torch.equal(a.contiguous().view(torch.uint8), b.contiguous().view(torch.uint8)) or torch.equal(
+                    torch.nan_to_num(a.float(), nan=12345.0), torch.nan_to_num(b.float(), nan=12345.0))
+                assert same, what + " " + name
+    torch.cuda.synchronize()
+    return total, tag
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=10.0)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--ops", choices=["lsq", "side"], default="lsq", help="lsq: forward + backward through functional.lsq; "
-                    "side: levels, mask backward, min / max, mean / std")
+    ap.add_argument("--ops", choices=["lsq", "side", "foreach"], default="lsq", help="lsq: forward + backward through functional.lsq; "
+                    "side: levels, mask backward, min / max, mean / std; foreach: lsq_foreach against N single calls")
     ap.add_argument("--only", type=int, default=-1, help="replay: run this case number of the seed only")
     a = ap.parse_args()
     import torchlsq  # noqa: F401
@@ -252,7 +323,7 @@ def main():
             case += 1
             continue
         try:
-            n, _tag = (one_case if a.ops == 'lsq' else side_case)(rng, dev, lsq, E, counts)
+            n, _tag = {'lsq': one_case, 'side': side_case, 'foreach': foreach_case}[a.ops](rng, dev, lsq, E, counts)
             elements += n
         except AssertionError as e:
             failures.append("seed %d case %d: %s" % (a.seed, case, str(e)[:600]))
@@ -260,16 +331,20 @@ def main():
         case += 1
         if a.only >= 0:
             break
-    print("# tools/soak_parity.py --minutes %g --seed %d --ops %s on %s: the shipped library %s against oracle/lsq_oracle.c"
+    print("# tools/soak_parity.py --minutes %g --seed %d --ops %s on %s: the shipped library %s %s"
           % (a.minutes, a.seed, a.ops, torch.cuda.get_device_name(0),
-             "through torchlsq.functional.lsq" if a.ops == "lsq" else "(quantize ops, masked forward + backward_from_mask, observer statistics)"))
-    if a.ops == "lsq":
+             {"lsq": "through torchlsq.functional.lsq", "side": "(quantize ops, masked forward + backward_from_mask, observer statistics)",
+              "foreach": "through torchlsq.functional.lsq_foreach"}[a.ops],
+             "against N single calls" if a.ops == "foreach" else "against oracle/lsq_oracle.c"))
+    if a.ops == "foreach":
+        print("# bar: every output and gradient bit-identical to N single lsq calls (which --ops lsq holds to the oracle)")
+    elif a.ops == "lsq":
         print("# bars: y, dx bit-exact (16-bit storage: the fp32 result rounded to the storage type); d_scale, d_shift within 1e-6 of sum|terms|")
     else:
         print("# bars: int8 levels, y, dx-from-mask, min, max exact; mean / std within 1e-6 (fp32), 1e-12 (fp64)")
     print("cases %d   elements %.3g   mismatches %d" % (case if a.only < 0 else 1, elements, len(failures)))
     for fam in sorted(counts, key=lambda f: -counts[f]):
-        print("  %-28s %5d cases" % (fam, counts[fam]))
+        print("  %-40s %7d%s" % (fam, counts[fam], "" if fam.startswith("  ") else " cases"))
     for f in failures:
         print("MISMATCH " + f)
     return 1 if failures else 0
