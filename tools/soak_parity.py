@@ -301,12 +301,86 @@ def foreach_case(rng, dev, lsq, E, counts):
     return total, tag
 
 
+def shards_case(rng, dev, lsq, E, counts):
+    """The batch-sharded backward without a transport: dim 0 cut into 2-8 UNEVEN contiguous shards, every shard through
+    `sharded_backward(..., global_numel=<the whole tensor's>, reduce=False)` -- the rank-local call of
+    torchlsq.distributed, wide fp64 sums scaled with the global count -- the shards' sums added in fp64 and rounded once, as
+    the all-reduce + cast does; against the oracle on the WHOLE tensor: dx bit-exact, d_scale / d_shift inside the bar."""
+    from torchlsq import distributed as D
+    for _ in range(100):
+        shape, axis, lab = draw_shape(rng)
+        if axis != 0 and shape[0] >= 8:
+            break
+    n = int(np.prod(shape))
+    dtype = [torch.float32, torch.float32, torch.bfloat16, torch.float16][int(rng.integers(0, 4))]
+    narrow = dtype != torch.float32
+    per_channel = rng.random() < 0.8
+    C = shape[axis] if per_channel else 1
+    qmin, qmax, tmin, tmax = RANGES[int(rng.integers(0, len(RANGES)))]
+    affine = bool(rng.random() < 0.6) or not (qmin <= 0 <= qmax)
+    init_mode = bool(rng.random() < 0.1)
+    use_gs = bool(rng.random() < 0.85)
+    gs = float(rng.choice([1.0, 0.5, 3.0]))
+    step = float(rng.choice([0.003, 0.05, 0.4]))
+    k = int(rng.integers(2, 9))
+    cuts = sorted(set(int(c) for c in rng.integers(0, shape[0] + 1, size=k - 1)))        # empty shards allowed
+    bounds = [0] + cuts + [shape[0]]
+    tag = "[shards] %s %s %s pc=%s axis=%d q=(%d,%d,%d,%d) affine=%s init=%s gs=(%s,%s) rows per shard %s" % (
+        lab, shape, str(dtype).replace("torch.", ""), per_channel, axis, qmin, qmax, tmin, tmax, affine, init_mode, use_gs, gs,
+        [b - a for a, b in zip(bounds[:-1], bounds[1:])])
+    x = rng.standard_normal(n, dtype=np.float32) * np.float32(step * (qmax - qmin) * 0.4) + np.float32(step * (qmax + qmin) * 0.5)
+    g = rng.standard_normal(n, dtype=np.float32) * np.float32(1e-2)
+    if narrow:
+        x = torch.from_numpy(x).to(dtype).to(torch.float32).numpy()
+        g = torch.from_numpy(g).to(dtype).to(torch.float32).numpy()
+    xs, gsh = x.reshape(shape), g.reshape(shape)
+    scale = (rng.uniform(0.5, 1.5, size=C) * step).astype(np.float32)
+    shift = (rng.standard_normal(C) * step * (2.0 if affine else 0.0)).astype(np.float32)
+    xt, gt = torch.from_numpy(xs).to(dev).to(dtype), torch.from_numpy(gsh).to(dev).to(dtype)
+    st, bt = torch.from_numpy(scale).to(dev), torch.from_numpy(shift).to(dev)
+    counts["shards/%d" % (len(bounds) - 1)] = counts.get("shards/%d" % (len(bounds) - 1), 0) + 1
+    dxs, total = [], None
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        dx, ds_, db_ = D.sharded_backward(gt[a:b], xt[a:b], st, bt, qmin, qmax, tmin, tmax, axis, use_gs, gs, affine, per_channel,
+                                         False, init_mode, None, n, False, False)
+        dxs.append(dx)
+        # reduce=False hands back the rank-local sums ALREADY rounded to the parameter type; the transport adds fp64 sums, so
+        # take those: the same call with the wide output
+        ops = torch.ops.torchlsq_native
+        if b > a:
+            if per_channel:
+                _dx, wide = ops.lsq_backward_per_channel_wide(gt[a:b], xt[a:b], st, bt, axis, qmin, qmax, tmin, tmax, use_gs, gs,
+                                                              not affine, False, init_mode, n)
+            else:
+                _dx, wide = ops.lsq_backward_per_tensor_wide(gt[a:b], xt[a:b], st, bt, qmin, qmax, tmin, tmax, use_gs, gs,
+                                                             not affine, False, init_mode, n)
+            assert torch.equal(_dx.view(torch.uint8), dx.view(torch.uint8)), tag + " dx of the two calls"
+            total = wide.double().reshape(2, -1) if total is None else total + wide.double().reshape(2, -1)
+    ds = total[0].to(torch.float32).cpu().numpy()
+    db = total[1].to(torch.float32).cpu().numpy()
+    dx_all = torch.cat(dxs, dim=0)
+    torch.cuda.synchronize()
+    if per_channel:
+        outer, C_, inner = O.axis_to_ocl(shape, axis)
+        r = O.bwd_pc(gsh, xs, scale, shift, outer, C_, inner, qmin, qmax, tmin, tmax, use_gs, gs, not affine, False, init_mode)
+    else:
+        r = O.bwd_pt(gsh, xs, scale[0], shift[0], qmin, qmax, tmin, tmax, use_gs, gs, not affine, False, init_mode)
+    if narrow:
+        narrow_equal(dx_all.cpu(), torch.from_numpy(np.ascontiguousarray(r.dx)).to(dtype), xs, tag + " dx")
+    else:
+        assert_bits_equal(dx_all.cpu().numpy(), r.dx, tag + " dx")
+    assert_reduction_close(ds, r.ds_wide, r.abs_ds, tag + " ds")
+    assert_reduction_close(db, r.db_wide, r.abs_db, tag + " db")
+    return n, tag
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=10.0)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--ops", choices=["lsq", "side", "foreach"], default="lsq", help="lsq: forward + backward through functional.lsq; "
-                    "side: levels, mask backward, min / max, mean / std; foreach: lsq_foreach against N single calls")
+    ap.add_argument("--ops", choices=["lsq", "side", "foreach", "shards"], default="lsq", help="lsq: forward + backward through functional.lsq; "
+                    "side: levels, mask backward, min / max, mean / std; foreach: lsq_foreach against N single calls; "
+                    "shards: dim 0 cut into uneven shards, their fp64 sums added, against the oracle on the whole tensor")
     ap.add_argument("--only", type=int, default=-1, help="replay: run this case number of the seed only")
     a = ap.parse_args()
     import torchlsq  # noqa: F401
@@ -323,7 +397,7 @@ def main():
             case += 1
             continue
         try:
-            n, _tag = {'lsq': one_case, 'side': side_case, 'foreach': foreach_case}[a.ops](rng, dev, lsq, E, counts)
+            n, _tag = {'lsq': one_case, 'side': side_case, 'foreach': foreach_case, 'shards': shards_case}[a.ops](rng, dev, lsq, E, counts)
             elements += n
         except AssertionError as e:
             failures.append("seed %d case %d: %s" % (a.seed, case, str(e)[:600]))
@@ -334,10 +408,13 @@ def main():
     print("# tools/soak_parity.py --minutes %g --seed %d --ops %s on %s: the shipped library %s %s"
           % (a.minutes, a.seed, a.ops, torch.cuda.get_device_name(0),
              {"lsq": "through torchlsq.functional.lsq", "side": "(quantize ops, masked forward + backward_from_mask, observer statistics)",
-              "foreach": "through torchlsq.functional.lsq_foreach"}[a.ops],
+              "foreach": "through torchlsq.functional.lsq_foreach",
+              "shards": "through torchlsq.distributed.sharded_backward, shard by shard,"}[a.ops],
              "against N single calls" if a.ops == "foreach" else "against oracle/lsq_oracle.c"))
     if a.ops == "foreach":
         print("# bar: every output and gradient bit-identical to N single lsq calls (which --ops lsq holds to the oracle)")
+    elif a.ops == "shards":
+        print("# bars: dx of the concatenated shards bit-exact; the shards' fp64 sums, added and rounded once, within 1e-6 of sum|terms|")
     elif a.ops == "lsq":
         print("# bars: y, dx bit-exact (16-bit storage: the fp32 result rounded to the storage type); d_scale, d_shift within 1e-6 of sum|terms|")
     else:
