@@ -338,6 +338,75 @@ def run_rank(a):
         dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
         one["up"] = True
 
+    preflight = {}
+
+    def native_preflight():
+        """N > 1 (or --assume-peers), native routes: BEFORE anything is timed the library's communicator adds up a known vector
+        over the ranks -- in stream order and through begin / end -- on a stream of its own, under a host-side deadline, and the
+        ranks agree (one MIN all-reduce over torch.distributed) on whether every one of them got n (n + 1) / 2 in time.  If
+        not -- no communicator, a wrong sum, a reduction that never finishes -- every rank takes torch.distributed's route for
+        the whole run and the record says so: the first time this communicator meets real peers is a driver run nobody can
+        repeat, and a hang there would cost the whole scaling record.  (A reduction that hung stays on its own stream; the
+        process then leaves through os._exit once the line is out.)"""
+        from torchlsq import distributed as D
+        t0 = time.perf_counter()
+        ok, why, comm = 1, "", None
+        D.set_native_collective(True)
+        try:
+            if a.assume_peers:
+                ensure_world_of_one()
+                D.assume_peers(True)
+            comm = D.native_comm(None, dev)          # collective: the id over torch.distributed, the ranks' verdicts MIN-reduced
+        except Exception as e:
+            why = "communicator: %r" % (e,)
+        finally:
+            if a.assume_peers:
+                D.assume_peers(False)
+        hung = False
+        if comm is None:
+            ok, why = 0, why or "no native communicator (RCCL not resolvable, or a rank could not join)"
+        else:
+            n = comm.nranks
+            want = n * (n + 1) / 2.0
+            pre = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(pre):
+                t = torch.full((8,), float(comm.rank + 1), dtype=torch.float64, device=dev)
+                u = torch.full((3,), float(comm.rank + 1), dtype=torch.float32, device=dev)
+                comm.all_reduce(t)                   # in stream order
+                comm.end(comm.begin(u))              # on the communicator's stream, joined again
+                ev = torch.cuda.Event()
+                ev.record(pre)
+            limit = float(os.environ.get("LSQ_BENCH_PREFLIGHT_S", "30"))      # (tests: a negative limit = "it never finished")
+            deadline = time.perf_counter() + limit
+            while not ev.query() and time.perf_counter() < deadline:
+                time.sleep(0.002)
+            if limit < 0 or not ev.query():
+                ok, why, hung = 0, "a reduction of 88 bytes did not finish in time", True
+            elif not (bool((t == want).all().item()) and bool((u == want).all().item())):
+                ok, why = 0, "wrong sum: %r / %r, expected %g" % (t.tolist()[:2], u.tolist()[:2], want)
+        if os.environ.get("LSQ_BENCH_PREFLIGHT_FAIL") == "1":        # (tests: the fall-back path without a broken transport)
+            ok, why = 0, why or "LSQ_BENCH_PREFLIGHT_FAIL=1"
+        flag = torch.tensor([ok, -int(hung)], dtype=torch.int32, device=dev)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)              # torch.distributed's own communicator and stream
+        agreed, hung = int(flag[0].item()), bool(int(flag[1].item()) < 0)      # (hung anywhere: nobody tears that communicator down)
+        preflight.update(route="native" if agreed else "c10d", ok=bool(agreed), seconds=round(time.perf_counter() - t0, 3),
+                         checked="sum of rank + 1 over %d rank(s), fp64 in stream order + fp32 through begin / end"
+                                 % (comm.nranks if comm is not None else world))
+        if not agreed:
+            preflight["why"] = why or "another rank failed"
+            preflight["hung"] = hung
+            a.collective = "c10d"
+            D.set_native_collective(False)
+            if hung:
+                D._COMMS.clear()            # never destroyed: its stream holds a reduction that will not end
+            else:
+                try:
+                    D.destroy_native_comms()
+                except Exception:
+                    D._COMMS.clear()
+        return agreed
+
     def measure(workload, steps, warmup, graph=False, buffers=0, ops=ops, warm_ms=0.0, extra_blocks=0, shard_of=0, multi=0,
                 collective=None, inputs=None, shape_override=None):
         """Time `steps` steps (forward op + backward op) of one workload after `warmup` untimed ones; returns the raw
@@ -657,6 +726,10 @@ def run_rank(a):
         if world != 1 or a.workload != "cfg4_shard":
             raise SystemExit("--assume-peers is for --gpus 1 --workload cfg4_shard")
         head_kw = dict(shard_of=8, collective=a.collective)
+    if (world > 1 and a.backend == "nccl" or a.assume_peers) and a.collective.startswith("native"):
+        native_preflight()
+        if a.assume_peers:
+            head_kw["collective"] = a.collective
     m = measure(a.workload, a.steps, a.warmup, a.graph, a.buffers, warm_ms=warm_floor_ms, extra_blocks=extra_blocks, **head_kw)
     c, dtype_name, esz, per_channel, shape, axis = m["c"], m["dtype_name"], m["esz"], m["per_channel"], m["shape"], m["axis"]
     scaling, n_local, n_global, n_sets, set_bytes = m["scaling"], m["n_local"], m["n_global"], m["n_sets"], m["set_bytes"]
@@ -738,6 +811,8 @@ def run_rank(a):
         }
         if world > 1 or a.assume_peers:
             line["config"]["collective"] = m["collective_route"] + (" (" + a.collective + ")" if a.assume_peers else "")
+            if preflight:
+                line["config"]["collective_preflight"] = dict(preflight)
         if world > 1:
             # rank 0's shard step alone / the same step inside the N-rank job (barrier-bracketed, max over ranks): what the
             # collective and the co-running ranks cost one GPU.  1.0 = none.
@@ -892,7 +967,7 @@ def run_rank(a):
         chosen = a.collective
         others = {}
         for route in ("native", "native-inline", "c10d"):
-            if route == chosen:
+            if route == chosen or (route.startswith("native") and preflight and not preflight["ok"]):
                 continue
             a.collective = route
             mr = measure("cfg4", a.steps, a.warmup)
@@ -916,6 +991,8 @@ def run_rank(a):
         os.dup2(stdout_fd, 1)                  # the real stdout, for exactly one line
         print(json.dumps(line), flush=True)
         os.dup2(2, 1)
+    if preflight.get("hung"):
+        os._exit(0)                            # a reduction that never ended sits on a stream: no orderly teardown with it
     if dist.is_initialized():
         from torchlsq import distributed as D
         D.destroy_native_comms()

@@ -10,8 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
-def _run(args, timeout=900):
+def _run(args, timeout=900, extra_env=None):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(extra_env or {})
     return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=env)
 
 
@@ -162,3 +163,27 @@ def test_per_channel_workloads_report_their_kernel(workload):
     assert out["n_gpus"] == 1 and "per-channel" in out["config"]["workload"]
     assert ("bwd_seg_kernel" if workload == "cfg3" else "bwd_pc_kernel") in out["roofline"]["kernel"]
     assert out["roofline"]["traffic_source"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how", ["ok", "wrong", "hung"])
+def test_native_route_is_checked_before_anything_is_timed(how):
+    """The library's communicator meets real peers for the first time in a driver run: before the timed region it adds up a
+    known vector under a deadline and the ranks agree on the outcome; a failure sends the whole run through torch.distributed
+    and the record says why -- never a hang, never a lost line.  Here in an RCCL world of one told it has a peer; the failures
+    are simulated (an env switch; a negative deadline, with which the communicator is treated as hung: not torn down,
+    the process leaves through os._exit once the line is out)."""
+    env = {"ok": {}, "wrong": {"LSQ_BENCH_PREFLIGHT_FAIL": "1"}, "hung": {"LSQ_BENCH_PREFLIGHT_S": "-1"}}[how]
+    r = _run(["--workload", "cfg4_shard", "--assume-peers", "--steps", "60", "--warmup", "20", "--no-secondary", "--no-cpu-baseline"],
+             extra_env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-500:]
+    out = json.loads(lines[0])
+    pre = out["config"]["collective_preflight"]
+    assert out["value"] > 0
+    if how == "ok":
+        assert pre["ok"] and pre["route"] == "native" and out["config"]["collective"].startswith("native")
+    else:
+        assert not pre["ok"] and pre["route"] == "c10d" and out["config"]["collective"].startswith("c10d") and pre["why"]
+        assert pre["hung"] == (how == "hung")
