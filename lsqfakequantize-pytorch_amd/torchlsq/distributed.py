@@ -13,6 +13,7 @@ plus a reduction, so it shards by splitting dim 0 (the batch) across ranks:
 `backend="nccl"` is RCCL on ROCm builds of PyTorch; the CPU tests use gloo.
 """
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -63,7 +64,10 @@ def _group_key(group):
 
 def native_comm(group, device, create=True):
     """The HipComm of (group, device), created on first use -- a COLLECTIVE call then: every rank of the group must make its
-    first sharded call at the same point, which data-parallel training does by construction.  None = torch.distributed."""
+    first sharded call at the same point, which data-parallel training does by construction.  None = torch.distributed.
+    A communicator is only kept if it WORKS: right after creation the ranks add up rank + 1 through it under a host-side
+    deadline (TORCHLSQ_COMM_CHECK_S, 60 s) and agree on the outcome; a rank that could not create it, a wrong sum or a
+    reduction that does not finish leaves every rank on torch.distributed."""
     if not _NATIVE_COLLECTIVE[0] or not (dist.is_available() and dist.is_initialized()):
         return None
     key = (_group_key(group), device.index)
@@ -83,15 +87,32 @@ def native_comm(group, device, create=True):
         uid = torch.zeros(_E.LSQ_COMM_ID_BYTES, dtype=torch.uint8, device=device)
     src = dist.get_global_rank(group, 0) if group is not None else 0
     dist.broadcast(uid, src=src, group=group)
+    hung = 0
     if ok:
         try:
             comm = _E.HipComm(bytes(uid.cpu().numpy().tobytes()), rank, ws, device)
+            # ... and it has to WORK before anything relies on it: the ranks add up rank + 1 through it, on a stream of its
+            # own (a reduction that never ends must not sit in the caller's stream) and under a host-side deadline
+            pre = torch.cuda.Stream(device=device)
+            with torch.cuda.stream(pre):
+                probe = torch.full((2,), float(rank + 1), dtype=torch.float64, device=device)
+                comm.all_reduce(probe)
+                ev = torch.cuda.Event()
+                ev.record(pre)
+            limit = float(os.environ.get("TORCHLSQ_COMM_CHECK_S", "60"))       # (tests: a negative limit = "it never finished")
+            deadline = time.monotonic() + limit
+            while not ev.query() and time.monotonic() < deadline:
+                time.sleep(0.002)
+            if limit < 0 or not ev.query():
+                ok, hung = 0, 1
+            elif float(probe[0].item()) != ws * (ws + 1) / 2.0:
+                ok = 0
         except Exception:
             ok = 0
-    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    flag = torch.tensor([ok, -hung], dtype=torch.int32, device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) != 1:
-        if comm is not None:
+    if int(flag[0].item()) != 1:
+        if comm is not None and int(flag[1].item()) == 0:       # (hung anywhere: left alone, a teardown would wait for it too)
             try:
                 comm.destroy()
             except Exception:

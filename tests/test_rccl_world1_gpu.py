@@ -192,3 +192,45 @@ def test_sharded_path_over_rccl_world_of_one():
     r = subprocess.run([sys.executable, "-c", CODE % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert "RESULT ok" in r.stdout, r.stdout[-3000:]
+
+
+CHECK_CODE = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%(root)r, "lsqfakequantize-pytorch_amd"))
+import torch, torch.distributed as dist
+import torchlsq
+from torchlsq import distributed as D, synth
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+D.assume_peers(True)
+comm = D.native_comm(None, dev)
+assert comm is None, "a communicator whose first reduction did not finish in time must not be kept"
+assert D.native_comm(None, dev, create=False) is None
+# ... and the sharded backward goes through torch.distributed, same answer as the plain op
+n = 8 * 64 * 14 * 14
+x = synth.normal_like(n, 3, 0.3, 1.0, device=dev).view(8, 64, 14, 14)
+g = synth.normal_like(n, 4, 0.0, 1e-2, device=dev).view(8, 64, 14, 14)
+s, b = torch.tensor([0.03], device=dev), torch.tensor([0.05], device=dev)
+dx, wide, work = D.sharded_backward(g, x, s, b, 0, 127, 0, 255, global_numel=n, async_op=True)
+assert work is not None and not getattr(work, "deferred", False), "the native route must be off"
+work.wait()
+dx1, ds1, db1 = D.sharded_backward(g, x, s, b, 0, 127, 0, 255, global_numel=n, reduce=False)
+assert torch.equal(dx, dx1) and torch.equal(wide[0].to(torch.float32).reshape(-1), ds1.reshape(-1))
+print("FALLBACK_OK", flush=True)
+os._exit(0)         # (the communicator that "hung" was left alone on purpose: no teardown)
+'''
+
+
+def test_a_communicator_that_fails_its_first_reduction_is_not_kept():
+    """native_comm() checks the communicator before anything relies on it (the ranks add up rank + 1 under a deadline and
+    agree); here the deadline is negative -- "it never finished" -- and the path must end on torch.distributed"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", TORCHLSQ_COMM_CHECK_S="-1")
+    r = subprocess.run([sys.executable, "-c", CHECK_CODE % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
