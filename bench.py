@@ -342,7 +342,7 @@ def run_rank(a):
 
     def native_preflight():
         """N > 1 (or --assume-peers), native routes: BEFORE anything is timed the library's communicator adds up a known vector
-        over the ranks -- in stream order and through begin / end -- on a stream of its own, under a host-side deadline, and the
+        over the ranks -- fp64 and fp32, in stream order -- on a stream of its own, under a host-side deadline, and the
         ranks agree (one MIN all-reduce over torch.distributed) on whether every one of them got n (n + 1) / 2 in time.  If
         not -- no communicator, a wrong sum, a reduction that never finishes -- every rank takes torch.distributed's route for
         the whole run and the record says so: the first time this communicator meets real peers is a driver run nobody can
@@ -372,8 +372,8 @@ def run_rank(a):
             with torch.cuda.stream(pre):
                 t = torch.full((8,), float(comm.rank + 1), dtype=torch.float64, device=dev)
                 u = torch.full((3,), float(comm.rank + 1), dtype=torch.float32, device=dev)
-                comm.all_reduce(t)                   # in stream order
-                comm.end(comm.begin(u))              # on the communicator's stream, joined again
+                comm.all_reduce(t)                   # both in stream order: begin() would choose the communicator's side stream
+                comm.all_reduce(u)                   # against THIS stream -- that choice belongs to the stream the steps run on
                 ev = torch.cuda.Event()
                 ev.record(pre)
             limit = float(os.environ.get("LSQ_BENCH_PREFLIGHT_S", "30"))      # (tests: a negative limit = "it never finished")
@@ -391,7 +391,7 @@ def run_rank(a):
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)              # torch.distributed's own communicator and stream
         agreed, hung = int(flag[0].item()), bool(int(flag[1].item()) < 0)      # (hung anywhere: nobody tears that communicator down)
         preflight.update(route="native" if agreed else "c10d", ok=bool(agreed), seconds=round(time.perf_counter() - t0, 3),
-                         checked="sum of rank + 1 over %d rank(s), fp64 in stream order + fp32 through begin / end"
+                         checked="sum of rank + 1 over %d rank(s), fp64 and fp32, in stream order on a stream of its own"
                                  % (comm.nranks if comm is not None else world))
         if not agreed:
             preflight["why"] = why or "another rank failed"
