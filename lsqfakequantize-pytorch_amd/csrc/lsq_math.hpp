@@ -227,6 +227,7 @@ struct io_f32 {
     __device__ static __forceinline__ float load1(const void* p, int64_t i) { return static_cast<const float*>(p)[i]; }
     __device__ static __forceinline__ void store1(void* p, int64_t i, float v) { static_cast<float*>(p)[i] = v; }
     __device__ static __forceinline__ float to_elem(float v) { return v; }
+    __device__ static __forceinline__ float passthrough(float v) { return v; }
 };
 struct io_f64 {
     using elem = double;
@@ -235,6 +236,7 @@ struct io_f64 {
     __device__ static __forceinline__ double load1(const void* p, int64_t i) { return static_cast<const double*>(p)[i]; }
     __device__ static __forceinline__ void store1(void* p, int64_t i, double v) { static_cast<double*>(p)[i] = v; }
     __device__ static __forceinline__ double to_elem(double v) { return v; }
+    __device__ static __forceinline__ double passthrough(double v) { return v; }
 };
 struct io_bf16 {
     using elem = __bf16;
@@ -244,6 +246,14 @@ struct io_bf16 {
         return static_cast<float>(static_cast<const __bf16*>(p)[i]);
     }
     __device__ static __forceinline__ __bf16 to_elem(float v) { return static_cast<__bf16>(v); }  // RNE (v_cvt_pk_bf16_f32)
+    // v == float(some bf16): its storage bits are the high half of v's -- NaN payload and sign included, where the rounding
+    // conversion writes the canonical NaN
+    __device__ static __forceinline__ __bf16 passthrough(float v) {
+        const unsigned short h = static_cast<unsigned short>(__float_as_uint(v) >> 16);
+        __bf16 out;
+        __builtin_memcpy(&out, &h, 2);
+        return out;
+    }
     __device__ static __forceinline__ void store1(void* p, int64_t i, float v) { static_cast<__bf16*>(p)[i] = to_elem(v); }
 };
 struct io_f16 {
@@ -261,7 +271,20 @@ struct io_f16 {
         return static_cast<_Float16>(v);
     }
     __device__ static __forceinline__ void store1(void* p, int64_t i, float v) { static_cast<_Float16*>(p)[i] = to_elem(v); }
+    __device__ static __forceinline__ _Float16 passthrough(float v) { return to_elem(v); }   // exact for v == float(some fp16); a quiet NaN keeps sign and payload
 };
+
+// init_mode hands values through (lsq_kernel.h:9 y = x; :112 / :140 dX = grad): EXACT = the value in hand IS a storage value
+// converted to the arithmetic type, and goes back as its bits -- not through the rounding conversion.
+template <typename IO, bool EXACT>
+__device__ __forceinline__ typename IO::elem out_elem(typename IO::arith v) {
+    if constexpr (EXACT) return IO::passthrough(v);
+    else return IO::to_elem(v);
+}
+template <typename IO, bool EXACT>
+__device__ __forceinline__ void store_out(void* p, int64_t i, typename IO::arith v) {
+    static_cast<typename IO::elem*>(p)[i] = out_elem<IO, EXACT>(v);
+}
 
 // A 16-byte packet of IO::VEC storage elements, moved with one global_load/store_dwordx4.
 template <typename IO>

@@ -326,8 +326,8 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
                 const f2 xv = f2{static_cast<T>(in[2 * pr]), static_cast<T>(in[2 * pr + 1])};
                 f2 c;
                 const f2 yv = forward_pair(xv, qp[pr], r, c);
-                out[2 * pr] = IO::to_elem(INIT ? xv.x : yv.x);
-                out[2 * pr + 1] = IO::to_elem(INIT ? xv.y : yv.y);
+                out[2 * pr] = out_elem<IO, INIT>(INIT ? xv.x : yv.x);
+                out[2 * pr + 1] = out_elem<IO, INIT>(INIT ? xv.y : yv.y);
                 if (LEVELS) {
                     lv.b[2 * pr] = aux_byte<T>(c.x, r, bias, aux_kind);
                     lv.b[2 * pr + 1] = aux_byte<T>(c.y, r, bias, aux_kind);
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
                 const QParams<T> q = ch.params(j);
                 const T xv = static_cast<T>(in[j]);
                 const T c = clamped<T>(xv, q, r);
-                out[j] = IO::to_elem(INIT ? xv : dequant<T>(rne(c), q));
+                out[j] = out_elem<IO, INIT>(INIT ? xv : dequant<T>(rne(c), q));
                 if (LEVELS) lv.b[j] = aux_byte<T>(c, r, bias, aux_kind);
             }
         }
@@ -687,8 +687,8 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
                         }
                     }
                 }
-                out[2 * pr] = IO::to_elem(dxv.x);
-                out[2 * pr + 1] = IO::to_elem(dxv.y);
+                out[2 * pr] = out_elem<IO, INIT>(dxv.x);                   // (init_mode: dX IS the gradient, :112)
+                out[2 * pr + 1] = out_elem<IO, INIT>(dxv.y);
             }
         } else {
 #pragma unroll
@@ -696,10 +696,10 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
                 const QParams<T> q = ch.params(j);
                 const T gv = static_cast<T>(gi[j]), xv = static_cast<T>(xi[j]);
                 if (EVAL) {
-                    out[j] = IO::to_elem(backward_elem_eval<T, INIT>(gv, xv, q, r));
+                    out[j] = out_elem<IO, INIT>(backward_elem_eval<T, INIT>(gv, xv, q, r));
                 } else {
                     T ds_t, db_t;
-                    out[j] = IO::to_elem(backward_elem<T, SYM, INIT>(gv, xv, q, r, grad_scaler, ds_t, db_t));
+                    out[j] = out_elem<IO, INIT>(backward_elem<T, SYM, INIT>(gv, xv, q, r, grad_scaler, ds_t, db_t));
                     if (!valid) { ds_t = static_cast<T>(0); db_t = static_cast<T>(0); }
                     const double a = static_cast<double>(ds_t), c = static_cast<double>(db_t);
                     acc_s[j < kAcc ? j : 0] += a;

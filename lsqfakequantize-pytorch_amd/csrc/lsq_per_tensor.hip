@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void fwd_pt_kernel(const void* __restrict__
         for (int j = 0; j < VEC; ++j) {
             const T xv = static_cast<T>(in.v[j]);
             const T c = clamped<T>(xv, q, r);
-            out.v[j] = IO::to_elem(INIT ? xv : dequant<T>(rne(c), q));  // lsq_kernel.h:13
+            out.v[j] = out_elem<IO, INIT>(INIT ? xv : dequant<T>(rne(c), q));  // lsq_kernel.h:13
             if (LEVELS) lv.b[j] = aux_byte<T>(c, r, bias, aux_kind);
         }
         if (!LEVELS || y != nullptr) {     // y == NULL: only the one-byte output is wanted (include/lsq_hip.h, lsq_fwd_extras)
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void fwd_pt_kernel(const void* __restrict__
         if (i < n) {
             const T xv = IO::load1(x, i);
             const T c = clamped<T>(xv, q, r);
-            if (!LEVELS || y != nullptr) IO::store1(y, i, INIT ? xv : dequant<T>(rne(c), q));
+            if (!LEVELS || y != nullptr) store_out<IO, INIT>(y, i, INIT ? xv : dequant<T>(rne(c), q));
             if (LEVELS) levels[i] = aux_byte<T>(c, r, bias, aux_kind);
         }
     }
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void fwd_pt_scalar_kernel(const void* __res
          i += static_cast<int64_t>(gridDim.x) * kBlock) {
         const T xv = IO::load1(x, i);
         const T c = clamped<T>(xv, q, r);
-        if (!LEVELS || y != nullptr) IO::store1(y, i, INIT ? xv : dequant<T>(rne(c), q));
+        if (!LEVELS || y != nullptr) store_out<IO, INIT>(y, i, INIT ? xv : dequant<T>(rne(c), q));
         if (LEVELS) levels[i] = aux_byte<T>(c, r, bias, aux_kind);
     }
 }
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void bwd_pt_kernel(const void* __restrict__
         Packet<IO> out;
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
-            out.v[j] = IO::to_elem(
+            out.v[j] = out_elem<IO, INIT>(          // (init_mode: dX IS the gradient, lsq_kernel.h:112)
                 acc.step(static_cast<T>(gi.v[j]), static_cast<T>(xi.v[j]), q, r, grad_scaler));
         if (NTS) store_packet_nt<IO>(dx, p * VEC, out); else store_packet<IO>(dx, p * VEC, out);
     };
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void bwd_pt_kernel(const void* __restrict__
     }
     if (blockIdx.x == 0) {
         const int64_t i = n_packets * VEC + threadIdx.x;
-        if (i < n) IO::store1(dx, i, acc.step(IO::load1(grad, i), IO::load1(x, i), q, r, grad_scaler));
+        if (i < n) store_out<IO, INIT>(dx, i, acc.step(IO::load1(grad, i), IO::load1(x, i), q, r, grad_scaler));
     }
     if (EVAL) eval_store_zero<T>(fold);
     else block_reduce_store<T>(acc.s, acc.b, partials, fold);
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void bwd_pt_scalar_kernel(const void* __res
     BwdAcc<T, SYM, INIT, EVAL> acc;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * kBlock)
-        IO::store1(dx, i, acc.step(IO::load1(grad, i), IO::load1(x, i), q, r, grad_scaler));
+        store_out<IO, INIT>(dx, i, acc.step(IO::load1(grad, i), IO::load1(x, i), q, r, grad_scaler));
     if (EVAL) eval_store_zero<T>(fold);
     else block_reduce_store<T>(acc.s, acc.b, partials, fold);
 }

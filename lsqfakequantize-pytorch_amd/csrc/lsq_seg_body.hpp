@@ -68,7 +68,7 @@ __device__ __forceinline__ void seg_forward(const void* __restrict__ x, void* __
         for (int j = 0; j < V; ++j) {
             const T xv = static_cast<T>(in[j]);
             const T c = clamped<T>(xv, q, r);
-            out[j] = IO::to_elem(INIT ? xv : dequant<T>(rne(c), q));
+            out[j] = out_elem<IO, INIT>(INIT ? xv : dequant<T>(rne(c), q));
             if (LEVELS) lv.b[j] = aux_byte<T>(c, r, bias, aux_kind);
         }
         if (valid) {
@@ -151,10 +151,10 @@ __device__ __forceinline__ void seg_backward(const void* __restrict__ grad, cons
         for (int j = 0; j < V; ++j) {
             const T gv = static_cast<T>(gi[j]), xv = static_cast<T>(xi[j]);
             if (EVAL) {
-                out[j] = IO::to_elem(backward_elem_eval<T, INIT>(gv, xv, q, r));
+                out[j] = out_elem<IO, INIT>(backward_elem_eval<T, INIT>(gv, xv, q, r));
             } else {
                 T ds_t, db_t;
-                out[j] = IO::to_elem(backward_elem<T, SYM, INIT>(gv, xv, q, r, grad_scaler, ds_t, db_t));
+                out[j] = out_elem<IO, INIT>(backward_elem<T, SYM, INIT>(gv, xv, q, r, grad_scaler, ds_t, db_t));
                 if (!valid) { ds_t = static_cast<T>(0); db_t = static_cast<T>(0); }
                 acc_s += static_cast<double>(ds_t);
                 if (!SYM) acc_b += static_cast<double>(db_t);

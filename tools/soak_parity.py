@@ -65,8 +65,8 @@ def draw_shape(rng):
 def narrow_equal(got, want, x, what):
     """16-bit storage: bit patterns, a mismatch names its first element.  A NaN matches any NaN: the payload is not part of
     the bar (torch's own fp32 -> bf16 conversion on the CPU writes 0xffff or 0x7fc0 depending on whether the element went
-    through its vector or its scalar loop; v_cvt_pk_bf16_f32 writes 0x7fc0) -- it shows where init_mode hands a NaN of x
-    through as y."""
+    through its vector or its scalar loop), which is where the EXPECTED bits of a NaN come from here.  That init_mode hands
+    the storage bits of x through, NaN payloads included, is tests/test_init_passthrough_gpu.py's business."""
     a, b = got.contiguous().view(torch.int16).reshape(-1), want.contiguous().view(torch.int16).reshape(-1)
     if not torch.equal(a, b):
         both_nan = torch.isnan(got.reshape(-1).float()) & torch.isnan(want.reshape(-1).float())
