@@ -618,7 +618,8 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
     //  * the terms of up to kPreRows consecutive rows are first added per component in fp32 (one packed add for two
     //    components), then the pre-sum joins the fp64 accumulator -- a convert and an fp64 add per kPreRows
     //    terms instead of per term; at most kPreRows - 1 fp32 roundings per pre-sum, <= 1.8e-7 of the sum of the |terms|
-    //    in the worst case, ~1e-9 typically;
+    //    in the worst case, ~1e-9 typically (range: a pre-sum overflows where four terms of one sign exceed FLT_MAX together --
+    //    gradient x level products around 1e38, where the fp32 terms themselves are about to);
     //  * the gradient scaler multiplies the fp64 sums once (backward_elem<.., RAW>) instead of every term.
     constexpr bool PRE32 = DMA > 0 && sizeof(E) < 4 && !EVAL;
     static_assert(!PRE32 || PAIRS, "16-bit storage on the ring moves packets of 8");
