@@ -78,7 +78,11 @@ def narrow_equal(got, want, x, what):
             what, bad.numel(), a.numel(), i, int(a[i]) & 0xffff, int(b[i]) & 0xffff, float(x.reshape(-1)[i])))
 
 
+EXTREME = [0.0]
+
+
 def one_case(rng, dev, lsq, E, counts):
+    extreme = rng.random() < EXTREME[0]
     shape, axis, lab = draw_shape(rng)
     n = int(np.prod(shape))
     dtype = [torch.float32, torch.float32, torch.bfloat16, torch.bfloat16, torch.float16, torch.float64][int(rng.integers(0, 6))]
@@ -113,6 +117,18 @@ def one_case(rng, dev, lsq, E, counts):
     if rng.random() < 0.1:
         scale[int(rng.integers(0, C))] = 0.0
     shift = (rng.standard_normal(C) * step * (2.0 if affine else 0.0)).astype(npdt)
+    if extreme:         # --extreme: parameters and gradients no training run should see, a share of the cases
+        what = int(rng.integers(0, 3))
+        with np.errstate(over="ignore"):
+            if what == 0:
+                scale[int(rng.integers(0, C))] = npdt(rng.choice([1e-40, 1e30, np.inf, np.nan, 1e-30]))
+            elif what == 1 and affine:
+                shift[int(rng.integers(0, C))] = npdt(rng.choice([np.inf, -np.inf, np.nan, 1e30, -1e30]))
+            else:
+                g[rng.integers(0, n, size=8)] = rng.choice(np.array([np.inf, -np.inf, np.nan, 1e30, -1e30], dtype=npdt), size=8)
+                if narrow:
+                    g = torch.from_numpy(g).to(dtype).to(torch.float32).numpy()
+        tag += " extreme=%d" % what
     xs, gsh = x.reshape(shape), g.reshape(shape)
 
     def on_gpu(a):
@@ -382,6 +398,8 @@ def main():
                     "side: levels, mask backward, min / max, mean / std; foreach: lsq_foreach against N single calls; "
                     "shards: dim 0 cut into uneven shards, their fp64 sums added, against the oracle on the whole tensor")
     ap.add_argument("--only", type=int, default=-1, help="replay: run this case number of the seed only")
+    ap.add_argument("--extreme", type=float, default=0.0, help="--ops lsq: share of the cases with a subnormal / huge / inf / NaN scale, "
+                    "an inf / NaN shift or inf / NaN / 1e30 gradients")
     a = ap.parse_args()
     import torchlsq  # noqa: F401
     from torchlsq import extension as E
@@ -389,6 +407,7 @@ def main():
     E._assert_has_ops()
     assert E.host_binding() == "native", "the soak is of the shipped stack: C++ binding over liblsq_hip.so"
     dev = torch.device("cuda:0")
+    EXTREME[0] = a.extreme
     counts, failures, elements, case = {}, [], 0, 0
     t_end = time.time() + a.minutes * 60.0
     while time.time() < t_end:
@@ -405,8 +424,8 @@ def main():
         case += 1
         if a.only >= 0:
             break
-    print("# tools/soak_parity.py --minutes %g --seed %d --ops %s on %s: the shipped library %s %s"
-          % (a.minutes, a.seed, a.ops, torch.cuda.get_device_name(0),
+    print("# tools/soak_parity.py --minutes %g --seed %d --ops %s%s on %s: the shipped library %s %s"
+          % (a.minutes, a.seed, a.ops, " --extreme %g" % a.extreme if a.extreme else "", torch.cuda.get_device_name(0),
              {"lsq": "through torchlsq.functional.lsq", "side": "(quantize ops, masked forward + backward_from_mask, observer statistics)",
               "foreach": "through torchlsq.functional.lsq_foreach",
               "shards": "through torchlsq.distributed.sharded_backward, shard by shard,"}[a.ops],
