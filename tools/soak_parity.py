@@ -79,14 +79,76 @@ def narrow_equal(got, want, x, what):
 
 
 EXTREME = [0.0]
+AGAINST = ["oracle"]
+REF = [None]          # --against reference: the worker process that runs the reference's own CPU ops
+
+
+def ref_worker():
+    """`--ref-worker` (started by --against reference): the REFERENCE's CPU ops -- oracle/_ref/libtorchlsq_ref_ops.so, its four
+    CPU translation units built where they lie by oracle/build_ref.py and shipped with the snapshot -- in a process of their
+    own (the library registers the same torchlsq::* names as the product).  One request per line on stdin: a directory with
+    x / g / scale / shift as .npy and the arguments as JSON; y / dx / d_scale / d_shift go back into it."""
+    import json
+    so = os.path.join(ROOT, "oracle", "_ref", "libtorchlsq_ref_ops.so")
+    torch.ops.load_library(so)
+    ref = torch.ops.torchlsq
+    print("ready", flush=True)
+    for line in sys.stdin:
+        d = line.strip()
+        if not d:
+            break
+        try:
+            a = json.load(open(os.path.join(d, "args.json")))
+            x = torch.from_numpy(np.load(os.path.join(d, "x.npy"))).requires_grad_(True)
+            g = torch.from_numpy(np.load(os.path.join(d, "g.npy")))
+            sc = torch.from_numpy(np.load(os.path.join(d, "scale.npy"))).requires_grad_(True)
+            sh = torch.from_numpy(np.load(os.path.join(d, "shift.npy"))).requires_grad_(True)
+            y = ref.lsq(x, sc, sh, a["qmin"], a["qmax"], a["tmin"], a["tmax"], a["axis"], a["use_gs"], a["gs"], a["affine"],
+                        a["per_channel"], a["eval_mode"], a["init_mode"])
+            y.backward(g)
+            np.save(os.path.join(d, "y.npy"), y.detach().numpy())
+            np.save(os.path.join(d, "dx.npy"), x.grad.numpy())
+            np.save(os.path.join(d, "ds.npy"), sc.grad.numpy() if sc.grad is not None else np.zeros(0))
+            np.save(os.path.join(d, "db.npy"), sh.grad.numpy() if sh.grad is not None else np.zeros(0))
+            print("ok", flush=True)
+        except Exception as e:          # the reference's own TORCH_CHECKs included
+            print("error " + repr(e).replace("\n", " ")[:300], flush=True)
+
+
+def ref_call(xs, gsh, scale, shift, args):
+    """(y, dx, ds, db) of the reference's CPU ops for these inputs, through the worker"""
+    import json
+    import shutil
+    import subprocess
+    import tempfile
+    if REF[0] is None:
+        env = {k: v for k, v in os.environ.items() if not k.startswith("HIP_") and k != "ROCR_VISIBLE_DEVICES"}
+        REF[0] = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--ref-worker"], stdin=subprocess.PIPE,
+                                  stdout=subprocess.PIPE, text=True, env=env)
+        assert REF[0].stdout.readline().strip() == "ready", "the reference worker did not start (oracle/_ref missing?)"
+    d = tempfile.mkdtemp(prefix="lsqsoak", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        for name, arr in (("x", xs), ("g", gsh), ("scale", scale), ("shift", shift)):
+            np.save(os.path.join(d, name + ".npy"), np.ascontiguousarray(arr))
+        json.dump(args, open(os.path.join(d, "args.json"), "w"))
+        REF[0].stdin.write(d + "\n")
+        REF[0].stdin.flush()
+        reply = REF[0].stdout.readline().strip()
+        assert reply == "ok", "reference worker: " + reply
+        return tuple(np.load(os.path.join(d, n + ".npy")) for n in ("y", "dx", "ds", "db"))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def one_case(rng, dev, lsq, E, counts):
     extreme = rng.random() < EXTREME[0]
+    against_ref = AGAINST[0] == "reference"
     shape, axis, lab = draw_shape(rng)
     n = int(np.prod(shape))
     dtype = [torch.float32, torch.float32, torch.bfloat16, torch.bfloat16, torch.float16, torch.float64][int(rng.integers(0, 6))]
     if dtype == torch.float64 and n > 6_000_000:
+        dtype = torch.float32
+    if against_ref and dtype in (torch.bfloat16, torch.float16):      # the reference's CPU ops: AT_DISPATCH_FLOATING_TYPES
         dtype = torch.float32
     npdt = np.float64 if dtype == torch.float64 else np.float32
     narrow = dtype in (torch.bfloat16, torch.float16)
@@ -160,6 +222,22 @@ def one_case(rng, dev, lsq, E, counts):
         oy = O.fwd_pt(xs, scale[0], shift[0], qmin, qmax, tmin, tmax, init_mode)
         r = O.bwd_pt(gsh, xs, scale[0], shift[0], qmin, qmax, tmin, tmax, use_gs, gs, not affine, eval_mode, init_mode)
     tag = "[%s] %s" % (family, tag)
+    if against_ref:
+        # the same inputs through the reference's own CPU ops: y, dx bit for bit; d_scale / d_shift inside the bar, with the
+        # oracle's sum|terms| as the yardstick (the reference does not report one)
+        ry, rdx, rds, rdb = ref_call(xs, gsh, scale, shift, dict(qmin=qmin, qmax=qmax, tmin=tmin, tmax=tmax, axis=axis, use_gs=use_gs, gs=gs,
+                                                                 affine=affine, per_channel=per_channel, eval_mode=eval_mode, init_mode=init_mode))
+        assert_bits_equal(y.detach().cpu().numpy(), ry, tag + " y vs the reference")
+        assert_bits_equal(xt.grad.cpu().numpy(), rdx, tag + " dx vs the reference")
+        assert_bits_equal(oy, ry, tag + " ORACLE y vs the reference")
+        assert_bits_equal(r.dx, rdx, tag + " ORACLE dx vs the reference")
+        ds = st.grad.cpu().numpy() if st.grad is not None else np.zeros(C, npdt)
+        db = bt.grad.cpu().numpy() if bt.grad is not None else np.zeros(C, npdt)
+        if rds.size == C:
+            assert_reduction_close(ds, rds, r.abs_ds, tag + " ds vs the reference")
+        if rdb.size == C:
+            assert_reduction_close(db, rdb, r.abs_db, tag + " db vs the reference")
+        return n, tag
     if narrow:
         want_y = torch.from_numpy(np.ascontiguousarray(oy)).to(dtype)
         want_dx = torch.from_numpy(np.ascontiguousarray(r.dx)).to(dtype)
@@ -398,9 +476,15 @@ def main():
                     "side: levels, mask backward, min / max, mean / std; foreach: lsq_foreach against N single calls; "
                     "shards: dim 0 cut into uneven shards, their fp64 sums added, against the oracle on the whole tensor")
     ap.add_argument("--only", type=int, default=-1, help="replay: run this case number of the seed only")
+    ap.add_argument("--against", choices=["oracle", "reference"], default="oracle", help="--ops lsq: reference = the reference's own CPU "
+                    "ops (oracle/_ref/libtorchlsq_ref_ops.so, in a worker process; fp32 / fp64 storage only)")
+    ap.add_argument("--ref-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--extreme", type=float, default=0.0, help="--ops lsq: share of the cases with a subnormal / huge / inf / NaN scale, "
                     "an inf / NaN shift or inf / NaN / 1e30 gradients")
     a = ap.parse_args()
+    if a.ref_worker:
+        return ref_worker()
+    AGAINST[0] = a.against
     import torchlsq  # noqa: F401
     from torchlsq import extension as E
     from torchlsq.functional import lsq
@@ -424,12 +508,17 @@ def main():
         case += 1
         if a.only >= 0:
             break
+    if REF[0] is not None:
+        REF[0].stdin.close()
+        REF[0].wait(timeout=60)
     print("# tools/soak_parity.py --minutes %g --seed %d --ops %s%s on %s: the shipped library %s %s"
           % (a.minutes, a.seed, a.ops, " --extreme %g" % a.extreme if a.extreme else "", torch.cuda.get_device_name(0),
              {"lsq": "through torchlsq.functional.lsq", "side": "(quantize ops, masked forward + backward_from_mask, observer statistics)",
               "foreach": "through torchlsq.functional.lsq_foreach",
               "shards": "through torchlsq.distributed.sharded_backward, shard by shard,"}[a.ops],
-             "against N single calls" if a.ops == "foreach" else "against oracle/lsq_oracle.c"))
+             "against N single calls" if a.ops == "foreach" else
+             ("against the REFERENCE's CPU ops (oracle/_ref/libtorchlsq_ref_ops.so) -- and the oracle against them" if a.against == "reference"
+              else "against oracle/lsq_oracle.c")))
     if a.ops == "foreach":
         print("# bar: every output and gradient bit-identical to N single lsq calls (which --ops lsq holds to the oracle)")
     elif a.ops == "shards":
