@@ -1743,13 +1743,24 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
                 // end, 8.4-11 M elements, it is -1 .. -8 % on nine shapes of twelve and +9 / +14 % on two with power-of-two row
                 // counts ([8192,1024], [4096,2048]), with a third of the partial rows (profiles/r04_ww_big_low_end.txt): the
                 // lower end stays at 2^23.
+                // Round 5, after the epilogue's combine went over all lanes (the fat workgroup's own cost): BELOW 2^23 elements it
+                // now leads wherever a row is at most 96 lanes -- every shape of [rows, 128 .. 768] bf16 from 3 M elements on
+                // (+4 .. +19 %: [8192,384] 14.2 -> 12.5 us, [10000,768] 20.6 -> 16.8, [12608,256] +8 %), and from 0.8 M on where
+                // the row does not tile a 256-lane workgroup (48, 80, 96 lanes: [2048,384] +8 %, [4096,640] +12 %, [3152,768]
+                // +14 %; rows of 16 / 32 / 64 lanes are -10 .. +2 % there and keep their four-wave workgroups); rows of 128+ lanes
+                // stay as they were ([4096,1024], [2048,2048] -5 %).  One row tile per workgroup is enough down there.
+                // profiles/r05_ww_big_small_tensors.txt
                 const bool fits = sizeof(typename IO::elem) < 4;
-                const bool use_big = big == 1 || (big == 0 && c.default_variant && c.C / V <= kBlock && c.C / V >= 64 && fits &&
-                                                  elems >= (int64_t{1} << 23) && elems < (int64_t{5} << 24));
+                const int64_t w_lanes = c.C / V;
+                const bool low = elems < (int64_t{1} << 23);
+                const bool low_ok = w_lanes >= 1 && w_lanes <= 96 && (elems >= (int64_t{3} << 20) ||
+                                                      (elems >= (int64_t{3} << 18) && kBlock % static_cast<int>(w_lanes) != 0));
+                const bool use_big = big == 1 || (big == 0 && c.default_variant && w_lanes <= kBlock && fits &&
+                                                  (low ? low_ok : (w_lanes >= 64 && elems < (int64_t{5} << 24))));
                 constexpr int kBigBlock = kBigBlockOf<sizeof(typename IO::elem)>;
                 if (use_big &&
                     run(bwd_pc_kernel<IO, V, CPL, SYM, INIT, EVAL, 1, true, true, false, WW, kDmaDepth, kBigBlock>, kDmaDepth,
-                        device_info().cu_count, big == 1 ? 0 : 2, INT64_MAX, kBigBlock))
+                        device_info().cu_count, (big == 1 || low) ? 0 : 2, INT64_MAX, kBigBlock))
                     return result;
             }
             // The tiles-per-workgroup floor of the ring (as many as it is deep) does not hold for 16-bit row groups: there the

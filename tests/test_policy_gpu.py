@@ -134,24 +134,38 @@ def test_owner_windows_band(T, dtype):
 
 
 def test_big_row_group_workgroups_band(T):
-    """16-bit storage: one 768-lane workgroup per CU for last-axis tensors of 2^23 .. 5 * 2^24 elements whose rows fit one window
-    and are at least 64 lanes wide ([rows,64] loses 11-16 % with it, profiles/r04_rowgroup_mid.txt); fp32 never (register loops
-    or the usual ring are level or ahead at every size on the round-4 box)"""
+    """16-bit storage: one 768-lane workgroup per CU for last-axis tensors whose rows fit one window --
+    2^23 .. 5 * 2^24 elements: rows of at least 64 lanes ([rows,64] loses 11-16 % with it, profiles/r04_rowgroup_mid.txt);
+    below 2^23 (round 5, profiles/r05_ww_big_small_tensors.txt): rows of at most 96 lanes, from 3 M elements on, and from
+    0.8 M on where the row does not tile a 256-lane workgroup (48, 80, 96 lanes);
+    fp32 never (register loops or the usual ring are level or ahead at every size on the round-4 box)"""
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    is_big = lambda note: note["block"] > 256 and note["grid_x"] * note["grid_y"] == cus    # one fat workgroup per CU
+    is_fat = lambda note: note["block"] > 256                                               # noqa: E731
+    is_big = lambda note: is_fat(note) and note["grid_x"] * note["grid_y"] == cus           # noqa: E731  (one per CU)
     dtype = torch.bfloat16
-    lo, hi = _rows(1 << 23, 768)
-    (_, a), (_, b) = _case(T, (lo, 768), 1, dtype), _case(T, (hi, 768), 1, dtype)
-    assert not is_big(a) and is_big(b), (a, b)
+    lo, hi = _rows(1 << 23, 1024)                  # rows of 128 lanes: the band begins at 2^23
+    (_, a), (_, b) = _case(T, (lo, 1024), 1, dtype), _case(T, (hi, 1024), 1, dtype)
+    assert not is_fat(a) and is_big(b), (a, b)
     assert b["block"] <= 768
     lo, hi = _rows(5 << 24, 768)                   # the upper end of the band
     (_, a), (_, b) = _case(T, (lo, 768), 1, dtype), _case(T, (hi, 768), 1, dtype)
-    assert is_big(a) and not is_big(b), (a, b)
-    # narrow rows (32 lanes): the usual workgroups, on the ring
+    assert is_big(a) and not is_fat(b), (a, b)
+    # narrow rows (32 lanes) inside the band: the usual workgroups, on the ring
     (_, c) = _case(T, ((1 << 24) // 256, 256), 1, dtype)
-    assert not is_big(c) and c["kind"] == "row-groups" and c["ring_depth"] == 4, c
+    assert not is_fat(c) and c["kind"] == "row-groups" and c["ring_depth"] == 4, c
     (_, d) = _case(T, ((1 << 24) // 768, 768), 1, torch.float32)
-    assert not is_big(d) and d["kind"] == "row-groups", d
+    assert not is_fat(d) and d["kind"] == "row-groups", d
+    # below 2^23 elements
+    for shape, fat in (((3152, 768), True), ((10000, 768), True), ((512, 768), False),         # 96 lanes: from 0.8 M
+                       ((8192, 384), True), ((2048, 384), True), ((1024, 384), False),        # 48 lanes: from 0.8 M
+                       ((8192, 512), True), ((2048, 512), False),                             # 64 lanes tile the workgroup: from 3 M
+                       ((12608, 256), True), ((4096, 256), False),                            # 32 lanes: from 3 M
+                       ((4096, 1024), False), ((2048, 2048), False)):                         # 128+ lanes: never down here
+        for dt in (torch.bfloat16, torch.float16):
+            (_, n) = _case(T, shape, 1, dt)
+            assert is_fat(n) == fat and n["kind"] == "row-groups" and n["ring_depth"] == 4, (shape, dt, n)
+        (_, n) = _case(T, shape, 1, torch.float32)
+        assert not is_fat(n), (shape, n)
 
 
 def test_row_group_ring_by_storage_type(T):
