@@ -135,7 +135,8 @@ def test_owner_windows_band(T, dtype):
 
 def test_big_row_group_workgroups_band(T):
     """16-bit storage: one 768-lane workgroup per CU for last-axis tensors whose rows fit one window --
-    2^23 .. 5 * 2^24 elements: rows of at least 64 lanes ([rows,64] loses 11-16 % with it, profiles/r04_rowgroup_mid.txt);
+    2^23 .. 5 * 2^24 elements: rows of at least 64 lanes, narrower ones up to 5 * 2^22 elements or where they do not tile a
+    256-lane workgroup (round 5; round 4 had [rows,64] 11-16 % behind with it, before the combine went over all lanes);
     below 2^23 (round 5, profiles/r05_ww_big_small_tensors.txt): rows of at most 96 lanes, from 3 M elements on, and from
     0.8 M on where the row does not tile a 256-lane workgroup (48, 80, 96 lanes);
     fp32 never (register loops or the usual ring are level or ahead at every size on the round-4 box)"""
@@ -150,9 +151,14 @@ def test_big_row_group_workgroups_band(T):
     lo, hi = _rows(5 << 24, 768)                   # the upper end of the band
     (_, a), (_, b) = _case(T, (lo, 768), 1, dtype), _case(T, (hi, 768), 1, dtype)
     assert is_big(a) and not is_fat(b), (a, b)
-    # narrow rows (32 lanes) inside the band: the usual workgroups, on the ring
-    (_, c) = _case(T, ((1 << 24) // 256, 256), 1, dtype)
+    # narrow rows (32 lanes) inside the band: fat up to 5 * 2^22 elements, the usual workgroups (on the ring) above; rows that
+    # do not tile a 256-lane workgroup (48 lanes): fat through the whole band
+    lo, hi = _rows(5 << 22, 256)
+    (_, c0), (_, c) = _case(T, (lo, 256), 1, dtype), _case(T, (hi, 256), 1, dtype)
+    assert is_big(c0), c0
     assert not is_fat(c) and c["kind"] == "row-groups" and c["ring_depth"] == 4, c
+    (_, c1) = _case(T, ((3 << 24) // 384, 384), 1, dtype)
+    assert is_big(c1), c1
     (_, d) = _case(T, ((1 << 24) // 768, 768), 1, torch.float32)
     assert not is_fat(d) and d["kind"] == "row-groups", d
     # below 2^23 elements
