@@ -341,12 +341,14 @@ def run_rank(a):
     preflight = {}
 
     def native_preflight():
-        """N > 1 (or --assume-peers), native routes: BEFORE anything is timed the library's communicator adds up a known vector
-        over the ranks -- fp64 and fp32, in stream order -- on a stream of its own, under a host-side deadline, and the
-        ranks agree (one MIN all-reduce over torch.distributed) on whether every one of them got n (n + 1) / 2 in time.  If
-        not -- no communicator, a wrong sum, a reduction that never finishes -- every rank takes torch.distributed's route for
-        the whole run and the record says so: the first time this communicator meets real peers is a driver run nobody can
-        repeat, and a hang there would cost the whole scaling record.  (A reduction that hung stays on its own stream; the
+        """N > 1 (or --assume-peers), native routes: BEFORE anything is timed the library's communicator is created and CHECKED
+        (torchlsq.distributed.native_comm: every rank agrees at every step of the creation; the ranks add up rank + 1 under a
+        host-side deadline; then the very route that will be timed -- begin on the communicator's stream, a consumer behind it
+        there, one join -- carries 128 reductions of changing values, first with events that skip the system-scope fence, with
+        fenced events if any rank saw a wrong value), and this run repeats the route check on the stream its steps run on.  If
+        anything fails -- no communicator, a wrong sum, a reduction that never finishes -- every rank takes torch.distributed's
+        route for the whole run and the record says so: the first time this communicator meets real peers is a driver run nobody
+        can repeat, and a hang there would cost the whole scaling record.  (A reduction that hung stays on its own stream; the
         process then leaves through os._exit once the line is out.)"""
         from torchlsq import distributed as D
         t0 = time.perf_counter()
@@ -356,7 +358,7 @@ def run_rank(a):
             if a.assume_peers:
                 ensure_world_of_one()
                 D.assume_peers(True)
-            comm = D.native_comm(None, dev)          # collective: the id over torch.distributed, the ranks' verdicts MIN-reduced
+            comm = D.native_comm(None, dev)          # collective: the id over torch.distributed, every verdict MIN-reduced
         except Exception as e:
             why = "communicator: %r" % (e,)
         finally:
@@ -364,26 +366,18 @@ def run_rank(a):
                 D.assume_peers(False)
         hung = False
         if comm is None:
-            ok, why = 0, why or "no native communicator (RCCL not resolvable, or a rank could not join)"
+            ok, why = 0, why or D.LAST_FAILURE.get("why") or "no native communicator (RCCL not resolvable, or a rank could not join)"
+            hung = bool(D.LAST_FAILURE.get("hung"))
         else:
-            n = comm.nranks
-            want = n * (n + 1) / 2.0
-            pre = torch.cuda.Stream(device=dev)
-            with torch.cuda.stream(pre):
-                t = torch.full((8,), float(comm.rank + 1), dtype=torch.float64, device=dev)
-                u = torch.full((3,), float(comm.rank + 1), dtype=torch.float32, device=dev)
-                comm.all_reduce(t)                   # both in stream order: begin() would choose the communicator's side stream
-                comm.all_reduce(u)                   # against THIS stream -- that choice belongs to the stream the steps run on
-                ev = torch.cuda.Event()
-                ev.record(pre)
             limit = float(os.environ.get("LSQ_BENCH_PREFLIGHT_S", "30"))      # (tests: a negative limit = "it never finished")
-            deadline = time.perf_counter() + limit
-            while not ev.query() and time.perf_counter() < deadline:
-                time.sleep(0.002)
-            if limit < 0 or not ev.query():
-                ok, why, hung = 0, "a reduction of 88 bytes did not finish in time", True
-            elif not (bool((t == want).all().item()) and bool((u == want).all().item())):
-                ok, why = 0, "wrong sum: %r / %r, expected %g" % (t.tolist()[:2], u.tolist()[:2], want)
+            try:
+                bad = D.check_timed_route(comm, dev, limit)      # the timed route, on the stream the steps will run on
+            except Exception as e:
+                bad = "route check: %r" % (e,)
+            if bad == "hung":
+                ok, why, hung = 0, "a reduction of 24 bytes on the timed route did not finish in time", True
+            elif bad:
+                ok, why = 0, bad
         if os.environ.get("LSQ_BENCH_PREFLIGHT_FAIL") == "1":        # (tests: the fall-back path without a broken transport)
             ok, why = 0, why or "LSQ_BENCH_PREFLIGHT_FAIL=1"
         flag = torch.tensor([ok, -int(hung)], dtype=torch.int32, device=dev)
@@ -391,8 +385,11 @@ def run_rank(a):
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)              # torch.distributed's own communicator and stream
         agreed, hung = int(flag[0].item()), bool(int(flag[1].item()) < 0)      # (hung anywhere: nobody tears that communicator down)
         preflight.update(route="native" if agreed else "c10d", ok=bool(agreed), seconds=round(time.perf_counter() - t0, 3),
-                         checked="sum of rank + 1 over %d rank(s), fp64 and fp32, in stream order on a stream of its own"
-                                 % (comm.nranks if comm is not None else world))
+                         checked="sum of rank + 1 over %d rank(s) in stream order, then %d reductions of changing values through the "
+                                 "TIMED route (begin on the communicator's stream, consumer behind it, join), at creation and again on "
+                                 "the stream the steps run on" % (comm.nranks if comm is not None else world, D.ROUTE_CHECK_REDUCTIONS))
+        if comm is not None and comm.checked:
+            preflight["events"] = comm.checked.get("events")
         if not agreed:
             preflight["why"] = why or "another rank failed"
             preflight["hung"] = hung
@@ -407,8 +404,122 @@ def run_rank(a):
                     D._COMMS.clear()
         return agreed
 
+    _shard_digests = {}
+
+    def shard_digests():
+        """tests/golden/shard_digests.json (made by tests/golden/make_golden.py --shards from the reference's CPU ops): what every
+        rank of a batch-sharded run of config 4 / weak-scaled config 2 must hold"""
+        if not _shard_digests:
+            try:
+                with open(os.path.join(ROOT, "tests", "golden", "shard_digests.json")) as f:
+                    _shard_digests.update(json.load(f)["shards"])
+            except Exception as e:
+                _shard_digests["error"] = repr(e)
+        return _shard_digests
+
+    def verify_sharded(reduced, workload, c, dt, shape, x0, g0, scale, shift, per_channel, axis, tail, n_scaler, ops, fwd_of, shard_of, route):
+        """What the timed region's LAST step reduced, proven twice (every rank runs this; the verdicts are MIN-agreed):
+
+        collective_verified -- the reduced [sum ds, sum db] against the ranks' own contributions, recomputed here with the same
+          kernel (lsq_backward_*_wide, the global element count in the scaler: bit-reproducible) and carried by an independent
+          transport: torch.distributed's all_gather, added up in rank order in fp64.  The two differ only in the ORDER the N
+          doubles were added: |reduced - gathered| <= 1e-12 * sum_r |contribution_r| (a rounded fp32 result of the in-order route:
+          + one fp32 rounding).  The ranks hold different data (their own slices), so a stale, dropped or doubled contribution
+          cannot cancel out.
+        parity_vs_reference -- where tests/golden/shard_digests.json has the workload (BASELINE config 4 at 2 / 4 / 8 ranks and
+          its 1/8 shard; weak-scaled config 2 at 2 / 4 / 8): each rank's y and dx by sha256 against the reference CPU csrc's
+          outputs for its slice (bit-exact), each rank's contribution and the reduced sums against the reference's d_scale /
+          d_shift on the concatenated tensor, |got - ref| <= 1e-6 * sum|terms| (north_star's bar; the contract is
+          lsq_cpu.cpp:103-104,138-139 on the whole batch)."""
+        import hashlib
+        C = scale.numel() if per_channel else 1
+        if reduced[0] == "wide":
+            red = reduced[1].detach().to(torch.float64).reshape(2, -1).clone()
+            rounded = False
+        else:
+            red = torch.stack([reduced[1].detach().reshape(-1), reduced[2].detach().reshape(-1)]).to(torch.float64)
+            rounded = True
+        if os.environ.get("LSQ_BENCH_CORRUPT_REDUCED") == "1":          # (tests: a wrong sum must show as ok: false, and still print)
+            red = red * (1.0 + 1e-3)
+        if per_channel:
+            dx_l, wide_l = ops.lsq_backward_per_channel_wide(g0, x0, scale, shift, axis, *tail, n_scaler)
+            y_l = fwd_of(x0, scale, shift, axis, *tail)
+        else:
+            dx_l, wide_l = ops.lsq_backward_per_tensor_wide(g0, x0, scale, shift, *tail, n_scaler)
+            y_l = fwd_of(x0, scale, shift, *tail)
+        mine = wide_l.detach().to(torch.float64).reshape(2, -1)
+        real_world = dist.get_world_size() if dist.is_initialized() else 1
+        if real_world > 1:
+            parts = [torch.zeros_like(mine) for _ in range(real_world)]
+            dist.all_gather(parts, mine.contiguous())
+        else:
+            parts = [mine]
+        total = torch.zeros_like(mine)
+        mag = torch.zeros_like(mine)
+        for p_ in parts:                       # rank order, fp64
+            total = total + p_
+            mag = mag + p_.abs()
+        tol = 1e-12 * mag + (1.2e-7 * total.abs() if rounded else 0.0) + 1e-300
+        err = (red - total).abs()
+        ok_col = bool((err <= tol).all().item())
+        worst = int(torch.argmax(err / tol).item())
+        col = {"ok": ok_col, "route": route, "ranks": real_world, "what": "the last timed step's reduced [sum ds, sum db] vs the ranks' own "
+               "contributions (recomputed, bit-reproducible kernel) all-gathered over torch.distributed and added in rank order",
+               "tolerance": "1e-12 * sum_r |contribution_r|" + (" + 1 fp32 rounding (the in-order route returns rounded sums)" if rounded else ""),
+               "max_err_over_tol": float((err / tol).max().item()),
+               "reduced": [float(red[0].reshape(-1)[worst % red.shape[1]].item()), float(red[1].reshape(-1)[worst % red.shape[1]].item())],
+               "gathered": [float(total[0].reshape(-1)[worst % red.shape[1]].item()), float(total[1].reshape(-1)[worst % red.shape[1]].item())],
+               "slots": int(red.numel()), "distinct_data_per_rank": real_world > 1}
+        # ---- against the reference's outputs for this rank's slice
+        par = {"ok": None, "why": "no reference digests for this workload / world size (tests/golden/shard_digests.json holds BASELINE config 4 "
+                                  "at 2, 4, 8 ranks and weak-scaled config 2 at 2, 4, 8)"}
+        sd = shard_digests()
+        key, nw = None, shard_of
+        if dt == torch.float32 and "error" not in sd:
+            if workload in ("cfg4", "cfg4_shard") and str(nw) in sd.get("cfg4", {}).get("by_world", {}):
+                key = "cfg4"
+            elif workload == "cfg2" and str(nw) in sd.get("cfg2_weak", {}).get("by_world", {}):
+                key = "cfg2_weak"
+        if key is not None:
+            bw = sd[key]["by_world"][str(nw)]
+            exp = bw["shards"][rank]
+            exp_sha = exp if key == "cfg4" else sd[key]["shards"][rank]
+            ysha = hashlib.sha256(memoryview(y_l.detach().cpu().contiguous().numpy()).cast("B")).hexdigest()
+            dxsha = hashlib.sha256(memoryview(dx_l.detach().cpu().contiguous().numpy()).cast("B")).hexdigest()
+            sha_ok = ysha == exp_sha["y_sha256"] and dxsha == exp_sha["dx_sha256"]
+            m_ds, m_db = float(mine[0, 0].item()), float(mine[1, 0].item())
+            mine_ok = abs(m_ds - exp["ds_wide"]) <= 1e-6 * exp["abs_ds"] and abs(m_db - exp["db_wide"]) <= 1e-6 * exp["abs_db"]
+            if key == "cfg4":
+                ref_ds, ref_db = sd[key]["ds"][0], sd[key]["db"][0]
+                ref_is = "the reference CPU csrc's d_scale / d_shift on the whole [1024,1024,14,14] tensor"
+            else:
+                ref_ds, ref_db = bw["sum_ds_wide"], bw["sum_db_wide"]
+                ref_is = "the sum of the ranks' contributions from the pinned oracle run with the global count (the reference's terms)"
+            if real_world == nw:
+                red_ok = abs(float(red[0, 0].item()) - ref_ds) <= 1e-6 * bw["abs_ds"] and abs(float(red[1, 0].item()) - ref_db) <= 1e-6 * bw["abs_db"]
+                red_note = {"reduced": [float(red[0, 0].item()), float(red[1, 0].item())], "reference": [ref_ds, ref_db],
+                            "budget_1e-6_sum_abs_terms": [1e-6 * bw["abs_ds"], 1e-6 * bw["abs_db"]], "reference_is": ref_is}
+            else:           # a world of one told it has peers: the "sum" is this rank's own contribution
+                red_ok, red_note = True, {"reduced": "n/a: %d real rank(s) of %d -- only this rank's contribution is checked" % (real_world, nw)}
+            flags = torch.tensor([int(sha_ok), int(mine_ok), int(red_ok)], dtype=torch.int32, device=dev)
+            if real_world > 1:
+                dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+            f = [bool(v) for v in flags.tolist()]
+            par = {"ok": all(f), "digests": "tests/golden/shard_digests.json[%s][by_world][%d]" % (key, nw),
+                   "y_dx_sha256_all_ranks_match_reference_slices": f[0], "each_rank_contribution_within_1e-6_sum_abs_terms": f[1],
+                   "reduced_within_1e-6_sum_abs_terms": f[2], "ranks_checked": real_world}
+            par.update(red_note)
+            if rank == 0 and not f[0]:
+                par["rank0_sha"] = {"y": ysha, "dx": dxsha, "expected_y": exp_sha["y_sha256"], "expected_dx": exp_sha["dx_sha256"]}
+        flag = torch.tensor([int(ok_col)], dtype=torch.int32, device=dev)
+        if real_world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        col["ok"] = bool(int(flag.item()))
+        del y_l, dx_l
+        return {"collective_verified": col, "parity_vs_reference": par}
+
     def measure(workload, steps, warmup, graph=False, buffers=0, ops=ops, warm_ms=0.0, extra_blocks=0, shard_of=0, multi=0,
-                collective=None, inputs=None, shape_override=None):
+                collective=None, inputs=None, shape_override=None, event_every=0):
         """Time `steps` steps (forward op + backward op) of one workload after `warmup` untimed ones; returns the raw
         measurements (K-step wall time bracketed by barrier + synchronize, max over ranks; per-op HIP-event times).
         shard_of = R (single rank only): the step ONE rank of an R-rank job runs on this shape -- the `*_wide` backward with
@@ -444,7 +555,13 @@ def run_rank(a):
             xs_in, gs_in, scale, shift = inputs
             x, g = xs_in[0], gs_in[0]
         else:
-            x, g, scale, shift = synth.make_inputs(c, device=dev, dtype=dt, shape=shape)
+            # N > 1: rank r holds ITS slice of the batch -- rows [r * rows, (r + 1) * rows) of the global tensor (config 4: of
+            # [1024,1024,14,14]; the weak-scaled workloads: of a virtual tensor N times the per-GPU shape), the same bits that
+            # slice of the whole tensor has (synth.make_inputs(first_index)); the ranks do NOT hold copies of one shard
+            n_shard = 1
+            for d_ in shape:
+                n_shard *= d_
+            x, g, scale, shift = synth.make_inputs(c, device=dev, dtype=dt, shape=shape, first_index=rank * n_shard if world > 1 else 0)
         n_local = x.numel()
         # Small workloads re-using one set of buffers are partly served by the 256 MB Infinity Cache (config 5 streams 308 MB per
         # step in fp32, 154 MB in bf16), which is not the HBM rate the roofline is about: the steps rotate through `n_sets`
@@ -501,6 +618,7 @@ def run_rank(a):
             return op_fwd_pt(xs[cur[0]], scale, shift, *tail)
 
         pending = []   # N > 1: the previous step's in-flight all-reduce (RCCL runs it on its own stream)
+        last_reduced = [None]   # what the LAST sharded backward's collective produced: ("wide", fp64 [2, C]) or ("rounded", ds, db)
 
         def bwd():
             if multi:
@@ -509,12 +627,15 @@ def run_rank(a):
                 return extension.hip_backward_per_channel_multi(gs[bset()], xs[bset()], scales, shifts, axes, *tail)
             if collective:      # ... and WITH it: the N > 1 branch below, in a world of one told it has peers
                 if collective == "native-inline":       # the reduction in stream order, right behind the backward's kernels
-                    return sharded_backward(gs[bset()], xs[bset()], scale, shift, *q, axis, True, 1.0, c["affine"], per_channel, False, False,
-                                            None, n_scaler)
+                    r3 = sharded_backward(gs[bset()], xs[bset()], scale, shift, *q, axis, True, 1.0, c["affine"], per_channel, False, False,
+                                          None, n_scaler)
+                    last_reduced[0] = ("rounded", r3[1], r3[2])
+                    return r3
                 dx, wide, work = sharded_backward(gs[bset()], xs[bset()], scale, shift, *q, axis, True, 1.0, c["affine"], per_channel, False, False,
                                                   None, n_scaler, async_op=True)
                 drain()
                 pending.append((wide, work))
+                last_reduced[0] = ("wide", wide)
                 return dx
             if shard_of:        # one rank's step of a shard_of-rank job: everything but the collective itself
                 if per_channel:
@@ -535,12 +656,15 @@ def run_rank(a):
             # consumed one step later (d_scale/d_shift are only needed by the optimizer), so its latency
             # hides behind the next step's kernels; every reduction is completed inside the timed region.
             if a.collective == "native-inline":
-                return sharded_backward(gs[bset()], xs[bset()], scale, shift, *q, axis, True, 1.0, c["affine"], per_channel, False, False,
-                                        None, n_global)
+                r3 = sharded_backward(gs[bset()], xs[bset()], scale, shift, *q, axis, True, 1.0, c["affine"], per_channel, False, False,
+                                      None, n_global)
+                last_reduced[0] = ("rounded", r3[1], r3[2])
+                return r3
             dx, wide, work = sharded_backward(gs[bset()], xs[bset()], scale, shift, *q, axis, True, 1.0, c["affine"], per_channel, False, False,
                                               None, n_global, async_op=True)
             drain()
             pending.append((wide, work))
+            last_reduced[0] = ("wide", wide)
             return dx
 
         last_native = [None]
@@ -635,7 +759,7 @@ def run_rank(a):
         # would cost a few % of a 0.7 ms step, and three records on every fourth step -- the earlier rule -- still cost the
         # host-bound 20 us workloads about a tenth of their step.  Under --graph the ops are nodes of one graph launch, so
         # the per-op split comes from a second, un-timed pass of eager launches.)
-        stride = max(1, steps // 10)
+        stride = event_every if event_every > 0 else max(1, steps // 10)     # (event_every: the sustained record samples 1 % of its steps)
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] if i % stride == 0 else None for i in range(steps)]
         if world > 1:
             dist.barrier()
@@ -710,7 +834,18 @@ def run_rank(a):
                 D.assume_peers(False)
             D.set_native_collective(a.collective.startswith("native"))
 
-        return dict(workload=workload, c=c, dtype_name=dtype_name, esz=esz, per_channel=per_channel, shape=shape, axis=axis,
+        verified = None
+        if (collective or world > 1) and last_reduced[0] is not None:
+            try:
+                verified = verify_sharded(last_reduced[0], workload, c, dt, shape, xs[0], gs[0], scale, shift, per_channel, axis, tail,
+                                          n_scaler if collective else n_global, ops, fwd_of=(op_fwd_pc if per_channel else op_fwd_pt),
+                                          shard_of=shard_of if collective else world, route=route)
+            except Exception as e:      # every rank takes the same path; the line must come out either way
+                import traceback
+                traceback.print_exc()
+                verified = {"collective_verified": {"ok": False, "error": repr(e)}, "parity_vs_reference": {"ok": False, "error": repr(e)}}
+
+        return dict(workload=workload, c=c, dtype_name=dtype_name, esz=esz, per_channel=per_channel, shape=shape, axis=axis, verified=verified,
                     scaling=scaling, n_local=n_local, n_global=n_global, n_sets=n_sets, set_bytes=set_bytes, steps=steps,
                     warmup=warmup, elapsed_max=elapsed_max, fwd_ms=fwd_ms, bwd_ms=bwd_ms, fwd_avg=fwd_avg, bwd_avg=bwd_avg,
                     xs=xs, gs=gs, x=x, scale=scale, shift=shift, solo_ms=solo_ms, block_times=block_times, graph=bool(graph),
@@ -813,6 +948,11 @@ def run_rank(a):
             line["config"]["collective"] = m["collective_route"] + (" (" + a.collective + ")" if a.assume_peers else "")
             if preflight:
                 line["config"]["collective_preflight"] = dict(preflight)
+            if m.get("verified"):
+                line["config"]["collective_verified"] = m["verified"]["collective_verified"]
+                line["parity_vs_reference"] = m["verified"]["parity_vs_reference"]
+            if route_info[0]:
+                line["config"]["communicator"] = route_info[0]
         if world > 1:
             # rank 0's shard step alone / the same step inside the N-rank job (barrier-bracketed, max over ranks): what the
             # collective and the co-running ranks cost one GPU.  1.0 = none.
@@ -840,6 +980,36 @@ def run_rank(a):
                 del scratch
             except Exception as e:      # context only: never let it break the bench line
                 line["roofline"]["same_box_reference_kernels"] = {"error": repr(e)}
+        sustained = None
+        if world == 1 and a.workload == "cfg2" and not a.graph and not a.no_secondary and not (a.variant_fwd or a.variant_bwd):
+            # The headline region is K steps (the driver's K = 20: 13 ms).  The SAME step, on the same buffers, for at least a
+            # second, HIP events on 1 % of the steps: the sustained figure next to the burst.  DESIGN.md section 5 says which of
+            # the two the 70 % claim rests on (both must clear it).
+            try:
+                per = elapsed_max / m["steps"]
+                sus_steps = int(min(6000, max(300, -(-1.05 // per)))) // 100 * 100
+                sm = measure("cfg2", sus_steps, 0, inputs=(m["xs"], m["gs"], m["scale"], m["shift"]), event_every=100)
+                s_wall = sm["elapsed_max"] / sm["steps"]
+                s_bwd = bytes_bwd * n_local / (sm["bwd_avg"] * 1e-3) / 1e9
+                s_fwd = bytes_fwd * n_local / (sm["fwd_avg"] * 1e-3) / 1e9
+                s_step = (bytes_fwd + bytes_bwd) * n_local / ((sm["fwd_avg"] + sm["bwd_avg"]) * 1e-3) / 1e9
+                sustained = {"workload": "cfg2_sustained", "shape": sm["shape"], "storage": sm["dtype_name"], "steps": sm["steps"],
+                             "wall_s": round(sm["elapsed_max"], 4), "value": round(n_local / s_wall / 1e9, 3), "unit": "GElem/s",
+                             "ms_per_step": round(s_wall * 1e3, 5), "fwd_ms": round(sm["fwd_avg"], 5), "bwd_ms": round(sm["bwd_avg"], 5),
+                             "bwd_frac": round(s_bwd / HBM_PEAK_GBS, 4), "fwd_frac": round(s_fwd / HBM_PEAK_GBS, 4),
+                             "step_frac": round(s_step / HBM_PEAK_GBS, 4),
+                             "step_frac_wall": round((bytes_fwd + bytes_bwd) * n_local / s_wall / 1e9 / HBM_PEAK_GBS, 4),
+                             "events_on_steps": len(sm["bwd_ms"]), "launch": "eager", "host_binding": binding,
+                             "what": "the headline step for >= 1 s on the headline's own buffers, HIP events on every 100th step"}
+                line["roofline"]["sustained"] = {"achieved": round(s_bwd, 1), "frac": round(s_bwd / HBM_PEAK_GBS, 4),
+                                                 "avg_launch_ms": round(sm["bwd_avg"], 5), "launches_timed": len(sm["bwd_ms"]),
+                                                 "step_frac": round(s_step / HBM_PEAK_GBS, 4), "step_frac_wall": sustained["step_frac_wall"],
+                                                 "steps": sm["steps"], "wall_s": sustained["wall_s"], "value": sustained["value"]}
+                line["roofline"]["burst_vs_sustained"] = ("`frac` / `step_frac` above: the K timed steps of `value` (a burst when K is small); "
+                                                          "`sustained`: the same step for >= 1 s -- the 70 % target is claimed on the LOWER of the two")
+                del sm
+            except Exception as e:      # context only
+                sustained = {"workload": "cfg2_sustained", "error": repr(e)}
         if world == 1 and binding == "native" and not a.graph and not a.no_secondary:
             # north_star describes Python host code over the thin C ABI; the timed region above ran the C++ host binding (same C
             # entry points, less host time per call).  The same workload through the Python / ctypes host layer, 20 steps:
@@ -901,6 +1071,9 @@ def run_rank(a):
                     if mkw.get("collective"):
                         rec["collective"] = sm["collective_route"]
                         rec["communicator"] = route_info[0]
+                        if sm.get("verified"):
+                            rec["collective_verified"] = sm["verified"]["collective_verified"]
+                            rec["parity_vs_reference"] = sm["verified"]["parity_vs_reference"]
                         solo = next((r_ for r_ in sec if r_.get("workload") == "cfg4_shard" and "ms_per_step" in r_), None)
                         if solo:
                             rec["wall_over_solo_shard_step"] = round(rec["ms_per_step"] / solo["ms_per_step"], 4)
@@ -941,6 +1114,8 @@ def run_rank(a):
                     sec.append(rec)
                 except Exception as e:      # never let a secondary record break the headline line
                     sec.append({"workload": extra.get("name", w), "error": repr(e)})
+            if sustained is not None:
+                sec.insert(0, sustained)
             line["secondary"] = sec
             line["secondary_wall_s"] = round(time.perf_counter() - t_sec, 2)
     strong = None
@@ -962,6 +1137,9 @@ def run_rank(a):
                           "rank0_shard_alone_ms_per_step": round(m4["solo_ms"], 5),
                           "per_gpu_efficiency": round(m4["solo_ms"] / (t4 * 1e3), 4), "input_buffer_sets": m4["n_sets"],
                           "collective": m4["collective_route"], "launch": "eager"}
+                if m4.get("verified"):
+                    strong["collective_verified"] = m4["verified"]["collective_verified"]
+                    strong["parity_vs_reference"] = m4["verified"]["parity_vs_reference"]
             del m4
             # the same strong-scaled step over the OTHER routes of the collective (every rank runs the same sequence): which one the
             # transport between the GPUs favours is the one thing a single GPU cannot tell
@@ -976,6 +1154,9 @@ def run_rank(a):
                     tr = mr["elapsed_max"] / mr["steps"]
                     others[route] = {"ms_per_step": round(tr * 1e3, 5), "per_gpu_efficiency": round(mr["solo_ms"] / (tr * 1e3), 4),
                                      "collective": mr["collective_route"]}
+                    if mr.get("verified"):
+                        others[route]["collective_verified"] = mr["verified"]["collective_verified"]["ok"]
+                        others[route]["parity_vs_reference"] = mr["verified"]["parity_vs_reference"]["ok"]
                 del mr
             a.collective = chosen
             if rank == 0:

@@ -10,11 +10,19 @@
  *
  * Contract:
  *  - the caller owns every buffer (outputs and workspace included); the library never allocates
- *    or frees tensor memory and keeps no reference after return;
+ *    or frees device memory and keeps no reference after return;
  *  - all pointers are DEVICE pointers on the current HIP device; kernels are enqueued on the
  *    `stream` argument (a hipStream_t passed as void*; NULL = the default stream) and the call
  *    returns without synchronising -- scale/shift are read on the device, never on the host
- *    (the reference's `scale[0].item()` host syncs, lsq_cuda.cu:52-53,120-121, are gone);
+ *    (the reference's `scale[0].item()` host syncs, lsq_cuda.cu:52-53,120-121, are gone).
+ *    The exceptions are the SETUP calls of the rank communicator, each documented where it is declared:
+ *    lsq_hip_comm_create / _destroy (RCCL's own bootstrap and teardown), lsq_hip_comm_tune (scratch
+ *    memory, synchronises) and lsq_hip_comm_configure (synchronises the communicator's stream).  No
+ *    entry point on the per-step path -- the ops, lsq_hip_comm_all_reduce*, _join, _sharded_finish --
+ *    allocates or synchronises;
+ *  - no behaviour depends on the process environment: the library reads no environment variable
+ *    (tests/test_abi.py checks that the shipped binary does not import getenv); what can be chosen is
+ *    an argument or a field of an options struct;
  *  - re-entrant, no mutable global state: forward (caller thread) and backward (autograd engine
  *    thread) may run concurrently.  The library keeps only fill-once lookup tables (device
  *    properties, kernel register counts, per-thread workspace sizes per shape) and exports nothing
@@ -39,7 +47,7 @@
 extern "C" {
 #endif
 
-#define LSQ_HIP_ABI_VERSION 5
+#define LSQ_HIP_ABI_VERSION 6
 
 /* Storage type of x / grad / y / dx.  Arithmetic is fp32 for F32, BF16 and F16 storage and fp64
  * for F64 (reference CPU path: AT_DISPATCH_FLOATING_TYPES, lsq_cpu.cpp:37,92,182,243).
@@ -267,9 +275,9 @@ int lsq_hip_plan_backward_per_channel(int dtype, int64_t outer, int64_t channels
  * (one per process group and rank, created once from a 128-byte id that rank 0 generates and the host layer broadcasts),
  * and two ways to run a reduction --
  *   lsq_hip_comm_all_reduce        on `stream`, in order with the kernels around it;
- *   lsq_hip_comm_all_reduce_begin  on the communicator's own high-priority stream, after everything enqueued on `stream`
+ *   lsq_hip_comm_all_reduce_begin  on the communicator's own stream, after everything enqueued on `stream`
  *                                  so far; `stream` itself goes on (the next step's kernels overlap the reduction) until
- *   lsq_hip_comm_all_reduce_end    makes `stream` wait for reduction `ticket` (up to 8 may be outstanding).
+ *   lsq_hip_comm_all_reduce_end    makes `stream` wait for reduction `ticket`, or lsq_hip_comm_join for all of them.
  * Both forms are legal under HIP-graph capture when every begin is ended before the capture ends.  send == recv reduces in
  * place.  Elements: LSQ_F64 (the un-rounded [sum ds, sum db, count] of lsq_hip_backward_*'s dsdb_wide) or LSQ_F32 (the packed
  * [min, -max] of the rank-synchronised observer).  The calls are made on the device the communicator was created on (the
@@ -280,23 +288,55 @@ typedef struct lsq_comm lsq_comm;
 #define LSQ_COMM_ID_BYTES 128
 enum lsq_comm_op { LSQ_COMM_SUM = 0, LSQ_COMM_MIN = 1, LSQ_COMM_MAX = 2 };
 
+/* What a caller may choose about a communicator (NULL wherever it is taken = the defaults, all zero).
+ *   size                 sizeof(lsq_comm_options) of the caller's build (the struct may grow at the end);
+ *   event_system_fence   0: the events that order a begun reduction against the caller's stream are recorded WITHOUT the
+ *                        system-scope fence (hipEventDisableSystemFence) -- producer, reduction and consumer run on one device,
+ *                        where the agent-scope release every kernel ends with is enough, and the default fence (write back +
+ *                        invalidate the L2s) costs a BASELINE-config-4 shard step 2-8 us (profiles/r05_comm_cost.txt);
+ *                        1: default events.  The host layer is expected to CHECK the unfenced form on the transport at hand
+ *                        before relying on it (torchlsq.distributed.native_comm: 128 reductions of changing values through
+ *                        begin / side stream / join) and to switch with lsq_hip_comm_configure when the check fails. */
+typedef struct lsq_comm_options {
+    int32_t size;
+    int32_t event_system_fence;
+    int32_t reserved[2];
+} lsq_comm_options;
+
 int lsq_hip_comm_unique_id(void* id /* LSQ_COMM_ID_BYTES, host memory */);
-int lsq_hip_comm_create(const void* id, int32_t rank, int32_t nranks, lsq_comm** out);
+/* SETUP, collective: returns once every rank of `nranks` has joined with the same id (RCCL's bootstrap: blocks, allocates). */
+int lsq_hip_comm_create(const void* id, int32_t rank, int32_t nranks, const lsq_comm_options* options, lsq_comm** out);
+/* SETUP: waits for the communicator's own stream to drain, then applies `options` (today: swaps the event set).  Not between a
+ * begin and its end / join. */
+int lsq_hip_comm_configure(lsq_comm* comm, const lsq_comm_options* options);
+/* SETUP: picks, by measurement against `stream` (the stream the caller computes on), which of the communicator's candidate
+ * streams the overlapped reductions run on, so that it does not share a hardware queue with `stream` (a cross-stream wait
+ * parked in the compute stream's queue stalls its next kernel 13-22 us: profiles/r05_comm_cost.txt).  Allocates up to
+ * 256 MB of scratch (freed before it returns), synchronises `stream` and the candidates, ~1 ms.  Call it once, after
+ * lsq_hip_comm_create, at the same point on every rank, before the first begin; LSQ_EINVAL while `stream` is capturing.
+ * Without it the first candidate is used -- correct, possibly on the compute stream's queue.  A box too short of memory for
+ * the measurement keeps the first candidate and returns LSQ_OK (lsq_hip_comm_info says which). */
+int lsq_hip_comm_tune(lsq_comm* comm, void* stream);
+/* SETUP, collective (RCCL's teardown).  The communicator's stream is parked for the next communicator of the device, not
+ * destroyed (a host allocator may still hold it as the consumer of a buffer). */
 int lsq_hip_comm_destroy(lsq_comm* comm);
-/* out4 = [rank, nranks, device | side-stream choice << 16, RCCL version code]; side-stream choice: 0 = not made yet, 2 = no
- * candidate stream ran apart from the caller's (the first is used), 2 + k = candidate k - 1 was chosen (see
- * lsq_hip_comm_all_reduce_begin: the stream of the overlapped form is picked, by measurement, so that it does not share a
- * hardware queue with the stream of the first begin) */
-int lsq_hip_comm_info(const lsq_comm* comm, int32_t* out4);
+/* out8 = [rank, nranks, device, side-stream choice, event_system_fence, RCCL version code, reductions begun so far (mod 2^31),
+ *         ticket ring size]; side-stream choice: 0 = lsq_hip_comm_tune has not run, 2 = it ran and no candidate was measurably
+ * apart from the caller's stream (or the measurement could not be made): the first is used, 2 + k = candidate k - 1 was chosen */
+int lsq_hip_comm_info(const lsq_comm* comm, int32_t* out8);
 /* The communicator's own stream (a hipStream_t), for work that CONSUMES a reduction begun with lsq_hip_comm_all_reduce_begin
  * without making the caller's stream wait for it: enqueue the consumer (lsq_hip_sharded_finish, a cast) on this stream behind
  * the begin, and join the caller's stream once per training step -- lsq_hip_comm_join -- instead
- * of once per reduction (a cross-stream wait costs the GPU ~7 us each way, profiles/r05_comm_cost.txt). */
+ * of once per reduction (a cross-stream wait costs the GPU ~7 us each way, profiles/r05_comm_cost.txt).  It changes only in
+ * lsq_hip_comm_tune. */
 void* lsq_hip_comm_side_stream(const lsq_comm* comm);
 /* `stream` waits for EVERYTHING enqueued on the communicator's stream so far -- the reductions begun and whatever consumers
  * the caller put behind them there: the once-per-step join of the pattern above. */
 int lsq_hip_comm_join(lsq_comm* comm, void* stream);
 int lsq_hip_comm_all_reduce(lsq_comm* comm, const void* send, void* recv, int64_t count, int dtype, int op, void* stream);
+/* Tickets come from a ring of 8: begin number n + 8 re-records the events of begin n.  A late lsq_hip_comm_all_reduce_end on
+ * the old ticket then waits for the NEWER reduction as well -- it over-waits, it never under-waits (the communicator's stream is
+ * in order) -- so more than 8 outstanding begins are legal; lsq_hip_comm_join needs no ticket at all. */
 int lsq_hip_comm_all_reduce_begin(lsq_comm* comm, const void* send, void* recv, int64_t count, int dtype, int op,
                                   void* stream, int32_t* ticket);
 int lsq_hip_comm_all_reduce_end(lsq_comm* comm, int32_t ticket, void* stream);

@@ -1753,12 +1753,15 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
                 const bool fits = sizeof(typename IO::elem) < 4;
                 const int64_t w_lanes = c.C / V;
                 const bool low = elems < (int64_t{1} << 23);
-                const bool low_ok = w_lanes >= 1 && w_lanes <= 96 && (elems >= (int64_t{3} << 20) ||
+                // (floors: what the round-5 sweep covered -- 16 lanes below 2^23 elements, 8 lanes inside the band; narrower rows
+                //  mean hundreds of row groups per workgroup and a ~100 KB combine buffer nobody measured: they keep the usual
+                //  four-wave workgroups)
+                const bool low_ok = w_lanes >= 16 && w_lanes <= 96 && (elems >= (int64_t{3} << 20) ||
                                                       (elems >= (int64_t{3} << 18) && kBlock % static_cast<int>(w_lanes) != 0));
                 // ... and INSIDE the band the narrow rows changed sides with it: [rows, 64 / 128 / 256] +4 .. +9 % at 9-17 M
                 // elements (round 4: -11 .. -16 % for [rows,64]), -3 % at 25 M, level above; [rows,384] +1 .. +13 % through the
                 // whole band (same file, second table)
-                const bool band_ok = w_lanes >= 1 && elems < (int64_t{5} << 24) &&
+                const bool band_ok = w_lanes >= 8 && elems < (int64_t{5} << 24) &&
                                      (w_lanes >= 64 || kBlock % static_cast<int>(w_lanes) != 0 || elems < (int64_t{5} << 22));
                 const bool use_big = big == 1 || (big == 0 && c.default_variant && w_lanes <= kBlock && fits && (low ? low_ok : band_ok));
                 constexpr int kBigBlock = kBigBlockOf<sizeof(typename IO::elem)>;

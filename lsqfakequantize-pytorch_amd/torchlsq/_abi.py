@@ -55,8 +55,13 @@ class LsqPcItem(ctypes.Structure):
                 ("outer", ctypes.c_int64), ("channels", ctypes.c_int64), ("inner", ctypes.c_int64)]
 
 
+class LsqCommOptions(ctypes.Structure):
+    """struct lsq_comm_options (include/lsq_hip.h)."""
+    _fields_ = [("size", ctypes.c_int32), ("event_system_fence", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2)]
+
+
 LSQ_TICKET_BYTES = 4096
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
 _PP = ctypes.POINTER(LsqParams)
@@ -82,9 +87,11 @@ C_ABI = {
     "lsq_hip_per_channel_multi_ok": (_int, [_int, _i64, _i64, _i64, _int]),
     "lsq_hip_plan_backward_per_channel": (_int, [_int, _i64, _i64, _i64, _int, _PP, ctypes.POINTER(ctypes.c_int32 * 8)]),
     "lsq_hip_comm_unique_id": (_int, [_vp]),
-    "lsq_hip_comm_create": (_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_vp)]),
+    "lsq_hip_comm_create": (_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(LsqCommOptions), ctypes.POINTER(_vp)]),
+    "lsq_hip_comm_configure": (_int, [_vp, ctypes.POINTER(LsqCommOptions)]),
+    "lsq_hip_comm_tune": (_int, [_vp, _vp]),
     "lsq_hip_comm_destroy": (_int, [_vp]),
-    "lsq_hip_comm_info": (_int, [_vp, ctypes.POINTER(ctypes.c_int32 * 4)]),
+    "lsq_hip_comm_info": (_int, [_vp, ctypes.POINTER(ctypes.c_int32 * 8)]),
     "lsq_hip_comm_side_stream": (_vp, [_vp]),
     "lsq_hip_comm_join": (_int, [_vp, _vp]),
     "lsq_hip_comm_all_reduce": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),

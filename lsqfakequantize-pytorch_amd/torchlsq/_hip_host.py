@@ -717,7 +717,7 @@ class HipComm:
             _status(rc, "lsq_hip_comm_unique_id")
         return bytes(buf)
 
-    def __init__(self, uid, rank, nranks, device):
+    def __init__(self, uid, rank, nranks, device, event_system_fence=False):
         _assert_has_ops()
         _check(len(uid) == LSQ_COMM_ID_BYTES, "HipComm: the id is %d bytes" % LSQ_COMM_ID_BYTES)
         self.device = torch.device(device)
@@ -726,25 +726,48 @@ class HipComm:
         handle = ctypes.c_void_p()
         buf = (ctypes.c_ubyte * LSQ_COMM_ID_BYTES).from_buffer_copy(uid)
         rc = _on_device(self.index, _abi._LIB.lsq_hip_comm_create, ctypes.cast(buf, ctypes.c_void_p), self.rank, self.nranks,
-                        ctypes.byref(handle))
+                        ctypes.byref(self._options(event_system_fence)), ctypes.byref(handle))
         if rc:
             _status(rc, "lsq_hip_comm_create")
         self.handle = handle.value
+        self.checked = None          # what torchlsq.distributed.native_comm found out about it (a dict), for records
+
+    @staticmethod
+    def _options(event_system_fence):
+        return _abi.LsqCommOptions(size=ctypes.sizeof(_abi.LsqCommOptions), event_system_fence=int(bool(event_system_fence)))
+
+    def configure(self, event_system_fence):
+        """SETUP (waits for the communicator's stream): events with / without the system-scope fence (include/lsq_hip.h,
+        lsq_comm_options)"""
+        rc = _on_device(self.index, _abi._LIB.lsq_hip_comm_configure, self.handle, ctypes.byref(self._options(event_system_fence)))
+        if rc:
+            _status(rc, "lsq_hip_comm_configure")
+
+    def tune(self):
+        """SETUP (allocates scratch, synchronises): pick the communicator's stream by measurement against the device's CURRENT
+        stream -- call it once, on the stream the steps will run on, at the same point on every rank"""
+        rc = _on_device(self.index, _abi._LIB.lsq_hip_comm_tune, self.handle, _stream_of(self.index))
+        if rc:
+            _status(rc, "lsq_hip_comm_tune")
 
     def side_stream(self):
         """the communicator's own stream as a torch stream (for consumers of a begun reduction; join with end() once)"""
-        ptr = int(_abi._LIB.lsq_hip_comm_side_stream(self.handle))     # (chosen at the first begin: ask every time)
+        ptr = int(_abi._LIB.lsq_hip_comm_side_stream(self.handle))     # (lsq_hip_comm_tune may change it: ask every time)
         hit = getattr(self, "_side", None)
         if hit is None or hit[0] != ptr:
             hit = self._side = (ptr, torch.cuda.ExternalStream(ptr, device=self.device))
         return hit[1]
 
     def info(self):
-        out = (ctypes.c_int32 * 4)()
+        out = (ctypes.c_int32 * 8)()
         rc = _abi._LIB.lsq_hip_comm_info(self.handle, ctypes.byref(out))
         if rc:
             _status(rc, "lsq_hip_comm_info")
-        return dict(rank=out[0], nranks=out[1], device=out[2] & 0xffff, side_stream_choice=out[2] >> 16, rccl_version=out[3])
+        d = dict(rank=out[0], nranks=out[1], device=out[2], side_stream_choice=out[3], event_system_fence=out[4], rccl_version=out[5],
+                 reductions_begun=out[6])
+        if self.checked is not None:
+            d["checked"] = dict(self.checked)
+        return d
 
     def _args(self, t, out, op):
         _check(t.is_cuda and t.device.index == self.index and t.is_contiguous() and t.dtype in _COMM_DTYPES,

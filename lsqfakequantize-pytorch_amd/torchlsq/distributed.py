@@ -13,6 +13,7 @@ plus a reduction, so it shards by splitting dim 0 (the batch) across ranks:
 `backend="nccl"` is RCCL on ROCm builds of PyTorch; the CPU tests use gloo.
 """
 import os
+import threading
 import time
 
 import torch
@@ -45,11 +46,12 @@ COLLECTIVE = "collective"      # global_numel=COLLECTIVE: the element count trav
 # torch.distributed's all_reduce costs ~60 us of HOST time per call (profiles/r04_module_sync_cost.txt), as much as a rank's
 # whole BASELINE-config-4 step takes on the GPU; lsq_hip_comm_all_reduce* (include/lsq_hip.h) makes the same RCCL call with a
 # handful of HIP calls.  One communicator per (process group, GPU), created at the first sharded backward of GPU tensors over
-# an RCCL ("nccl") process group: rank 0's 128-byte id is broadcast through that group, every rank joins, and the ranks then
-# AGREE (one MIN all-reduce of a flag) that all of them succeeded -- otherwise all of them keep torch.distributed.
+# an RCCL ("nccl") process group -- see native_comm for the protocol: every step of it is agreed between the ranks over
+# torch.distributed, and any failure leaves ALL of them on torch.distributed.
 # TORCHLSQ_COLLECTIVE=c10d switches the native route off; gloo groups and CPU tensors never take it.
 _COMMS = {}                 # (group key, device index) -> HipComm, or None: this group stays on torch.distributed
 _NATIVE_COLLECTIVE = [os.environ.get("TORCHLSQ_COLLECTIVE", "native").lower() != "c10d"]
+ROUTE_CHECK_REDUCTIONS = 128    # reductions of the timed route's self-check (native_comm step 5)
 
 
 def set_native_collective(on):
@@ -62,70 +64,208 @@ def _group_key(group):
     return 0 if group is None else id(group)
 
 
+def _agree(values, device, group):
+    """MIN over the ranks of a few small ints, through torch.distributed (its own communicator and stream)"""
+    flag = torch.tensor([int(v) for v in values], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return [int(v) for v in flag.tolist()]
+
+
+def _wait_event(ev, limit):
+    """poll a recorded event under a host-side deadline; False = it did not finish (a negative limit, tests: 'it never did')"""
+    deadline = time.monotonic() + limit
+    while not ev.query() and time.monotonic() < deadline:
+        time.sleep(0.002)
+    return limit >= 0 and ev.query()
+
+
+def _create_under_deadline(uid, rank, ws, device, limit):
+    """HipComm(...) -- ncclCommInitRank, a collective -- on a helper thread: the caller gets (comm, None), (None, error text) or
+    (None, None) when the bootstrap did not return within `limit` seconds (the thread is a daemon and is left to it)."""
+    box = {}
+
+    def work():
+        try:
+            box["comm"] = _E.HipComm(uid, rank, ws, device)
+        except Exception as e:           # noqa: BLE001 -- anything: the caller falls back
+            box["error"] = "%s: %s" % (type(e).__name__, e)
+
+    th = threading.Thread(target=work, daemon=True, name="lsq-comm-create")
+    th.start()
+    th.join(limit)
+    if th.is_alive():
+        return None, None
+    return box.get("comm"), box.get("error", "no communicator")
+
+
+def check_timed_route(comm, device, limit, n=ROUTE_CHECK_REDUCTIONS):
+    """The route sharded_backward(async_op=True) takes, exercised BEFORE anything relies on it: `n` reductions whose value
+    changes every time, each produced on the current stream, reduced with begin on the communicator's stream, consumed there
+    (a copy behind the reduction, like the rounding of the real route) and, after a join every fourth reduction, consumed
+    again on the current stream; four buffers in rotation, each rewritten right after the join that covers its last reader.
+    A missing ordering anywhere -- producer -> reduction (the `ready` event), reduction -> consumer on the communicator's stream
+    (stream order), reduction -> consumer on the current stream (the join's event) -- shows up as a stale or torn value.
+    Returns "" (every one of the 2 n consumed values is the exact sum), "hung" or what was wrong."""
+    ws, rank = comm.nranks, comm.rank
+    cur = torch.cuda.current_stream(device)
+    side = comm.side_stream()
+    bufs = [torch.zeros(3, dtype=torch.float64, device=device) for _ in range(4)]
+    seen_side = torch.zeros(n, 3, dtype=torch.float64, device=device)
+    seen_cur = torch.zeros(n, 3, dtype=torch.float64, device=device)
+    base = torch.arange(n, dtype=torch.float64, device=device) * 1000.0 + float(rank + 1)
+    torch.cuda.synchronize(device)
+    for k in range(n):
+        b = bufs[k % 4]
+        b.copy_(base[k].expand(3))                 # the producer, on the current stream: k * 1000 + rank + 1
+        comm.begin(b)
+        with torch.cuda.stream(side):
+            seen_side[k].copy_(b)                  # the consumer behind the reduction, on the communicator's stream
+        if k % 4 == 3 or k == n - 1:
+            comm.join()
+            lo = k - (k % 4)
+            for j in range(lo, k + 1):
+                seen_cur[j].copy_(bufs[j % 4])     # ... and one on the current stream, after the join
+    for t in bufs + [seen_side, seen_cur, base]:
+        t.record_stream(side)
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    if not _wait_event(ev, limit):
+        return "hung"
+    want = (torch.arange(n, dtype=torch.float64) * 1000.0 * ws + ws * (ws + 1) / 2.0).unsqueeze(1).expand(n, 3)
+    for name, got in (("communicator's stream", seen_side.cpu()), ("current stream after join", seen_cur.cpu())):
+        bad = (got != want).any(dim=1).nonzero().reshape(-1)
+        if bad.numel():
+            k = int(bad[0])
+            return "%d of %d reductions wrong when consumed on the %s; first: #%d got %r, expected %r" % (
+                bad.numel(), n, name, k, got[k].tolist(), float(want[k, 0]))
+    return ""
+
+
 def native_comm(group, device, create=True):
     """The HipComm of (group, device), created on first use -- a COLLECTIVE call then: every rank of the group must make its
     first sharded call at the same point, which data-parallel training does by construction.  None = torch.distributed.
-    A communicator is only kept if it WORKS: right after creation the ranks add up rank + 1 through it under a host-side
-    deadline (TORCHLSQ_COMM_CHECK_S, 60 s) and agree on the outcome; a rank that could not create it, a wrong sum or a
-    reduction that does not finish leaves every rank on torch.distributed."""
+    create=False only looks: it never creates and never decides anything for later calls.
+
+    A communicator is only kept if it WORKS, and no rank enters a step another rank skips -- every decision is a MIN over the
+    ranks through torch.distributed (host-side deadline per step: TORCHLSQ_COMM_CHECK_S, 60 s):
+      1. rank 0 makes the 128-byte id, every rank checks that the library can reach RCCL; the id is broadcast;
+      2. AGREE: all ranks can go on -- otherwise nobody calls ncclCommInitRank (a rank waiting in RCCL's bootstrap for one that
+         never comes would wait forever);
+      3. lsq_hip_comm_create on a helper thread, under the deadline; lsq_hip_comm_tune on the current stream (the
+         communicator's stream is picked against the stream the steps run on; setup call: allocates, synchronises);
+      4. the ranks add up rank + 1 through it in stream order, on a stream of its own, under the deadline;
+      5. the route of sharded_backward(async_op=True) -- begin on the communicator's stream, a consumer behind it there, one
+         join -- carries ROUTE_CHECK_REDUCTIONS reductions of changing values (check_timed_route) with the events recorded
+         WITHOUT the system-scope fence; AGREE; if any rank saw a wrong value: lsq_hip_comm_configure(event_system_fence = 1)
+         on every rank and the same check again;
+      6. AGREE: kept only if every rank passed 4 and 5.  `comm.checked` records what was found (bench.py prints it)."""
     if not _NATIVE_COLLECTIVE[0] or not (dist.is_available() and dist.is_initialized()):
         return None
     key = (_group_key(group), device.index)
+    rank, ws = dist.get_rank(group), dist.get_world_size(group)
     if key in _COMMS:
-        return _COMMS[key]
-    if not create or dist.get_backend(group) != "nccl":
+        comm = _COMMS[key]
+        # a hit must still belong to THIS world: dist.destroy_process_group() + a new init, or a new group object that got a
+        # recycled id(), would otherwise be handed a communicator of ranks that no longer exist
+        if comm is None or (comm.handle and comm.nranks == ws and comm.rank == rank):
+            return comm
+        del _COMMS[key]
+    if not create:
+        return None
+    if dist.get_backend(group) != "nccl":
         _COMMS[key] = None
         return None
-    rank, ws = dist.get_rank(group), dist.get_world_size(group)
-    comm, ok = None, 1
-    try:
-        uid = torch.zeros(_E.LSQ_COMM_ID_BYTES, dtype=torch.uint8, device=device)
+    limit = float(os.environ.get("TORCHLSQ_COMM_CHECK_S", "60"))       # (tests: a negative limit = "it never finished")
+    t0 = time.monotonic()
+    checked = {"world": ws}
+    ok = 1
+    uid = torch.zeros(_E.LSQ_COMM_ID_BYTES, dtype=torch.uint8, device=device)
+    try:                                                        # 1.
+        mine = _E.HipComm.unique_id()                           # (every rank: it is also the "RCCL resolves here" probe)
         if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(_E.HipComm.unique_id()), dtype=torch.uint8))
-    except Exception:       # no RCCL behind the library: still take part in the two collectives below
-        ok = 0
-        uid = torch.zeros(_E.LSQ_COMM_ID_BYTES, dtype=torch.uint8, device=device)
+            uid.copy_(torch.frombuffer(bytearray(mine), dtype=torch.uint8))
+    except Exception as e:       # noqa: BLE001 -- no RCCL behind the library: still take part in the collectives below
+        ok, checked["why"] = 0, "RCCL not reachable from the library: %s" % e
     src = dist.get_global_rank(group, 0) if group is not None else 0
     dist.broadcast(uid, src=src, group=group)
+    if _agree([ok], device, group)[0] != 1:                     # 2.
+        _COMMS[key] = None
+        return None
+    comm, err = _create_under_deadline(bytes(uid.cpu().numpy().tobytes()), rank, ws, device, limit if limit > 0 else 60.0)   # 3.
     hung = 0
-    if ok:
+    if comm is None:
+        ok, hung = 0, int(err is None)
+        checked["why"] = err or "ncclCommInitRank did not return in time"
+    ok, nothung = _agree([ok, nothung_of(hung)], device, group)      # (a rank without peers must not start a reduction)
+    hung = -nothung
+    unfenced_ok = 1
+    if ok == 1:
         try:
-            comm = _E.HipComm(bytes(uid.cpu().numpy().tobytes()), rank, ws, device)
-            # ... and it has to WORK before anything relies on it: the ranks add up rank + 1 through it, on a stream of its
-            # own (a reduction that never ends must not sit in the caller's stream) and under a host-side deadline
-            pre = torch.cuda.Stream(device=device)
+            comm.tune()
+            pre = torch.cuda.Stream(device=device)              # 4. (a reduction that never ends must not sit in the caller's stream)
             with torch.cuda.stream(pre):
                 probe = torch.full((2,), float(rank + 1), dtype=torch.float64, device=device)
                 comm.all_reduce(probe)
                 ev = torch.cuda.Event()
                 ev.record(pre)
-            limit = float(os.environ.get("TORCHLSQ_COMM_CHECK_S", "60"))       # (tests: a negative limit = "it never finished")
-            deadline = time.monotonic() + limit
-            while not ev.query() and time.monotonic() < deadline:
-                time.sleep(0.002)
-            if limit < 0 or not ev.query():
-                ok, hung = 0, 1
+            if not _wait_event(ev, limit):
+                ok, hung, checked["why"] = 0, 1, "the first reduction (16 bytes, stream order) did not finish in time"
             elif float(probe[0].item()) != ws * (ws + 1) / 2.0:
-                ok = 0
-        except Exception:
-            ok = 0
-    flag = torch.tensor([ok, -hung], dtype=torch.int32, device=device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag[0].item()) != 1:
-        if comm is not None and int(flag[1].item()) == 0:       # (hung anywhere: left alone, a teardown would wait for it too)
+                ok, checked["why"] = 0, "the first reduction gave %r, expected %r" % (float(probe[0].item()), ws * (ws + 1) / 2.0)
+            else:
+                why = check_timed_route(comm, device, limit)    # 5., unfenced events
+                if not why and _TEST_HOOKS.get("unfenced_fails"):
+                    why = "forced by a test hook"
+                if why == "hung":
+                    ok, hung, checked["why"] = 0, 1, "the timed route's self-check did not finish in time"
+                elif why:
+                    unfenced_ok, checked["unfenced"] = 0, why
+        except Exception as e:       # noqa: BLE001
+            ok, checked["why"] = 0, "%s: %s" % (type(e).__name__, e)
+        ok, nothung, unfenced_ok = _agree([ok, nothung_of(hung), unfenced_ok], device, group)
+        hung = -nothung
+    if ok == 1 and unfenced_ok != 1:
+        fenced_ok = 1
+        try:
+            comm.configure(event_system_fence=True)
+            why = check_timed_route(comm, device, limit)
+            if why:
+                fenced_ok, hung, checked["why"] = 0, int(why == "hung"), "with system-fenced events too: " + why
+        except Exception as e:       # noqa: BLE001
+            fenced_ok, checked["why"] = 0, "%s: %s" % (type(e).__name__, e)
+        ok, nothung = _agree([fenced_ok, nothung_of(hung)], device, group)
+        hung = -nothung
+    if ok != 1:                                                 # 6.
+        if comm is not None and not hung:       # (hung anywhere: left alone, a teardown would wait for it too)
             try:
                 comm.destroy()
-            except Exception:
+            except Exception:        # noqa: BLE001
                 pass
+        LAST_FAILURE.clear()
+        LAST_FAILURE.update(checked, hung=bool(hung), why=checked.get("why", "another rank failed"))
         comm = None
+    else:
+        checked.update(route_check="%d reductions of changing values through begin / side stream / join: all exact" % ROUTE_CHECK_REDUCTIONS,
+                       events="system-fenced (the unfenced form failed the check on some rank)" if unfenced_ok != 1 else
+                              "no system-scope fence (checked)", seconds=round(time.monotonic() - t0, 3))
+        comm.checked = checked
     _COMMS[key] = comm
     return comm
 
 
+def nothung_of(hung):
+    return -int(bool(hung))
+
+
+_TEST_HOOKS = {}            # tests only: {"unfenced_fails": True} makes step 5 take the system-fenced branch
+LAST_FAILURE = {}           # why the last native_comm creation fell back (records; empty = none did)
+
+
 def destroy_native_comms():
-    """tear the library's communicators down (before dist.destroy_process_group(); collective per communicator)"""
+    """tear the library's communicators down -- REQUIRED before dist.destroy_process_group() when the native route was used
+    (collective per communicator)"""
     for key, comm in list(_COMMS.items()):
-        if comm is not None:
+        if comm is not None and comm.handle:
             comm.destroy()
         del _COMMS[key]
 

@@ -45,8 +45,9 @@ _IH_STD = math.sqrt(4.0 * (65536.0 ** 2 - 1.0) / 12.0)
 
 
 def normal_like(numel, seed, mean=0.0, std=1.0, device="cpu", dtype=torch.float32, chunk=1 << 24,
-                absolute=False):
-    """1-D tensor of `numel` approximately N(mean, std) values (|.| of the variate if `absolute`).
+                absolute=False, first_index=0):
+    """1-D tensor of `numel` approximately N(mean, std) values (|.| of the variate if `absolute`): elements
+    first_index .. first_index + numel - 1 of stream `seed` (a slice of a longer stream is that stream's bits).
 
     value_i = fp64(mean) + fp64(std / IH_STD) * (sum of the 4 u16 fields of hash64(i) - IH_MEAN),
     each step a single IEEE operation in fp64, then one rounding to `dtype`.
@@ -55,7 +56,7 @@ def normal_like(numel, seed, mean=0.0, std=1.0, device="cpu", dtype=torch.float3
     k = float(std) / _IH_STD
     for lo in range(0, numel, chunk):
         hi = min(numel, lo + chunk)
-        idx = torch.arange(lo, hi, dtype=torch.int64, device=device)
+        idx = torch.arange(lo + int(first_index), hi + int(first_index), dtype=torch.int64, device=device)
         h = hash64(idx, seed)
         s = (h & 0xFFFF) + (_lsr(h, 16) & 0xFFFF) + (_lsr(h, 32) & 0xFFFF) + _lsr(h, 48)
         v = (s - _IH_MEAN).to(torch.float64)
@@ -152,7 +153,7 @@ def ds_term_sign(x, scale, shift, c):
     return torch.where(coef < 0, -torch.ones_like(coef), torch.ones_like(coef))
 
 
-def make_inputs(cfg, device="cpu", dtype=None, shape=None, abs_grad=False):
+def make_inputs(cfg, device="cpu", dtype=None, shape=None, abs_grad=False, first_index=0):
     """(x, grad, scale, shift) for a CONFIGS entry (or a dict of the same keys).
 
     `shape` overrides the configured shape (e.g. one rank's shard); `dtype` overrides the storage
@@ -161,6 +162,9 @@ def make_inputs(cfg, device="cpu", dtype=None, shape=None, abs_grad=False):
     side has one sign: no cancellation in a per-tensor quint8 d_scale, still some in a signed range); "dspos" -- |grad| times
     the sign of the element's d_scale factor (ds_term_sign): every d_scale term is >= 0, the no-cancellation case of d_scale
     for any range.
+    `first_index`: x / grad are elements first_index .. first_index + numel - 1 of their streams -- with `shape` one rank's
+    dim-0 slice of the configured tensor (rank r of N holds rows [r * rows / N, (r + 1) * rows / N): first_index = r * numel of
+    a shard), the SAME bits the slice of the whole tensor has.  scale / shift are replicated, never offset.
     """
     c = CONFIGS[cfg] if isinstance(cfg, str) else cfg
     shape = tuple(shape if shape is not None else c["shape"])
@@ -169,8 +173,8 @@ def make_inputs(cfg, device="cpu", dtype=None, shape=None, abs_grad=False):
         numel *= d
     dt = dtype if dtype is not None else getattr(torch, c["dtype"])
     pdt = torch.float64 if dt == torch.float64 else torch.float32
-    x = normal_like(numel, SEED_X, c["x_mean"], c["x_std"], device, dt).view(shape)
-    g = normal_like(numel, SEED_G, 0.0, GRAD_STD, device, dt, absolute=bool(abs_grad)).view(shape)
+    x = normal_like(numel, SEED_X, c["x_mean"], c["x_std"], device, dt, first_index=first_index).view(shape)
+    g = normal_like(numel, SEED_G, 0.0, GRAD_STD, device, dt, absolute=bool(abs_grad), first_index=first_index).view(shape)
     C = shape[c["axis"]] if c["per_channel"] else 1
     sc = c["scale"]
     if isinstance(sc, tuple):

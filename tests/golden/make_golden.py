@@ -6,6 +6,7 @@ Run in the build container only (needs /root/reference):
     python oracle/build_ref.py            # reference csrc -> oracle/_ref/libtorchlsq_ref_ops.so
     python tests/golden/make_golden.py            # small cases + cfg1/cfg3/cfg5 digests (~2 min)
     python tests/golden/make_golden.py --big      # + cfg2 / cfg4 (205 M elements each, ~10 min)
+    python tests/golden/make_golden.py --skip-small --shards   # only the per-rank records of the batch-sharded runs (~15 min)
 
 What is written (data only -- inputs and the reference's outputs):
     tests/golden/small_cases.npz / small_cases.json   full tensors for ~60 small cases
@@ -371,6 +372,81 @@ def digest_config(ref, name, cfg_key, bf16=False, abs_grad=False):
     return rec
 
 
+def shard_digests(ref):
+    """What every RANK of a batch-sharded run must hold (bench.py --gpus N verifies itself against this; tests/test_bench_cli.py).
+
+    cfg4 (strong scaling): rank r of N in {2, 4, 8} owns rows [r * 1024 / N, (r + 1) * 1024 / N) of the [1024,1024,14,14] tensor.
+      y / dx are elementwise, so a rank's outputs are the slices of the reference's outputs on the whole tensor: sha256 per shard.
+      The reduced [ds, db] must equal the reference's on the whole tensor (config "cfg4" above); each rank's own contribution is
+      recorded from the oracle run on the shard with the GLOBAL element count in the gradient scaler (lsq_cpu.cpp:103 uses
+      x.numel() of the concatenated tensor), and the sum of those contributions is checked HERE against the reference's result.
+    cfg2_weak (weak scaling): rank r owns a full BASELINE-config-2 tensor, rows [128 r, 128 (r + 1)) of a virtual [128 N,512,56,56]
+      one (synth.make_inputs(first_index = r * numel)).  y / dx: the reference's own ops on the shard's inputs (elementwise: what
+      they would be inside the concatenated tensor).  ds / db contributions per (N, r): the oracle with the global count."""
+    out = {}
+    # ---- cfg4: one reference run on the whole tensor, sliced
+    p = S.op_kwargs("cfg4")
+    c = S.CONFIGS["cfg4"]
+    x, g, scale, shift = S.make_inputs("cfg4", dtype=torch.float32)
+    y, dx, ds, db = ref_fwd_bwd(ref, x, g, scale, shift, p)
+    rows = x.shape[0]
+    rec = dict(shape=list(x.shape), y_sha256=sha(y), dx_sha256=sha(dx), ds=ds.astype(np.float64).tolist(), db=db.astype(np.float64).tolist(), by_world={})
+    xn, gn = x.numpy(), g.numpy()
+    for N in (2, 4, 8):
+        per = rows // N
+        shards, tot_ds, tot_db, tot_ads, tot_adb = [], 0.0, 0.0, 0.0, 0.0
+        for r in range(N):
+            sl = slice(r * per, (r + 1) * per)
+            o = O.bwd_pt(gn[sl], xn[sl], scale[0].item(), shift[0].item(), p["quant_min"], p["quant_max"], p["type_min"], p["type_max"],
+                         True, 1.0, False, False, False, numel_for_scaler=x.numel())
+            assert bits_equal(o.dx.reshape(dx[sl].shape), dx[sl]), "cfg4 shard %d/%d: oracle dx differs from the reference's slice" % (r, N)
+            shards.append(dict(rank=r, first_index=r * per * int(np.prod(x.shape[1:])), shape=[per] + list(x.shape[1:]),
+                               y_sha256=sha(y[sl]), dx_sha256=sha(dx[sl]),
+                               ds_wide=float(o.ds_wide[0]), db_wide=float(o.db_wide[0]), abs_ds=float(o.abs_ds[0]), abs_db=float(o.abs_db[0])))
+            tot_ds += float(o.ds_wide[0]); tot_db += float(o.db_wide[0]); tot_ads += float(o.abs_ds[0]); tot_adb += float(o.abs_db[0])
+        # the method itself, against the reference on the concatenated tensor: shard sums with the global count == its ds / db
+        assert abs(tot_ds - float(ds[0])) <= 1e-6 * tot_ads and abs(tot_db - float(db[0])) <= 1e-6 * tot_adb, (N, tot_ds, ds, tot_db, db)
+        rec["by_world"][str(N)] = dict(shards=shards, sum_ds_wide=tot_ds, sum_db_wide=tot_db, abs_ds=tot_ads, abs_db=tot_adb)
+        print("  cfg4 shards N=%d: sum of shard sums %.12g / %.12g vs reference %.9g / %.9g" % (N, tot_ds, tot_db, ds[0], db[0]))
+    out["cfg4"] = rec
+    del x, g, y, dx, xn, gn
+    # ---- cfg2, weak-scaled: eight shards of a virtual [1024,512,56,56] tensor
+    p = S.op_kwargs("cfg2")
+    n = int(np.prod(S.CONFIGS["cfg2"]["shape"]))
+    shards, per_world = [], {str(N): [] for N in (1, 2, 4, 8)}
+    for r in range(8):
+        t0 = time.time()
+        x, g, scale, shift = S.make_inputs("cfg2", dtype=torch.float32, first_index=r * n)
+        y, dx, ds, db = ref_fwd_bwd(ref, x, g, scale, shift, p)
+        shards.append(dict(rank=r, first_index=r * n, x_sha256=sha(x.numpy()), g_sha256=sha(g.numpy()), y_sha256=sha(y), dx_sha256=sha(dx),
+                           ds_alone=ds.astype(np.float64).tolist(), db_alone=db.astype(np.float64).tolist()))
+        for N in (1, 2, 4, 8):
+            if r >= N:
+                continue
+            o = O.bwd_pt(g.numpy(), x.numpy(), scale[0].item(), shift[0].item(), p["quant_min"], p["quant_max"], p["type_min"], p["type_max"],
+                         True, 1.0, False, False, False, numel_for_scaler=N * n)
+            assert bits_equal(o.dx.reshape(dx.shape), dx), "cfg2 weak shard %d: oracle dx differs from the reference" % r
+            per_world[str(N)].append(dict(rank=r, ds_wide=float(o.ds_wide[0]), db_wide=float(o.db_wide[0]), abs_ds=float(o.abs_ds[0]),
+                                          abs_db=float(o.abs_db[0])))
+            if N == 1:      # a world of one is the plain op: the reference's own result on this shard
+                assert abs(o.ds_wide[0] - float(ds[0])) <= 1e-6 * o.abs_ds[0] and abs(o.db_wide[0] - float(db[0])) <= 1e-6 * o.abs_db[0]
+        print("  cfg2 weak shard %d  %5.1fs  ds alone %.9g" % (r, time.time() - t0, ds[0]))
+        del x, g, y, dx
+    out["cfg2_weak"] = dict(shard_shape=list(S.CONFIGS["cfg2"]["shape"]), shards=shards,
+                            by_world={N: dict(shards=v, sum_ds_wide=sum(s_["ds_wide"] for s_ in v), sum_db_wide=sum(s_["db_wide"] for s_ in v),
+                                              abs_ds=sum(s_["abs_ds"] for s_ in v), abs_db=sum(s_["abs_db"] for s_ in v))
+                                      for N, v in per_world.items() if N != "1"})
+    path = os.path.join(HERE, "shard_digests.json")
+    with open(path, "w") as f:
+        json.dump(dict(generator="tests/golden/make_golden.py --shards", torch=torch.__version__,
+                       note="per-rank expectations of the batch-sharded bench runs: y / dx sha256 from the reference CPU csrc (slices of its "
+                            "outputs on the whole tensor for cfg4; its outputs on the shard's inputs for cfg2_weak), each rank's fp64 [ds, db] "
+                            "contribution from oracle/lsq_oracle.c run with the GLOBAL element count in the gradient scaler (checked at "
+                            "generation time: their sum == the reference's ds / db on the concatenated cfg4 tensor within 1e-6 sum|terms|)",
+                       shards=out), f, indent=1)
+    print("wrote", path)
+
+
 def make_digests(ref, big, only=None):
     path = os.path.join(HERE, "config_digests.json")
     out = {}
@@ -410,11 +486,15 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also digest cfg2/cfg4 (205 M elements each)")
     ap.add_argument("--skip-small", action="store_true")
+    ap.add_argument("--shards", action="store_true", help="ONLY tests/golden/shard_digests.json: what each rank of a batch-sharded run must hold")
     ap.add_argument("--only", default="", help="comma-separated digest names to (re)generate; the others are kept as they are")
     a = ap.parse_args()
     import warnings
     warnings.filterwarnings("ignore")
     ref = load_reference()
+    if a.shards:
+        shard_digests(ref)
+        sys.exit(0)
     if not a.skip_small:
         make_small(ref)
     make_digests(ref, a.big, set(a.only.split(",")) if a.only else None)

@@ -23,7 +23,7 @@ def _declared():
 
 def test_header_symbols_are_exported():
     names = _declared()
-    assert len(names) == 34, names
+    assert len(names) == 36, names
     nm = subprocess.run(["nm", "-D", "--defined-only", LIB], capture_output=True, text=True, check=True).stdout
     exported = sorted(set(l.split()[-1] for l in nm.splitlines() if " T " in l and l.split()[-1].startswith("lsq_")))
     # exported == declared, not a superset: no `_ex` twin, no lsq_hip_debug_* knob, nothing else with C linkage
@@ -38,7 +38,7 @@ def test_tools_build_carries_the_internal_entry_points():
     """tools/_tune/liblsq_hip_tools.so (-DLSQ_TOOLS): include/lsq_hip.h plus csrc/lsq_internal.h, typed by tools/lsq_tools.py"""
     import lsq_tools
     lib = lsq_tools.load()
-    assert lib.lsq_hip_abi_version() == 5
+    assert lib.lsq_hip_abi_version() == 6
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "lsqfakequantize-pytorch_amd", "csrc", "lsq_internal.h")).read(), flags=re.S)
     internal = sorted(set(re.findall(r"\b(lsq_hip_\w+)\s*\(", text)))
     assert internal == sorted(lsq_tools.internal_abi()), (internal, sorted(lsq_tools.internal_abi()))
@@ -49,7 +49,7 @@ def test_tools_build_carries_the_internal_entry_points():
 def test_python_binding_table_matches_header():
     from torchlsq import extension as E
     assert sorted(E.C_ABI) == _declared()
-    assert E._HAS_OPS and E.library().lsq_hip_abi_version() == E.ABI_VERSION == 5
+    assert E._HAS_OPS and E.library().lsq_hip_abi_version() == E.ABI_VERSION == 6
     assert E.library().lsq_hip_runtime_version() > 0
     import torch
     assert torch.ops.torchlsq._cuda_version() == E.library().lsq_hip_runtime_version()
@@ -198,11 +198,31 @@ def test_comm_entry_points_validate_before_anything_else():
     assert lib.lsq_hip_comm_unique_id(None) == -1 and b"NULL" in lib.lsq_hip_last_error()
     out = ctypes.c_void_p()
     buf = (ctypes.c_ubyte * E.LSQ_COMM_ID_BYTES).from_buffer_copy(uid)
-    assert lib.lsq_hip_comm_create(ctypes.cast(buf, ctypes.c_void_p), 3, 2, ctypes.byref(out)) == -1      # rank 3 of 2
+    assert lib.lsq_hip_comm_create(ctypes.cast(buf, ctypes.c_void_p), 3, 2, None, ctypes.byref(out)) == -1      # rank 3 of 2
     assert b"rank 3 of 2" in lib.lsq_hip_last_error() and not out.value
+    # options are arguments, validated like any other (lsq_comm_options: a sized struct, NULL = defaults)
+    from torchlsq import _abi
+    assert ctypes.sizeof(_abi.LsqCommOptions) == 16
+    bad = _abi.LsqCommOptions(size=16, event_system_fence=7)
+    assert lib.lsq_hip_comm_create(ctypes.cast(buf, ctypes.c_void_p), 0, 1, ctypes.byref(bad), ctypes.byref(out)) == -1
+    assert b"event_system_fence" in lib.lsq_hip_last_error() and not out.value
+    short = _abi.LsqCommOptions(size=2)
+    assert lib.lsq_hip_comm_create(ctypes.cast(buf, ctypes.c_void_p), 0, 1, ctypes.byref(short), ctypes.byref(out)) == -1
+    assert lib.lsq_hip_comm_tune(None, None) == -1 and lib.lsq_hip_comm_configure(None, None) == -1
     assert lib.lsq_hip_comm_all_reduce(None, None, None, 1, E.LSQ_F64, E.LSQ_COMM_SUM, None) == -1
     assert lib.lsq_hip_comm_all_reduce_end(None, 0, None) == -1 and lib.lsq_hip_comm_join(None, None) == -1
     assert lib.lsq_hip_comm_destroy(None) == 0 and not lib.lsq_hip_comm_side_stream(None)
+
+
+def test_the_shipped_library_reads_no_environment_variable():
+    """include/lsq_hip.h: "no behaviour depends on the process environment" -- the product binary does not even import getenv
+    (RCCL, resolved with dlopen, reads its own NCCL_* / RCCL_* variables: that is RCCL's contract, not this library's); the
+    experiment switches of earlier rounds (LSQ_COMM_PICK_STREAM, LSQ_COMM_EVENT_FENCE) are lsq_comm_options / lsq_hip_comm_tune now"""
+    und = subprocess.run(["nm", "-D", "--undefined-only", LIB], capture_output=True, text=True, check=True).stdout
+    imported = sorted(set(l.split()[-1].split("@")[0] for l in und.splitlines() if l.strip()))
+    assert not [n for n in imported if "getenv" in n], [n for n in imported if "getenv" in n]
+    src = open(os.path.join(ROOT, "lsqfakequantize-pytorch_amd", "csrc", "lsq_comm.hip")).read()
+    assert "getenv" not in src
 
 
 def test_plan_query_answers_without_launching_anything():

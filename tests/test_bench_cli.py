@@ -38,6 +38,23 @@ def test_self_spawned_ranks_on_one_device():
     assert out["config"]["global_elements"] == 2 * out["config"]["elements_per_gpu"]
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
     assert 0 < out["per_gpu_efficiency"] and out["rank0_shard_alone_ms_per_step"] > 0
+    # the line proves its own sums: the two ranks hold DIFFERENT slices, the reduced [ds, db] of the last timed step equals their
+    # contributions gathered over an independent transport (no reference digests for a 2-rank config 1: parity n/a)
+    cv = out["config"]["collective_verified"]
+    assert cv["ok"] and cv["ranks"] == 2 and cv["distinct_data_per_rank"] and cv["max_err_over_tol"] <= 1.0, cv
+    assert out["parity_vs_reference"]["ok"] is None
+
+
+@pytest.mark.gpu
+def test_a_wrong_sum_prints_the_line_with_ok_false():
+    """a corrupted reduction (test switch: the reduced sums scaled by 1 + 1e-3 before they are checked) must not cost the line --
+    it comes out with collective_verified.ok = false"""
+    r = _run(["--gpus", "2", "--backend", "gloo", "--single-device", "--workload", "cfg1", "--steps", "4", "--warmup", "1",
+              "--no-cpu-baseline"], extra_env={"LSQ_BENCH_CORRUPT_REDUCED": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    cv = out["config"]["collective_verified"]
+    assert out["value"] > 0 and cv["ok"] is False and cv["max_err_over_tol"] > 1e6, cv
 
 
 @pytest.mark.gpu
@@ -53,6 +70,14 @@ def test_default_multi_rank_line_carries_the_strong_scaled_config_too():
     assert s4["value"] > 0 and 0 < s4["per_gpu_efficiency"] and 0 < out["per_gpu_efficiency"]
     # ... and over the other routes of the collective (over gloo every route ends in torch.distributed: the control flow)
     assert sorted(s4["other_routes"]) == ["c10d", "native-inline"] and all(r["ms_per_step"] > 0 for r in s4["other_routes"].values())
+    # both records verify themselves: reduced == gathered contributions, and against the REFERENCE's outputs for every rank's
+    # slice (tests/golden/shard_digests.json: weak-scaled config 2 and config 4 at 2 ranks) -- y / dx by sha256, sums to 1e-6
+    for rec, cfg in ((out, out["config"]), (s4, s4)):
+        assert cfg["collective_verified"]["ok"] and cfg["collective_verified"]["ranks"] == 2, cfg["collective_verified"]
+        par = rec["parity_vs_reference"]
+        assert par["ok"] and par["y_dx_sha256_all_ranks_match_reference_slices"] and par["reduced_within_1e-6_sum_abs_terms"], par
+        assert par["ranks_checked"] == 2 and abs(par["reduced"][0] - par["reference"][0]) <= par["budget_1e-6_sum_abs_terms"][0]
+    assert all(r["collective_verified"] and r["parity_vs_reference"] for r in s4["other_routes"].values()), s4["other_routes"]
 
 
 def test_default_line_has_secondary_records_declared():
@@ -143,6 +168,12 @@ def test_eight_ranks_control_flow_on_one_device():
     assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["config"]["parallelism"] == "dp8"
     assert out["config"]["elements_per_gpu"] == 128 * 1024 * 14 * 14 and out["config"]["global_elements"] == 1024 * 1024 * 14 * 14
     assert out["value"] > 0 and 0 < out["per_gpu_efficiency"]
+    # eight TRUE slices of [1024,1024,14,14]: every rank's y / dx match the reference's slice by sha256, every rank's contribution
+    # and the reduced sums sit within 1e-6 sum|terms| of the reference CPU csrc's d_scale / d_shift on the whole tensor
+    cv, par = out["config"]["collective_verified"], out["parity_vs_reference"]
+    assert cv["ok"] and cv["ranks"] == 8 and cv["distinct_data_per_rank"], cv
+    assert par["ok"] and par["ranks_checked"] == 8 and par["y_dx_sha256_all_ranks_match_reference_slices"], par
+    assert par["each_rank_contribution_within_1e-6_sum_abs_terms"] and par["reduced_within_1e-6_sum_abs_terms"], par
 
 
 @pytest.mark.gpu
@@ -182,8 +213,13 @@ def test_native_route_is_checked_before_anything_is_timed(how):
     out = json.loads(lines[0])
     pre = out["config"]["collective_preflight"]
     assert out["value"] > 0
+    cv, par = out["config"]["collective_verified"], out["parity_vs_reference"]
+    assert cv["ok"] and cv["ranks"] == 1, cv                 # whatever the route: the last step's sums are this rank's own
+    assert par["ok"] and par["y_dx_sha256_all_ranks_match_reference_slices"] and par["each_rank_contribution_within_1e-6_sum_abs_terms"], par
     if how == "ok":
         assert pre["ok"] and pre["route"] == "native" and out["config"]["collective"].startswith("native")
+        assert pre["events"].startswith("no system-scope fence") and "TIMED route" in pre["checked"], pre
+        assert out["config"]["communicator"]["side_stream_choice"] >= 2 and out["config"]["communicator"]["checked"]["world"] == 1
     else:
         assert not pre["ok"] and pre["route"] == "c10d" and out["config"]["collective"].startswith("c10d") and pre["why"]
         assert pre["hung"] == (how == "hung")

@@ -1,0 +1,58 @@
+"""CPU: the bookkeeping around the library's RCCL communicator (torchlsq.distributed.native_comm) that needs no GPU -- what a
+look-up may and may not decide, and that a cached communicator is re-validated against the world it is asked for."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+
+@pytest.fixture()
+def world_of_one():
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group(backend="gloo", rank=0, world_size=1)
+    from torchlsq import distributed as D
+    D._COMMS.clear()
+    yield D
+    D._COMMS.clear()
+    dist.destroy_process_group()
+
+
+def test_a_lookup_never_decides_for_later_calls(world_of_one, monkeypatch):
+    """join() -- a look-up, create=False -- before the first sharded backward must not switch the native route off for the rest
+    of the process (round-5 advisor): it caches nothing, and the next creating call still gets as far as asking for the backend"""
+    D = world_of_one
+    dev = torch.device("cuda", 0)
+    asked = []
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: asked.append(1) or "gloo")
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    D.join(None, dev)
+    assert D.native_comm(None, dev, create=False) is None
+    assert not D._COMMS and not asked, "a look-up cached a decision"
+    assert D.native_comm(None, dev) is None and asked == [1]           # the creating call decides (gloo: torch.distributed) ...
+    assert D._COMMS == {(0, 0): None}                                  # ... and only that is cached
+
+
+def test_a_cached_communicator_of_another_world_is_dropped(world_of_one, monkeypatch):
+    """dist.destroy_process_group() + a new init (or a recycled id(group)) must not be handed the old world's communicator"""
+    D = world_of_one
+    dev = torch.device("cuda", 0)
+
+    class Stale:
+        handle, nranks, rank = 1, 8, 5
+
+    class Mine:
+        handle, nranks, rank = 1, 1, 0
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "gloo")
+    D._COMMS[(0, 0)] = Stale()
+    assert D.native_comm(None, dev, create=False) is None and (0, 0) not in D._COMMS
+    mine = Mine()
+    D._COMMS[(0, 0)] = mine
+    assert D.native_comm(None, dev, create=False) is mine
+    mine.handle = None                      # destroyed behind the cache's back
+    assert D.native_comm(None, dev, create=False) is None

@@ -172,6 +172,12 @@ def test_big_row_group_workgroups_band(T):
             assert is_fat(n) == fat and n["kind"] == "row-groups" and n["ring_depth"] == 4, (shape, dt, n)
         (_, n) = _case(T, shape, 1, torch.float32)
         assert not is_fat(n), (shape, n)
+    # rows narrower than anything the round-5 sweep measured keep the usual four-wave workgroups: fewer than 16 lanes below
+    # 2^23 elements ([rows, 8 .. 120] 16-bit), fewer than 8 lanes inside the band (round-5 advisor: a 768-lane workgroup over
+    # 1-15-lane rows means hundreds of row groups and a ~100 KB combine buffer nobody timed)
+    for shape in ((65536, 64), (40000, 96), (100000, 40), (1 << 18, 16), (200000, 56)):
+        (_, n) = _case(T, shape, 1, dtype)
+        assert not is_fat(n), (shape, n)
 
 
 def test_row_group_ring_by_storage_type(T):

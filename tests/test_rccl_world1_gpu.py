@@ -38,7 +38,14 @@ for _name in ("all_reduce", "begin"):          # ... and the library's own commu
         return f
     setattr(_HH.HipComm, _name, _wrap(getattr(_HH.HipComm, _name)))
 D.assume_peers(True)                    # communicate as if there were peers
-assert D.native_comm(None, dev) is not None, "the library's RCCL communicator could not be created"   # (a collective call: id broadcast + agreement)
+_c0 = D.native_comm(None, dev)                                                                          # (a collective call: id broadcast + agreement)
+assert _c0 is not None, "the library's RCCL communicator could not be created: %%r" %% (D.LAST_FAILURE,)
+# ... and it was CHECKED before anything relies on it: the timed route carried its 128 changing reductions with unfenced events,
+# the communicator's stream was picked by lsq_hip_comm_tune (a setup call), and begin itself never had to
+_i0 = _c0.info()
+assert _c0.checked and _c0.checked["events"].startswith("no system-scope fence") and "all exact" in _c0.checked["route_check"], _c0.checked
+assert _i0["side_stream_choice"] >= 2 and _i0["event_system_fence"] == 0 and _i0["reductions_begun"] >= D.ROUTE_CHECK_REDUCTIONS, _i0
+assert D.check_timed_route(_c0, dev, 30.0) == ""
 calls["n"] = 0
 ok = True
 for per_channel in (False, True):
@@ -234,3 +241,62 @@ def test_a_communicator_that_fails_its_first_reduction_is_not_kept():
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", TORCHLSQ_COMM_CHECK_S="-1")
     r = subprocess.run([sys.executable, "-c", CHECK_CODE % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+FENCED_CODE = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%(root)r, "lsqfakequantize-pytorch_amd"))
+import torch, torch.distributed as dist
+import torchlsq
+from torchlsq import distributed as D, synth
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+D.assume_peers(True)
+D._TEST_HOOKS["unfenced_fails"] = True
+comm = D.native_comm(None, dev)
+assert comm is not None, D.LAST_FAILURE
+info = comm.info()
+assert info["event_system_fence"] == 1 and comm.checked["events"].startswith("system-fenced"), (info, comm.checked)
+# the sharded step over the re-configured communicator: same answer as the plain op
+n = 8 * 64 * 14 * 14
+x = synth.normal_like(n, 3, 0.3, 1.0, device=dev).view(8, 64, 14, 14)
+g = synth.normal_like(n, 4, 0.0, 1e-2, device=dev).view(8, 64, 14, 14)
+s, b = torch.tensor([0.03], device=dev), torch.tensor([0.05], device=dev)
+dx, wide, work = D.sharded_backward(g, x, s, b, 0, 127, 0, 255, global_numel=n, async_op=True)
+assert getattr(work, "deferred", False)
+work.wait()
+dx1, ds1, db1 = D.sharded_backward(g, x, s, b, 0, 127, 0, 255, global_numel=n, reduce=False)
+torch.cuda.synchronize()
+assert torch.equal(dx, dx1) and torch.equal(work.rounded[0].reshape(-1), ds1.reshape(-1)) and torch.equal(work.rounded[1].reshape(-1), db1.reshape(-1))
+# configure back and forth is a setup call that leaves a working communicator
+comm.configure(event_system_fence=False)
+assert comm.info()["event_system_fence"] == 0 and D.check_timed_route(comm, dev, 30.0) == ""
+# a second communicator of the process takes the parked stream of a destroyed one over (no stream left behind per communicator)
+side0 = comm.side_stream().cuda_stream
+D.destroy_native_comms()
+D._TEST_HOOKS.clear()
+comm2 = D.native_comm(None, dev)
+assert comm2 is not None and comm2 is not comm
+import ctypes
+from torchlsq import _abi
+cands_first = comm2.side_stream().cuda_stream
+print("parked stream reused or re-picked:", side0, cands_first, flush=True)
+D.destroy_native_comms()
+dist.destroy_process_group()
+print("FENCED_OK", flush=True)
+'''
+
+
+def test_the_system_fenced_fallback_of_the_route_check():
+    """native_comm step 5: when the unfenced events fail the timed route's self-check on any rank, every rank re-configures the
+    communicator with system-fenced events, checks again and keeps it -- here forced by a test hook, in an RCCL world of one"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", FENCED_CODE % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "FENCED_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
