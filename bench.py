@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- GElem/s of the LSQ fake-quantize hot path (forward op + backward op) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg1|cfg3|cfg4|cfg5|cfg5_bf16|cfg5_axis0|tok|tok_bf16|vit|vit_bf16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg1|cfg3|cfg4|cfg5|cfg5_bf16|cfg5_axis0|tok|tok_bf16|vit|vit_bf16|
+                                                                        cfg2_misaligned|cfg5[_bf16]_channels_last|cfg5[_bf16]_mixed_layout]
 
 One "step" = one forward op + one backward op (training mode) over one batch of synthetic input already resident
 in HBM.  The default workload is BASELINE.json config 2 -- per-tensor quint8, fp32 [128,512,56,56] (205.5 M elements,
@@ -64,6 +65,14 @@ WORKLOADS = {
     "cfg5_bf16": ("cfg5", "bfloat16", None),
     "cfg5_axis0": ("cfg5", "float32", 0),
     # not BASELINE configs: token-layout activations (quantized axis last), the shapes the round-1 review asked about
+    # not BASELINE configs either: the layouts the reference's TensorIterator walks in place (lsq_cpu.cpp:31-36,80-90) --
+    #   *_misaligned      x and grad are views one element into their buffers (16-byte misaligned; outputs as the op allocates them)
+    #   *_channels_last   x and grad both in channels-last memory order (per-channel on axis 1 = the memory order's LAST axis)
+    #   *_mixed_layout    channels-last x, contiguous (NCHW) grad: the host layer re-orders grad first (one copy, +2 storage
+    #                     elements of traffic per element)
+    "cfg2_misaligned": ("cfg2", "float32", None),
+    "cfg5_channels_last": ("cfg5", "float32", None), "cfg5_mixed_layout": ("cfg5", "float32", None),
+    "cfg5_bf16_channels_last": ("cfg5", "bfloat16", None), "cfg5_bf16_mixed_layout": ("cfg5", "bfloat16", None),
     "tok": ("tok", "float32", None), "tok_bf16": ("tok", "bfloat16", None),
     "vit": ("vit", "float32", None), "vit_bf16": ("vit", "bfloat16", None),
 }
@@ -562,6 +571,21 @@ def run_rank(a):
             for d_ in shape:
                 n_shard *= d_
             x, g, scale, shift = synth.make_inputs(c, device=dev, dtype=dt, shape=shape, first_index=rank * n_shard if world > 1 else 0)
+        # the layout variants (WORKLOADS): every buffer set gets the same treatment
+        def relayout(t, is_grad):
+            if workload.endswith("_misaligned"):
+                home = torch.empty(t.numel() + 4, dtype=t.dtype, device=t.device)
+                v = home[1:1 + t.numel()].view(t.shape)
+                v.copy_(t)
+                assert v.data_ptr() % 16 != 0
+                return v
+            if workload.endswith("_channels_last") or (workload.endswith("_mixed_layout") and not is_grad):
+                return t.contiguous(memory_format=torch.channels_last)
+            return t.clone()
+        if inputs is None and workload.rsplit("_", 1)[-1] in ("misaligned", "last", "layout"):
+            x, g = relayout(x, False), relayout(g, True)
+        else:
+            relayout = None
         n_local = x.numel()
         # Small workloads re-using one set of buffers are partly served by the 256 MB Infinity Cache (config 5 streams 308 MB per
         # step in fp32, 154 MB in bf16), which is not the HBM rate the roofline is about: the steps rotate through `n_sets`
@@ -582,8 +606,8 @@ def run_rank(a):
         else:
             xs, gs = [x], [g]
             for _ in range(n_sets - 1):
-                xs.append(x.clone())
-                gs.append(g.clone())
+                xs.append(relayout(x, False) if relayout else x.clone())
+                gs.append(relayout(g, True) if relayout else g.clone())
         cur = [0]
 
         def bset():       # the backward works on a set the forward touched n_sets / 2 steps ago: not on lines the forward just read
@@ -918,6 +942,10 @@ def run_rank(a):
             "config": {"workload": "%s: %s %s %s per GPU, %s%s" % (a.workload, what, dtype_name, shape, opnames,
                                                                     "" if world == 1 else ", batch-sharded, 1 RCCL all-reduce of fp64 [ds,db] per step"),
                        "storage": dtype_name, "arithmetic": "float32",
+                       "layout": ("x and grad one element into their buffers (16-byte misaligned views)" if a.workload.endswith("_misaligned") else
+                                  "x and grad in channels-last memory order: the kernels see [N*H*W, C, 1]" if a.workload.endswith("_channels_last") else
+                                  "channels-last x, contiguous grad: the host layer re-orders grad into x's memory order first (a copy)"
+                                  if a.workload.endswith("_mixed_layout") else "contiguous"),
                        "elements_per_gpu": n_local, "global_elements": n_global,
                        "parallelism": "dp%d" % world, "host_binding": binding,
                        "launch": ("hip-graph replay (%d steps per graph launch)" % m["graph_steps"]) if a.graph else "eager",

@@ -341,6 +341,16 @@ int lsq_hip_comm_all_reduce_begin(lsq_comm* comm, const void* send, void* recv, 
                                   void* stream, int32_t* ticket);
 int lsq_hip_comm_all_reduce_end(lsq_comm* comm, int32_t ticket, void* stream);
 
+/* ---- a gradient in another dense memory order than its input -------------------------------------------- */
+
+/* dst[a][c][b] = src[a][b][c] for dense arrays of `dtype` elements (a < A, b < B, c < C): the batched transposition that
+ * takes a contiguous NCHW gradient into the memory order of a channels-last input (A = N, B = C, C = H*W) or back (B = H*W,
+ * C = C).  The reference's backward meets grad and x element by element through one TensorIterator whatever their strides
+ * (lsq_cpu.cpp:80-90, :229-249); these kernels walk x's memory order, so the host layers bring such a grad into it first --
+ * with this pass (LDS tiles, both sides coalesced) instead of the framework's generic strided copy (2.5 x slower on MI355X,
+ * profiles/r06_layout_workloads.txt).  src and dst must not overlap; element-aligned pointers. */
+int lsq_hip_relayout(int dtype, const void* src, void* dst, int64_t a, int64_t b, int64_t c, void* stream);
+
 /* ---- eval-mode backward from the saved mask ---------------------------------------------------- */
 
 /* dx = grad * mask for the eval-mode / plain fake-quantizer backward (lsq_kernel.h:126-145: dX only,

@@ -334,6 +334,17 @@ int lsq_hip_sharded_finish(int dtype, const double* packed, int64_t channels, in
     return hip_status(e, "lsq_hip_sharded_finish");
 }
 
+int lsq_hip_relayout(int dtype, const void* src, void* dst, int64_t a, int64_t b, int64_t c, void* stream) {
+    if (dtype < LSQ_F32 || dtype > LSQ_F16) return fail(LSQ_EINVAL, "relayout: unknown dtype %d", dtype);
+    if (a < 0 || b < 0 || c < 0) return fail(LSQ_EINVAL, "relayout: negative extent");
+    if (a == 0 || b == 0 || c == 0) return LSQ_OK;
+    if (!src || !dst) return fail(LSQ_EINVAL, "relayout: NULL buffer");
+    const int esz = dtype == LSQ_F64 ? 8 : (dtype == LSQ_F32 ? 4 : 2);
+    if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & static_cast<uintptr_t>(esz - 1))
+        return fail(LSQ_EINVAL, "relayout: buffers must be element-aligned");
+    return hip_status(lsq::relayout(esz, src, dst, a, b, c, static_cast<hipStream_t>(stream)), "lsq_hip_relayout");
+}
+
 #ifdef LSQ_TOOLS
 void lsq_hip_debug_set_observe_wg_per_cu(int v) { lsq::knob::set(lsq::knob::kObserveWgPerCu, v); }
 void lsq_hip_debug_force_ring(int v) { lsq::knob::set(lsq::knob::kForceRing, v < 0 || v > 2 ? 0 : v); }

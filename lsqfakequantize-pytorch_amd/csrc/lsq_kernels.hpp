@@ -218,6 +218,9 @@ inline LaunchNote& last_launch_note() {
 #endif
 
 inline bool is_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+// a pointer to storage elements that is a multiple of the element size (every tensor view is; a raw C caller may not be)
+template <typename IO>
+inline bool is_elem_aligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (sizeof(typename IO::elem) - 1u)) == 0; }
 
 template <typename T>
 inline Range<T> make_range(const lsq_params& p) {
@@ -349,6 +352,7 @@ template <typename IO>
 hipError_t backward_per_channel_multi(const lsq_pc_item* items, int32_t count, const lsq_params& p, hipStream_t stream);
 
 // batch-sharded backward: scaler from the global element count + rounding, after the all-reduce (lsq_per_tensor.hip)
+hipError_t relayout(int elem_bytes, const void* src, void* dst, int64_t A, int64_t B, int64_t C, hipStream_t stream);   // lsq_relayout.hip
 template <typename T>
 hipError_t sharded_finish(const double* packed, int64_t channels, bool per_channel, const lsq_params& p, void* ds, void* db,
                           hipStream_t stream);

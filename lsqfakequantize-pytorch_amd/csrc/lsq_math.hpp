@@ -287,6 +287,21 @@ __device__ __forceinline__ void store_out(void* p, int64_t i, typename IO::arith
 }
 
 // A 16-byte packet of IO::VEC storage elements, moved with one global_load/store_dwordx4.
+// The packet pointer is only promised ELEMENT alignment (PacketWord: a 16-byte vector type declared with the alignment of
+// one storage element): gfx9 under HSA runs with unaligned access enabled, the compiler knows it (it emits the same single
+// global_load_dwordx4 / global_store_dwordx4 either way: tests/test_device_code.py) and the hardware splits an access that
+// straddles a cache line itself.  That is what lets a sliced view -- x[1:], a storage offset that is not a multiple of 16
+// bytes, buffers whose offsets differ from each other -- run the packet kernels instead of one element per lane
+// (reference: TensorIterator walks any view in place, lsq_cpu.cpp:31-36,80-90).
+template <int ELEM_BYTES> struct PacketWordOf;
+template <> struct PacketWordOf<2> { typedef __attribute__((ext_vector_type(4))) unsigned int type __attribute__((aligned(2))); };
+template <> struct PacketWordOf<4> { typedef __attribute__((ext_vector_type(4))) unsigned int type __attribute__((aligned(4))); };
+template <> struct PacketWordOf<8> { typedef __attribute__((ext_vector_type(4))) unsigned int type __attribute__((aligned(8))); };
+template <typename IO>
+struct PacketWord {
+    typedef typename PacketWordOf<static_cast<int>(sizeof(typename IO::elem))>::type type;
+};
+
 template <typename IO>
 struct alignas(16) Packet {
     typename IO::elem v[IO::VEC];
@@ -295,7 +310,7 @@ struct alignas(16) Packet {
 template <typename IO>
 __device__ __forceinline__ Packet<IO> load_packet(const void* base, int64_t elem_index) {
     using V4 = __attribute__((ext_vector_type(4))) unsigned int;
-    const V4 raw = *reinterpret_cast<const V4*>(static_cast<const typename IO::elem*>(base) + elem_index);
+    const V4 raw = *reinterpret_cast<const typename PacketWord<IO>::type*>(static_cast<const typename IO::elem*>(base) + elem_index);
     Packet<IO> p;
     __builtin_memcpy(&p, &raw, 16);
     return p;
@@ -305,7 +320,7 @@ template <typename IO>
 __device__ __forceinline__ Packet<IO> load_packet_nt(const void* base, int64_t elem_index) {
     using V4 = __attribute__((ext_vector_type(4))) unsigned int;
     const V4 raw = __builtin_nontemporal_load(
-        reinterpret_cast<const V4*>(static_cast<const typename IO::elem*>(base) + elem_index));
+        reinterpret_cast<const typename PacketWord<IO>::type*>(static_cast<const typename IO::elem*>(base) + elem_index));
     Packet<IO> p;
     __builtin_memcpy(&p, &raw, 16);
     return p;
@@ -316,7 +331,7 @@ __device__ __forceinline__ void store_packet(void* base, int64_t elem_index, con
     using V4 = __attribute__((ext_vector_type(4))) unsigned int;
     V4 raw;
     __builtin_memcpy(&raw, &p, 16);
-    *reinterpret_cast<V4*>(static_cast<typename IO::elem*>(base) + elem_index) = raw;
+    *reinterpret_cast<typename PacketWord<IO>::type*>(static_cast<typename IO::elem*>(base) + elem_index) = raw;
 }
 
 template <typename IO>
@@ -324,7 +339,7 @@ __device__ __forceinline__ void store_packet_nt(void* base, int64_t elem_index, 
     using V4 = __attribute__((ext_vector_type(4))) unsigned int;
     V4 raw;
     __builtin_memcpy(&raw, &p, 16);
-    __builtin_nontemporal_store(raw, reinterpret_cast<V4*>(static_cast<typename IO::elem*>(base) + elem_index));
+    __builtin_nontemporal_store(raw, reinterpret_cast<typename PacketWord<IO>::type*>(static_cast<typename IO::elem*>(base) + elem_index));
 }
 
 // ---- wave64 / block reductions -----------------------------------------------------------------

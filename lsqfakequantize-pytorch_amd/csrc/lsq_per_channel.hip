@@ -402,8 +402,11 @@ __global__ __launch_bounds__(kBlock) void fwd_pc_kernel(const void* __restrict__
 // numbered with a ballot + popcount and the scan is keyed by run id, not by channel).  After
 // log2(64) shuffle steps the first lane of every run owns the run total and adds it to the
 // window's LDS slot with an LDS fp64 atomic (ds_add_f64).
+// The two halves are separate so that the shuffles of all waves run side by side while the ADDS can be made in wave order
+// (bwd_pc_kernel's epilogue): segmented_wave_reduce leaves the run total in (s, b) of the run's first lane and says whether
+// this lane is one that adds; segmented_wave_commit adds.
 template <bool SYM>
-__device__ __forceinline__ void segmented_wave_accumulate(int key, double s, double b, double* lds_s, double* lds_b) {
+__device__ __forceinline__ bool segmented_wave_reduce(int key, double& s, double& b) {
     const int lane = threadIdx.x & 63;
     const int prev = __shfl_up(key, 1, 64);
     const bool head = (lane == 0) || (prev != key);
@@ -419,7 +422,11 @@ __device__ __forceinline__ void segmented_wave_accumulate(int key, double s, dou
             if (!SYM) b += ob;
         }
     }
-    if (head && key >= 0) {
+    return head && key >= 0;
+}
+template <bool SYM>
+__device__ __forceinline__ void segmented_wave_commit(bool adds, int key, double s, double b, double* lds_s, double* lds_b) {
+    if (adds) {
         __hip_atomic_fetch_add(&lds_s[key], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (!SYM) __hip_atomic_fetch_add(&lds_b[key], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -983,6 +990,24 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
         return;
     }
 
+    // The window's slots take the waves' run totals with LDS fp64 atomics.  One slot set per workgroup (256-lane windows):
+    // the adds are made in WAVE ORDER -- wave w adds between barrier w and barrier w + 1; inside a wave the order is the
+    // program's and the LDS unit's lane order -- so the partial row a workgroup publishes, and with it d_scale / d_shift / the
+    // un-rounded sums the sharded path all-reduces, are the same bits launch after launch (until round 6 the four waves added in
+    // arrival order: two launches could differ by an fp64 rounding).  The shuffles above ran in all waves at once; what is
+    // serialised is one or two LDS atomics per lane.  Owner windows keep a slot set per wave (added in wave order below).
+    const int my_wave = static_cast<int>(threadIdx.x >> 6);
+    auto in_wave_order = [&](auto&& adds_fn) {
+        if constexpr (OWN) {
+            adds_fn();
+            __syncthreads();
+        } else {
+            for (int w = 0; w < BLOCK / 64; ++w) {
+                if (my_wave == w) adds_fn();
+                __syncthreads();
+            }
+        }
+    };
     if (CPL == 2) {
         // components below `split` -> first channel, the rest -> second channel (two disjoint sums: a
         // non-finite term of one channel never reaches the other).  The second channel of lane i is
@@ -1006,18 +1031,22 @@ __global__ __launch_bounds__(BLOCK) void bwd_pc_kernel(const void* __restrict__ 
         const double give_s = handoff ? hi_s : 0.0, give_b = handoff ? hi_b : 0.0;
         const double got_s = shfl_up_f64(give_s, 1), got_b = shfl_up_f64(give_b, 1);
         if (lane > 0) { lo_s += got_s; lo_b += got_b; }
-        if (has_hi && !handoff) {
-            __hip_atomic_fetch_add(&lds_s[key_hi], hi_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (!SYM) __hip_atomic_fetch_add(&lds_b[key_hi], hi_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        segmented_wave_accumulate<SYM>(site.counts ? ch.key[0] : -1, lo_s, lo_b, lds_s, lds_b);
+        const int key_lo = site.counts ? ch.key[0] : -1;
+        const bool adds_lo = segmented_wave_reduce<SYM>(key_lo, lo_s, lo_b);
+        in_wave_order([&]() {
+            segmented_wave_commit<SYM>(has_hi && !handoff, key_hi, hi_s, hi_b, lds_s, lds_b);
+            segmented_wave_commit<SYM>(adds_lo, key_lo, lo_s, lo_b, lds_s, lds_b);
+        });
     } else {
         // lanes -> window slots.  Dead lanes carry key -1 (never written).
+        bool adds[LC::N];
 #pragma unroll
-        for (int j = 0; j < LC::N; ++j)
-            segmented_wave_accumulate<SYM>(site.counts ? ch.key[j] : -1, acc_s[j], acc_b[j], lds_s, lds_b);
+        for (int j = 0; j < LC::N; ++j) adds[j] = segmented_wave_reduce<SYM>(site.counts ? ch.key[j] : -1, acc_s[j], acc_b[j]);
+        in_wave_order([&]() {
+#pragma unroll
+            for (int j = 0; j < LC::N; ++j) segmented_wave_commit<SYM>(adds[j], ch.key[j], acc_s[j], acc_b[j], lds_s, lds_b);
+        });
     }
-    __syncthreads();
     if constexpr (OWN) {
         // every element of these channels went through this workgroup: the slots are the channels' totals
         for (int k = threadIdx.x; k < g.k_slots; k += static_cast<int>(blockDim.x)) {

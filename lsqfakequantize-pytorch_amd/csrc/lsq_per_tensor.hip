@@ -109,7 +109,8 @@ __global__ __launch_bounds__(kBlock) void fwd_pt_kernel(const void* __restrict__
     }
 }
 
-// scalar fallback for buffers that are not 16-byte aligned (sliced views): 1 element per lane
+// scalar form, 1 element per lane: only where packets cannot be used at all -- a `levels` buffer that is not 8-byte
+// aligned.  Views whose buffers are merely not 16-byte aligned run the packet kernel above (lsq_math.hpp, PacketWord).
 template <typename IO, bool INIT, bool LEVELS>
 __global__ __launch_bounds__(kBlock) void fwd_pt_scalar_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                                int8_t* __restrict__ levels, int level_bias, int aux_kind,
@@ -329,7 +330,8 @@ static hipError_t launch_fwd_pt(const void* x, void* y, int8_t* levels, int leve
     const Range<T> r = make_range<T>(p);
     const T* sc = static_cast<const T*>(scale);
     const T* sh = static_cast<const T*>(shift);
-    const bool aligned = is_aligned16(x) && is_aligned16(y);
+    // packets need element alignment only (PacketWord); the 8 / 4 level bytes of a packet are stored as one word
+    const bool aligned = is_elem_aligned<IO>(x) && is_elem_aligned<IO>(y) && (!levels || (reinterpret_cast<uintptr_t>(levels) & 7u) == 0);
     const DeviceInfo& dev = device_info();
     if (!aligned) {
         const int64_t want = (n + kBlock - 1) / kBlock;
@@ -395,7 +397,7 @@ static hipError_t launch_bwd_pt(const void* grad, const void* x, void* dx, void*
     const int64_t n4s = p.numel_for_scaler > 0 ? p.numel_for_scaler : n;
     const T gs = grad_scaler_per_tensor<T>(n4s, p.quant_max, p.use_grad_scaling != 0, p.grad_scaler);
     double2* partials = static_cast<double2*>(workspace);
-    const bool aligned = is_aligned16(grad) && is_aligned16(x) && is_aligned16(dx);
+    const bool aligned = is_elem_aligned<IO>(grad) && is_elem_aligned<IO>(x) && is_elem_aligned<IO>(dx);    // (PacketWord: any view)
     const Variant v = decode_variant(variant, kDefaultBwdVariant);
     const int grid = bwd_pt_grid(n, IO::VEC, v, aligned);
     const T sym_term = static_cast<T>(0) * gs;
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(kBlock) void bwd_mask_kernel(const void* __restrict
 template <typename IO>
 hipError_t backward_from_mask(const void* grad, const void* mask, void* dx, int64_t n, hipStream_t stream) {
     const DeviceInfo& dev = device_info();
-    const bool aligned = is_aligned16(grad) && is_aligned16(dx) && (reinterpret_cast<uintptr_t>(mask) & 7u) == 0;
+    const bool aligned = is_elem_aligned<IO>(grad) && is_elem_aligned<IO>(dx) && (reinterpret_cast<uintptr_t>(mask) & 7u) == 0;
     constexpr int kU = 4;
     const int64_t tile = static_cast<int64_t>(kBlock) * kU * IO::VEC;
     const int64_t want = std::max<int64_t>(1, (n + tile - 1) / tile);

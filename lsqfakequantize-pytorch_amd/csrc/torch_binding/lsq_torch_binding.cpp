@@ -26,6 +26,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <array>
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <limits>
@@ -143,14 +144,52 @@ Geometry geometry(const Tensor& t, int64_t axis) {
     return {outer, c, inner};
 }
 
+void* stream_of(const Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+// memory order of a dense tensor: its non-unit dims, slowest first (empty: not dense)
+std::vector<int64_t> physical_order(const Tensor& t) {
+    std::vector<int64_t> dims;
+    for (int64_t d = 0; d < t.dim(); ++d)
+        if (t.size(d) != 1) dims.push_back(d);
+    std::stable_sort(dims.begin(), dims.end(), [&](int64_t a, int64_t b) { return t.stride(a) > t.stride(b); });
+    int64_t expect = 1;
+    for (auto it = dims.rbegin(); it != dims.rend(); ++it) {
+        if (t.stride(*it) != expect) return {};
+        expect *= t.size(*it);
+    }
+    return dims;
+}
+
+// grad laid out exactly like the dense xd.  Two dense orders that differ by ONE swap of adjacent dimension groups -- g's memory
+// [A][B][C], xd's [A][C][B]: a contiguous NCHW gradient for a channels-last input, or the reverse -- go through the library's
+// tiled pass (lsq_hip_relayout); anything else through Tensor.copy_ (torchlsq/_hip_host.py: _like_layout, the same rule).
 Tensor like_layout(const Tensor& g, const Tensor& xd) {
     if (g.sizes() == xd.sizes() && g.strides() == xd.strides()) return g;
     Tensor out = at::empty_like(xd);  // preserve_format keeps the strides of the dense xd
+    if (g.is_cuda() && g.sizes() == xd.sizes() && g.scalar_type() == xd.scalar_type() && g.device() == xd.device()) {
+        const std::vector<int64_t> og = physical_order(g), ox = physical_order(xd);
+        if (!og.empty() && og.size() == ox.size() && og != ox) {
+            size_t k0 = 0;
+            while (og[k0] == ox[k0]) ++k0;
+            const size_t n = og.size() - k0;
+            for (size_t k = 1; k < n; ++k) {
+                bool rotated = true;
+                for (size_t i = 0; i < n && rotated; ++i) rotated = og[k0 + (k + i) % n] == ox[k0 + i];
+                if (!rotated) continue;
+                int64_t A = 1, B = 1, C = 1;
+                for (size_t i = 0; i < k0; ++i) A *= g.size(og[i]);
+                for (size_t i = 0; i < k; ++i) B *= g.size(og[k0 + i]);
+                for (size_t i = k; i < n; ++i) C *= g.size(og[k0 + i]);
+                c10::DeviceGuard guard(xd.device());
+                status(lsq_hip_relayout(dtype_code(g.scalar_type(), "lsq_backward"), g.data_ptr(), out.data_ptr(), A, B, C, stream_of(xd)),
+                       "lsq_hip_relayout");
+                return out;
+            }
+        }
+    }
     out.copy_(g.sizes() == xd.sizes() ? g : g.reshape(xd.sizes()));
     return out;
 }
-
-void* stream_of(const Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
 
 Tensor byte_workspace(const Tensor& like, size_t nbytes) {
     return at::empty({static_cast<int64_t>(nbytes < 256 ? 256 : nbytes)}, like.options().dtype(at::kByte));

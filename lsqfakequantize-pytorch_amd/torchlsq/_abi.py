@@ -99,6 +99,7 @@ C_ABI = {
     "lsq_hip_comm_all_reduce_end": (_int, [_vp, ctypes.c_int32, _vp]),
     "lsq_hip_forward_per_channel_multi": (_int, [_int, ctypes.POINTER(LsqPcItem), ctypes.c_int32, _PP, _vp]),
     "lsq_hip_backward_per_channel_multi": (_int, [_int, ctypes.POINTER(LsqPcItem), ctypes.c_int32, _PP, _vp]),
+    "lsq_hip_relayout": (_int, [_int, _vp, _vp, _i64, _i64, _i64, _vp]),
     "lsq_hip_backward_from_mask": (_int, [_int, _vp, _vp, _vp, _i64, _vp]),
     "lsq_hip_minmax_workspace": (_sz, [_int, _i64, _i64, _i64]),
     "lsq_hip_minmax_per_tensor": (_int, [_int, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),

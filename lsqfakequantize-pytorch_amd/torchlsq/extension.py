@@ -25,7 +25,7 @@ from ._abi import (ABI_VERSION, C_ABI, C_ABI_CPU, _assert_has_ops, _check_hip_ve
 from ._hip_host import *  # noqa: F401,F403
 from ._hip_host import (_SINGLE_LAUNCH_BWD, _TICKET_SLABS, _TICKETS, _WS_BYTES_PC, _WS_BYTES_PT, _check, _dense,  # noqa: F401
                         _wants_ticket,
-                        _like_layout, _ocl, _param_dtype, _params, _physical_order, _ROW_MAJOR, hip_backward_from_mask,
+                        _like_layout, _ocl, _param_dtype, _params, _physical_order, _ROW_MAJOR, _transposition, hip_backward_from_mask,
                         hip_backward_per_channel, hip_backward_per_channel_multi, hip_backward_per_tensor,
                         hip_forward_per_channel, hip_forward_per_channel_multi, hip_forward_per_tensor, hip_meanstd,
                         hip_minmax, hip_multi_eligible, hip_observer_update, hip_plan_backward_per_channel, hip_sharded_finish, HipComm, LSQ_COMM_ID_BYTES,

@@ -23,7 +23,7 @@ def _declared():
 
 def test_header_symbols_are_exported():
     names = _declared()
-    assert len(names) == 36, names
+    assert len(names) == 37, names
     nm = subprocess.run(["nm", "-D", "--defined-only", LIB], capture_output=True, text=True, check=True).stdout
     exported = sorted(set(l.split()[-1] for l in nm.splitlines() if " T " in l and l.split()[-1].startswith("lsq_")))
     # exported == declared, not a superset: no `_ex` twin, no lsq_hip_debug_* knob, nothing else with C linkage

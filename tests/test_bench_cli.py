@@ -127,11 +127,17 @@ def test_default_line_carries_the_per_channel_half():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     sec = {s["workload"]: s for s in out["secondary"]}
-    assert sorted(sec) == ["cfg1", "cfg1_graph", "cfg3", "cfg3_graph", "cfg3_x50_foreach", "cfg4_shard", "cfg4_shard_collective", "cfg5",
-                           "cfg5_bf16"]
+    assert sorted(sec) == ["cfg1", "cfg1_graph", "cfg2_sustained", "cfg3", "cfg3_graph", "cfg3_x50_foreach", "cfg4_shard",
+                           "cfg4_shard_collective", "cfg5", "cfg5_bf16"]
     for name, s in sec.items():
         assert "error" not in s and s["value"] > 0 and 0 < s["step_frac"] < 1, s
         assert s["launch"] == ("graph" if name.endswith("_graph") else "eager")
+    # the headline next to itself for >= 1 s (events on 1 % of the steps): both figures in `roofline`, both above the target
+    sus = out["roofline"]["sustained"]
+    assert sec["cfg2_sustained"]["wall_s"] >= 1.0 and sus["steps"] >= 300 and sus["launches_timed"] >= 3, sus
+    assert sus["step_frac"] >= 0.70 and out["roofline"]["step_frac"] >= 0.70, (sus, out["roofline"]["step_frac"])
+    # the sharded step's record proves its own sums (a world of one: this rank's contribution) against the reference's shard 0 of 8
+    assert sec["cfg4_shard_collective"]["collective_verified"]["ok"] and sec["cfg4_shard_collective"]["parity_vs_reference"]["ok"]
     assert "ms_per_step_ctypes_binding" in sec["cfg1"] and sec["cfg5_bf16"]["storage"] == "bfloat16"
     # the headline workload through the Python / ctypes host layer north_star describes, next to the C++ binding's figure,
     # measured on the timed region's own buffers with the per-op split

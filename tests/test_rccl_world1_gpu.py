@@ -67,8 +67,16 @@ for per_channel in (False, True):
             before = calls["n"]
             D.lsq_sharded(xs, ss, bs, global_numel=mode, **kw).backward(g)
             torch.cuda.synchronize()
-            good = (torch.equal(xs.grad, xf.grad) and torch.allclose(ss.grad, sf.grad, rtol=2e-6, atol=0) and
-                    torch.allclose(bs.grad, bf.grad, rtol=2e-6, atol=1e-12) and calls["n"] - before == 1)
+            if mode == D.COLLECTIVE:
+                # the count travels in the collective: the gradient scaler multiplies the fp64 SUM once instead of every fp32 term
+                # (include/lsq_hip.h, lsq_hip_sharded_finish) -- up to 2^-24 per term relative to sum|terms|, i.e. inside
+                # north_star's 1e-6 * sum|terms|; measured here against |sum| itself, which on these mostly one-signed sums
+                # (grad = |.|) is within a factor two of sum|terms|: hence 2e-6, not a looser bar
+                sums = torch.allclose(ss.grad, sf.grad, rtol=2e-6, atol=0) and torch.allclose(bs.grad, bf.grad, rtol=2e-6, atol=1e-12)
+            else:
+                # the count known up front: an identity all-reduce of the same fp64 sums, rounded once -- the plain op's bits
+                sums = torch.equal(ss.grad, sf.grad) and torch.equal(bs.grad, bf.grad)
+            good = torch.equal(xs.grad, xf.grad) and sums and calls["n"] - before == 1
             ok = ok and good
             print(per_channel, dtype, mode if mode == D.COLLECTIVE else "int", good, calls["n"] - before, flush=True)
 # bench.py's pattern: the collective issued async, consumed one step later
@@ -126,6 +134,9 @@ for obs_cls, extra in ((MovingAverageMinMaxObserver, {}), (MovingAveragePerChann
         torch.cuda.synchronize()
         good = torch.equal(ya.detach(), yp.detach()) and torch.equal(a.scale, p.scale) and torch.equal(a.shift, p.shift)
         if a.scale.grad is not None and p.scale.grad is not None:
+            # (the synchronised module takes the counted route above -- scaler on the sum -- and these activation gradients are
+            #  mixed-sign sums: |sum| is ~10 x smaller than sum|terms|, so 1e-6 * sum|terms| reads as 2e-5 of the sum; the arithmetic
+            #  bar itself is held against the oracle in tests/test_module_sync_gpu.py / test_sharded_gpu.py)
             good = good and torch.allclose(a.scale.grad, p.scale.grad, rtol=2e-5, atol=1e-12) and torch.allclose(a.shift.grad, p.shift.grad, rtol=2e-5, atol=1e-10)
         ok = ok and good
         print("module", obs_cls.__name__, "call", i, good, "collectives", calls["n"] - before, flush=True)

@@ -3,8 +3,9 @@
 Two processes share cuda:0 (the 1-GPU test box; the RCCL transport itself cannot be exercised there -- RCCL refuses two
 ranks on one device -- so the collective runs over gloo, which stages the 16-byte fp64 pair through the host).  What this
 pins on the device: the `*_wide` ops (un-rounded fp64 sums, global element count in the gradient scaler), the single
-all-reduce, and that the sharded result equals the unsharded op on the concatenated tensor: y, dx bit-exact per shard;
-d_scale / d_shift to 1e-6.
+all-reduce, and that the sharded result equals the reference's (the pinned oracle's) on the concatenated tensor: y, dx
+bit-exact per shard; d_scale / d_shift within 1e-6 * sum|terms| (north_star's bar), and the GPU's own unsharded op bit for bit
+in y / dx.
 """
 import os
 import socket
@@ -74,10 +75,25 @@ def _worker(rank, world, port, per_channel, dtype_name, out_q, shape=(64, 48, 14
         ys = lsq_sharded(xs, ss, bs, **kw)
         ys.backward(g[sl])
         torch.cuda.synchronize()
-        err_s = float(((ss.grad - sf.grad).abs() / sf.grad.abs().clamp_min(1e-30)).max())
-        err_b = float(((bs.grad - bf.grad).abs() / bf.grad.abs().clamp_min(1e-30)).max())
-        ok = (torch.equal(ys, yf[sl]) and torch.equal(xs.grad, xf.grad[sl]) and err_s <= 2e-6 and err_b <= 2e-6
-              and calls["n"] == 1)
+        # the bar is north_star's: against the ORACLE (pinned to the reference CPU csrc) on the CONCATENATED tensor -- fp32 math on
+        # the stored values, for 16-bit storage too --, |got - ref| <= 1e-6 * sum|terms| per channel; y and dx bit-exact
+        sys.path.insert(0, ROOT)
+        from oracle import lsq_oracle as O
+        xn, gn = x.float().cpu().numpy(), g.float().cpu().numpy()
+        q4 = (kw["quant_min"], kw["quant_max"], kw["type_min"], kw["type_max"])
+        if per_channel:
+            outer, Cc, inner = O.axis_to_ocl(xn.shape, 1)
+            ref = O.bwd_pc(gn, xn, scale.cpu().numpy(), shift.cpu().numpy(), outer, Cc, inner, *q4, True, 1.0, False)
+            oy = O.fwd_pc(xn, scale.cpu().numpy(), shift.cpu().numpy(), outer, Cc, inner, *q4)
+        else:
+            ref = O.bwd_pt(gn, xn, float(scale[0]), float(shift[0]), *q4, True, 1.0, False)
+            oy = O.fwd_pt(xn, float(scale[0]), float(shift[0]), *q4)
+        err_s = float((np.abs(ss.grad.double().cpu().numpy() - ref.ds_wide) / np.maximum(ref.abs_ds, 1e-300)).max())
+        err_b = float((np.abs(bs.grad.double().cpu().numpy() - ref.db_wide) / np.maximum(ref.abs_db, 1e-300)).max())
+        oy_t = torch.from_numpy(oy.reshape(shape)).to(dtype)
+        odx_t = torch.from_numpy(ref.dx.reshape(shape)).to(dtype)
+        ok = (torch.equal(ys.cpu(), oy_t[sl]) and torch.equal(xs.grad.cpu(), odx_t[sl]) and err_s <= 1e-6 and err_b <= 1e-6
+              and torch.equal(ys, yf[sl]) and torch.equal(xs.grad, xf.grad[sl]) and calls["n"] == 1)
         out_q.put((rank, bool(ok), calls["n"], err_s, err_b))
     finally:
         dist.destroy_process_group()
@@ -98,7 +114,7 @@ def test_sharded_equals_unsharded_on_the_gpu(per_channel, dtype_name):
         p.join(timeout=120)
         assert p.exitcode == 0
     for rank, ok, ncalls, err_s, err_b in res:
-        assert ok, "rank %d: sharded != unsharded (all_reduce calls %d, rel err ds %g db %g)" % (rank, ncalls, err_s, err_b)
+        assert ok, "rank %d: sharded != oracle on the whole batch (all_reduce calls %d, err / sum|terms| ds %g db %g)" % (rank, ncalls, err_s, err_b)
 
 
 def test_config4_per_rank_shard_over_two_ranks():
@@ -117,4 +133,4 @@ def test_config4_per_rank_shard_over_two_ranks():
         p.join(timeout=120)
         assert p.exitcode == 0
     for rank, ok, ncalls, err_s, err_b in res:
-        assert ok, "rank %d: sharded != unsharded (all_reduce calls %d, rel err ds %g db %g)" % (rank, ncalls, err_s, err_b)
+        assert ok, "rank %d: sharded != oracle on the whole batch (all_reduce calls %d, err / sum|terms| ds %g db %g)" % (rank, ncalls, err_s, err_b)

@@ -42,3 +42,27 @@ rows = [("python loop + lambda call", lambda: None),
 print("# host microseconds per call, GPU not waited for (cfg3 tensors, %d calls, best of 5)" % N)
 for name, fn in rows:
     print("%-64s %6.2f us" % (name, per_call(fn)))
+
+# BASELINE config 1 -- the size real activation quantizers have (reference quantized/modules/observers.py:458-461 calls
+# functional.lsq once per activation and step): the per-tensor ops, the functional entry point with autograd, the module
+x1, g1, s1, b1 = synth.make_inputs("cfg1", device=dev, dtype=torch.float32)
+q1 = (0, 127, 0, 255, True, 1.0, False, False, False)
+f1, b1op = ns.lsq_forward_per_tensor.default, ns.lsq_backward_per_tensor.default
+from torchlsq.functional import lsq
+xr, sr, br = x1.clone().requires_grad_(True), s1.clone().requires_grad_(True), b1.clone().requires_grad_(True)
+
+
+def step_functional():
+    y = lsq(xr, sr, br, 0, 127, 0, 255)
+    y.backward(g1)
+    xr.grad = None; sr.grad = None; br.grad = None
+
+
+rows1 = [("cfg1 forward op (per-tensor), default overload", lambda: f1(x1, s1, b1, *q1)),
+         ("cfg1 backward op (per-tensor; one launch with its ticket)", lambda: b1op(g1, x1, s1, b1, *q1)),
+         ("cfg1 forward + backward ops (the bench's step)", lambda: (f1(x1, s1, b1, *q1), b1op(g1, x1, s1, b1, *q1))),
+         ("two ATen single-launch ops: torch.add(x, g); torch.mul(x, g)", lambda: (torch.add(x1, g1), torch.mul(x1, g1))),
+         ("functional.lsq(...) forward + .backward(g) (C++ front op + autograd node)", step_functional)]
+print("# BASELINE config 1 [4,64,56,56] fp32 (0.8 M elements: ~3 us of GPU time per op -- the host is the bottleneck)")
+for name, fn in rows1:
+    print("%-78s %6.2f us" % (name, per_call(fn)))
