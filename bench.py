@@ -1015,7 +1015,7 @@ def run_rank(a):
             # the two the 70 % claim rests on (both must clear it).
             try:
                 per = elapsed_max / m["steps"]
-                sus_steps = int(min(6000, max(300, -(-1.05 // per)))) // 100 * 100
+                sus_steps = int(min(6000, max(300, -(-(1.1 / per) // 100) * 100)))       # >= 1.1 s of steps, a multiple of 100
                 sm = measure("cfg2", sus_steps, 0, inputs=(m["xs"], m["gs"], m["scale"], m["shift"]), event_every=100)
                 s_wall = sm["elapsed_max"] / sm["steps"]
                 s_bwd = bytes_bwd * n_local / (sm["bwd_avg"] * 1e-3) / 1e9
