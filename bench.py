@@ -2,7 +2,7 @@
 """bench.py -- GElem/s of the LSQ fake-quantize hot path (forward op + backward op) on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg1|cfg3|cfg4|cfg5|cfg5_bf16|cfg5_axis0|tok|tok_bf16|vit|vit_bf16|
-                                                                        cfg2_misaligned|cfg5[_bf16]_channels_last|cfg5[_bf16]_mixed_layout]
+                                                                        cfg2_misaligned|cfg5[_bf16]_misaligned|cfg5[_bf16]_channels_last|cfg5[_bf16]_mixed_layout]
 
 One "step" = one forward op + one backward op (training mode) over one batch of synthetic input already resident
 in HBM.  The default workload is BASELINE.json config 2 -- per-tensor quint8, fp32 [128,512,56,56] (205.5 M elements,
@@ -71,6 +71,7 @@ WORKLOADS = {
     #   *_mixed_layout    channels-last x, contiguous (NCHW) grad: the host layer re-orders grad first (one copy, +2 storage
     #                     elements of traffic per element)
     "cfg2_misaligned": ("cfg2", "float32", None),
+    "cfg5_misaligned": ("cfg5", "float32", None), "cfg5_bf16_misaligned": ("cfg5", "bfloat16", None),
     "cfg5_channels_last": ("cfg5", "float32", None), "cfg5_mixed_layout": ("cfg5", "float32", None),
     "cfg5_bf16_channels_last": ("cfg5", "bfloat16", None), "cfg5_bf16_mixed_layout": ("cfg5", "bfloat16", None),
     "tok": ("tok", "float32", None), "tok_bf16": ("tok", "bfloat16", None),

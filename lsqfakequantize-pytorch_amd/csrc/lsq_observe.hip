@@ -678,7 +678,7 @@ hipError_t minmax_per_tensor(const void* x, int64_t n, void* out_min, void* out_
     const DeviceInfo& dev = device_info();
     auto* partials = static_cast<MinMaxPartial<T>*>(workspace);
     int grid;
-    if (!is_aligned16(x)) {
+    if (!is_elem_aligned<IO>(x)) {      // (packets take any element-aligned view: lsq_math.hpp, PacketWord)
         const int64_t want = std::max<int64_t>(1, (n + kBlock - 1) / kBlock);
         grid = static_cast<int>(std::min<int64_t>(want, static_cast<int64_t>(dev.cu_count) * observe_wg_per_cu(kObserveWgPerTensor)));
         hipLaunchKernelGGL((minmax_pt_scalar_kernel<IO>), dim3(grid), dim3(kBlock), 0, stream, x, n, partials);
@@ -701,7 +701,7 @@ hipError_t minmax_per_channel(const void* x, int64_t outer, int64_t channels, in
     using T = typename IO::arith;
     using K = typename key_of<T>::type;
     const DeviceInfo& dev = device_info();
-    const int vec = pick_vec(IO::VEC, channels * inner, is_aligned16(x));
+    const int vec = pick_vec(IO::VEC, channels * inner, is_elem_aligned<IO>(x));
     const unsigned fgrid_c = static_cast<unsigned>((channels + kMmFinCh - 1) / kMmFinCh);
     if (pick_segment_mode(vec, outer, channels, inner)) {
         const SegGeom sg = make_seg_geom(outer, channels, inner, vec, dev.cu_count * observe_wg_per_cu(kObserveWgSegment));
@@ -748,7 +748,7 @@ hipError_t meanstd_per_tensor(const void* x, int64_t n, void* out_mean, void* ou
     const DeviceInfo& dev = device_info();
     auto* partials = static_cast<double2*>(workspace);
     int grid;
-    if (!is_aligned16(x)) {
+    if (!is_elem_aligned<IO>(x)) {      // (packets take any element-aligned view: lsq_math.hpp, PacketWord)
         const int64_t want = std::max<int64_t>(1, (n + kBlock - 1) / kBlock);
         grid = static_cast<int>(std::min<int64_t>(want, static_cast<int64_t>(dev.cu_count) * observe_wg_per_cu(kObserveWgPerTensor)));
         hipLaunchKernelGGL((moments_pt_scalar_kernel<IO>), dim3(grid), dim3(kBlock), 0, stream, x, n, partials);
@@ -770,7 +770,7 @@ hipError_t meanstd_per_channel(const void* x, int64_t outer, int64_t channels, i
                                void* out_std, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     using T = typename IO::arith;
     const DeviceInfo& dev = device_info();
-    const int vec = pick_vec(IO::VEC, channels * inner, is_aligned16(x));
+    const int vec = pick_vec(IO::VEC, channels * inner, is_elem_aligned<IO>(x));
     const unsigned fgrid = static_cast<unsigned>((channels + kMmFinCh - 1) / kMmFinCh);
     auto* partials = static_cast<double2*>(workspace);
     if (pick_segment_mode(vec, outer, channels, inner)) {

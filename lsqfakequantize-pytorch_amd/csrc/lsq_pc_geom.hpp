@@ -24,7 +24,8 @@ __device__ __forceinline__ void load_elems(const void* base, int64_t e, typename
         out[0] = static_cast<const E*>(base)[e];
     } else if constexpr (V * sizeof(E) == 8) {
         using V2 = __attribute__((ext_vector_type(2))) unsigned int;
-        const V2* src = reinterpret_cast<const V2*>(static_cast<const E*>(base) + e);
+        typedef V2 V2u __attribute__((aligned(2)));      // element alignment is all a view promises (lsq_math.hpp, PacketWord)
+        const V2u* src = reinterpret_cast<const V2u*>(static_cast<const E*>(base) + e);
         const V2 raw = NTL ? __builtin_nontemporal_load(src) : *src;
         __builtin_memcpy(&out[0], &raw, 8);
     } else {
@@ -44,7 +45,8 @@ __device__ __forceinline__ void store_elems(void* base, int64_t e, const typenam
         using V2 = __attribute__((ext_vector_type(2))) unsigned int;
         V2 raw;
         __builtin_memcpy(&raw, &in[0], 8);
-        V2* dst = reinterpret_cast<V2*>(static_cast<E*>(base) + e);
+        typedef V2 V2u __attribute__((aligned(2)));
+        V2u* dst = reinterpret_cast<V2u*>(static_cast<E*>(base) + e);
         if (NTS) __builtin_nontemporal_store(raw, dst); else *dst = raw;
     } else {
         static_assert(V == IO::VEC, "a lane moves 1 element, 8 bytes or 16 bytes");

@@ -1484,7 +1484,10 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
     const int bias = ex ? ex->level_bias : 0;
     const int aux_kind = ex ? ex->aux_kind : 0;
     const DeviceInfo& dev = device_info();
-    const bool aligned = is_aligned16(x) && is_aligned16(y) && (!levels || (reinterpret_cast<uintptr_t>(levels) & 7u) == 0);
+    // Packets need ELEMENT alignment only (lsq_math.hpp, PacketWord): a sliced view runs the packet kernels' register loops.
+    // What wants 16-byte sources is the LDS-DMA ring (ring_ok); the level bytes of a packet are stored as one word.
+    const bool aligned = is_elem_aligned<IO>(x) && is_elem_aligned<IO>(y) && (!levels || (reinterpret_cast<uintptr_t>(levels) & 7u) == 0);
+    const bool ring_ok = is_aligned16(x) && is_aligned16(y);
     const int vec = pick_vec(IO::VEC, channels * inner, aligned);
     const bool seg = pick_segment_mode(vec, outer, channels, inner, dev.cu_count);
     const Variant v = decode_variant(variant, seg ? (sizeof(typename IO::elem) >= 4 ? kDefaultPcSegVariant : kDefaultPcSegNarrowVariant)
@@ -1538,7 +1541,7 @@ hipError_t forward_per_channel(const void* x, void* y, int64_t outer, int64_t ch
         // (tiles_each >= 8 on the ring's grid with a 2048-slot table already implies >= 2^24 elements: no separate size rule)
         if (v.dma == 2 || (table_big && tiles_each >= kFwdDmaDepth && tiles_each <= 64)) {
             g = gd;
-            vv.dma = table_big ? 1 : 2;
+            vv.dma = (table_big || !ring_ok) ? 1 : 2;
             g.direct = (direct && vv.dma == 1) ? 1 : 0;
             g.ring_nt = ring_nt_for(outer * channels * inner * static_cast<int64_t>(sizeof(typename IO::elem)), false, false);
         }
@@ -1573,6 +1576,7 @@ struct BwdPcCall {
     int target_blocks;     // requested workgroups (CUs x workgroups per CU)
     bool default_variant;  // the caller passed variant 0: the launcher may pick the grid of the code path it chooses
     bool whole_rounds;     // size the grid in whole rounds of what the chip holds at once (make_geom)
+    bool ring_ok;          // grad / x / dx are 16-byte aligned: the LDS-DMA ring (and the owner windows built on it) may be used
     Variant v;
     hipStream_t stream;
     size_t* plan_need;     // not null: PLAN only -- record the workspace bytes the launch would need, launch nothing
@@ -1699,7 +1703,7 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
         const int own_knob = knob::get(knob::kOwn);     // tools builds: 1 = wherever the shape allows, 2 = never, 3 = 1 without the priority turns
         const int own = own_knob == 3 ? 1 : own_knob;
         const int64_t bytes = c.outer * c.C * c.inner * static_cast<int64_t>(sizeof(typename IO::elem));
-        if (own != 2 && (own == 1 || (c.default_variant && c.outer * c.C * c.inner <= kOwnMaxElemsOf<static_cast<int>(sizeof(typename IO::elem))>))) {
+        if (c.ring_ok && own != 2 && (own == 1 || (c.default_variant && c.outer * c.C * c.inner <= kOwnMaxElemsOf<static_cast<int>(sizeof(typename IO::elem))>))) {
             const int64_t elems = c.outer * c.C * c.inner;
             auto launch_own = [&](auto block_c) -> bool {
                 constexpr int OB = decltype(block_c)::value;
@@ -1742,7 +1746,7 @@ static hipError_t launch_bwd_pc(const BwdPcCall<typename IO::arith>& c) {
         // (4- and 8-byte storage with one channel per lane, CPL == 1, keeps its register loop: it already has eight loads
         // in flight per lane and few registers, the ring only adds its LDS round trip -- measured 3-6 % slower)
         constexpr bool kDefaultHere = kDmaDefault<IO> && (sizeof(typename IO::elem) < 4 || CPL >= 2);
-        if (c.v.dma == 2 || (c.v.dma == 0 && kDefaultHere)) {
+        if (c.ring_ok && (c.v.dma == 2 || (c.v.dma == 0 && kDefaultHere))) {
             const int target = c.default_variant ? device_info().cu_count * kDmaBwdBlocksPerCU<IO> : c.target_blocks;
             // (row-group windows of 4- and 8-byte storage: only tensors up to 160 MB -- [8192,4096] 78 -> 69 us,
             // [64,197,768] 33 -> 28 us; on the bigger ones, four elements a row, the ring's per-row bookkeeping costs more
@@ -1906,7 +1910,9 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
     using T = typename IO::arith;
     (void)ticket;
     const DeviceInfo& dev = device_info();
-    const bool aligned = is_aligned16(grad) && is_aligned16(x) && is_aligned16(dx);
+    // (forward_per_channel: packets on any element-aligned view; the ring and the owner windows built on it want 16 bytes)
+    const bool aligned = is_elem_aligned<IO>(grad) && is_elem_aligned<IO>(x) && is_elem_aligned<IO>(dx);
+    const bool ring_ok = is_aligned16(grad) && is_aligned16(x) && is_aligned16(dx);
     const int vec = pick_vec(IO::VEC, channels * inner, aligned);
     const bool seg = pick_segment_mode(vec, outer, channels, inner, dev.cu_count);
     const Variant v = decode_variant(variant, seg ? (sizeof(typename IO::elem) >= 4 ? kDefaultPcSegVariant : kDefaultPcSegNarrowVariant)
@@ -1957,13 +1963,13 @@ hipError_t backward_per_channel(const void* grad, const void* x, void* dx, void*
         // the chip holds (variant: workgroups per CU requested, rounded to whole rounds)
         BwdPcCall<T> call{grad, x, dx, static_cast<T*>(ds), static_cast<T*>(db), wide, outer, channels, inner, scale, shift, &p,
                           gs, sym_term, partials, workspace_bytes, variant == 0 ? dev.cu_count * kWwBwdBlocksPerCU : target,
-                          /*default_variant=*/variant == 0, /*whole_rounds=*/true, v, stream, plan_need, plan_note};
+                          /*default_variant=*/variant == 0, /*whole_rounds=*/true, ring_ok, v, stream, plan_need, plan_note};
         return bwd_pc_modes<IO, VB, VB, true>(call);
     }
     const int target_w = (variant == 0 && last_axis) ? dev.cu_count * kLastAxisBwdBlocksPerCU : target;
     BwdPcCall<T> call{grad, x, dx, static_cast<T*>(ds), static_cast<T*>(db), wide, outer, channels, inner, scale, shift, &p,
                       gs, sym_term, partials, workspace_bytes, target_w, /*default_variant=*/variant == 0,
-                      /*whole_rounds=*/!last_axis, v, stream, plan_need, plan_note};
+                      /*whole_rounds=*/!last_axis, ring_ok, v, stream, plan_need, plan_note};
     if (vecw == 1) return bwd_pc_modes<IO, 1, 1>(call);
     if (cpl == 1) return bwd_pc_modes<IO, VB, 1>(call);
     if (cpl == 2) return bwd_pc_modes<IO, VB, 2>(call);

@@ -12,7 +12,9 @@
 //
 // 64 x 64 tiles through LDS (row pitch 65 elements: the column-wise read-out is bank-conflict-free); the read side walks
 // runs of min(C, 64) contiguous elements -- a tile that spans the whole of C is ONE contiguous chunk of the source --, the
-// write side runs of min(B, 64).  HBM-bound: 2 elements of traffic per element, nothing else.
+// write side runs of min(B, 64).  HBM-bound in fp32 (4.9 TB/s on [256,2048,7,7], the rate of a contiguous copy); 2-byte
+// elements run at the same ELEMENT rate (2.8 TB/s: 128-byte runs scattered at stride B) -- a variant with 128 x 64 tiles and
+// 4-byte pair stores was measured at half of that (140 VGPRs, three workgroups per CU) and dropped.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -22,76 +24,136 @@ namespace lsq {
 
 constexpr int kRelTile = 64;
 
-template <typename W>
+// Persistent workgroups, tiles round-robin; the NEXT tile's global loads are issued (into registers) before the current
+// tile's stores, so a workgroup always has a tile of reads or a tile of writes in flight.
+// EPL: 64-lane groups of b a lane serves on the write side (1 everywhere today); a tile is TB = 64 * EPL rows of b by 64 columns of c.
+template <typename W, int EPL>
 __global__ __launch_bounds__(kBlock) void relayout_kernel(const W* __restrict__ src, W* __restrict__ dst, int64_t B, int64_t C,
-                                                          int64_t tiles_b, int64_t tiles_c) {
-    __shared__ W tile[kRelTile][kRelTile + 1];
-    const int64_t t = blockIdx.x;
-    const int64_t tc = t % tiles_c;
-    const int64_t tb = (t / tiles_c) % tiles_b;
-    const int64_t a = t / (tiles_c * tiles_b);
-    const int64_t b0 = tb * kRelTile, c0 = tc * kRelTile;
-    const int nb = static_cast<int>(B - b0 < kRelTile ? B - b0 : kRelTile);
-    const int nc = static_cast<int>(C - c0 < kRelTile ? C - c0 : kRelTile);
-    const W* s = src + (a * B + b0) * C + c0;
-    W* d = dst + (a * C + c0) * B + b0;
-    const int lane = threadIdx.x & 63, row0 = threadIdx.x >> 6;          // 4 waves: wave w takes rows w, w + 4, ...
-    if (nc == C) {
-        // the tile's nb rows of the source are ONE contiguous run of nb * C elements: read it flat (full wave instructions
-        // whatever C is -- C = 49 would otherwise leave 15 lanes of every row instruction idle)
-        const int n = nb * nc;
-        const int q = kBlock / nc, r = kBlock - q * nc;                   // one division per lane, then (b, c) advance by (q, r)
-        int b = static_cast<int>(threadIdx.x) / nc, c = static_cast<int>(threadIdx.x) - b * nc;
-        for (int i = threadIdx.x; i < n; i += kBlock) {
-            tile[b][c] = s[i];
+                                                          int64_t tiles_b, int64_t tiles_c, int64_t tiles) {
+    constexpr int TB = kRelTile * EPL;
+    constexpr int kPerLane = TB * kRelTile / kBlock;       // elements of a tile per lane: 16 (EPL 1), 32 (EPL 2)
+    __shared__ W tile[TB][kRelTile + 1];
+    const int tid = static_cast<int>(threadIdx.x), lane = tid & 63, row0 = tid >> 6;       // 4 waves: wave w takes rows w, w + 4, ...
+    // A tile that spans the whole of C is ONE contiguous run of nb * C source elements (read flat: full wave instructions
+    // whatever C is -- C = 49 would otherwise leave 15 lanes of every row instruction idle); likewise the destination when a
+    // tile spans the whole of B.  Element i = tid + 256 k of such a run sits at (i / n, i % n): the same for every tile.
+    const bool flat_r = C <= kRelTile, flat_w = B <= TB;
+    const int nc_all = static_cast<int>(C < kRelTile ? C : kRelTile), nb_all = static_cast<int>(B < TB ? B : TB);
+    int rq[kPerLane], wq[kPerLane];          // (row << 8 | column) of this lane's k-th element, read side / write side
+    {
+        const int q = kBlock / nc_all, r = kBlock - q * nc_all;
+        int b = tid / nc_all, c = tid - b * nc_all;
+#pragma unroll
+        for (int k = 0; k < kPerLane; ++k) {
+            rq[k] = (b << 8) | c;
             b += q; c += r;
-            if (c >= nc) { c -= nc; ++b; }
+            if (c >= nc_all) { c -= nc_all; ++b; }
         }
-    } else {
-#pragma unroll 4
-        for (int b = row0; b < nb; b += kBlock / 64)
-            if (lane < nc) tile[b][lane] = s[static_cast<int64_t>(b) * C + lane];
+        const int q2 = kBlock / nb_all, r2 = kBlock - q2 * nb_all;
+        int cc = tid / nb_all, bb = tid - cc * nb_all;
+#pragma unroll
+        for (int k = 0; k < kPerLane; ++k) {
+            wq[k] = (bb << 8) | cc;
+            cc += q2; bb += r2;
+            if (bb >= nb_all) { bb -= nb_all; ++cc; }
+        }
     }
-    __syncthreads();
-    if (nb == B) {
-        const int n = nb * nc;
-        const int q = kBlock / nb, r = kBlock - q * nb;
-        int c = static_cast<int>(threadIdx.x) / nb, b = static_cast<int>(threadIdx.x) - c * nb;
-        for (int i = threadIdx.x; i < n; i += kBlock) {
-            d[i] = tile[b][c];
-            c += q; b += r;
-            if (b >= nb) { b -= nb; ++c; }
+    struct Where { const W* s; W* d; int nb, nc; };
+    auto where = [&](int64_t t) {
+        const int64_t tc = t % tiles_c, tb = (t / tiles_c) % tiles_b, a = t / (tiles_c * tiles_b);
+        const int64_t b0 = tb * TB, c0 = tc * kRelTile;
+        Where w;
+        w.nb = static_cast<int>(B - b0 < TB ? B - b0 : TB);
+        w.nc = static_cast<int>(C - c0 < kRelTile ? C - c0 : kRelTile);
+        w.s = src + (a * B + b0) * C + c0;
+        w.d = dst + (a * C + c0) * B + b0;
+        return w;
+    };
+    W regs[kPerLane];
+    auto fetch = [&](const Where& w) {
+        if (flat_r) {
+            const int n = w.nb * w.nc;
+#pragma unroll
+            for (int k = 0; k < kPerLane; ++k) {
+                const int i = tid + k * kBlock;
+                regs[k] = i < n ? w.s[i] : W(0);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPerLane; ++k) {
+                const int b = row0 + k * (kBlock / 64);
+                regs[k] = (b < w.nb && lane < w.nc) ? w.s[static_cast<int64_t>(b) * C + lane] : W(0);
+            }
         }
-    } else {
-#pragma unroll 4
-        for (int c = row0; c < nc; c += kBlock / 64)
-            if (lane < nb) d[static_cast<int64_t>(c) * B + lane] = tile[lane][c];
+    };
+    int64_t t = blockIdx.x;
+    if (t >= tiles) return;
+    Where cur = where(t);
+    fetch(cur);
+    for (;;) {
+        // registers -> LDS
+        if (flat_r) {
+            const int n = cur.nb * cur.nc;
+#pragma unroll
+            for (int k = 0; k < kPerLane; ++k)
+                if (tid + k * kBlock < n) tile[rq[k] >> 8][rq[k] & 255] = regs[k];      // (i < n <=> row < nb <= TB)
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPerLane; ++k) tile[row0 + k * (kBlock / 64)][lane] = regs[k];
+        }
+        __syncthreads();
+        const int64_t tn = t + gridDim.x;
+        const bool more = tn < tiles;
+        Where nxt = cur;
+        if (more) {
+            nxt = where(tn);
+            fetch(nxt);                                   // in flight while this tile is written out
+        }
+        if (flat_w) {
+            const int n = cur.nb * cur.nc;
+#pragma unroll
+            for (int k = 0; k < kPerLane; ++k) {
+                const int i = tid + k * kBlock;
+                if (i < n) cur.d[i] = tile[wq[k] >> 8][wq[k] & 255];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kRelTile / (kBlock / 64); ++k) {
+                const int c = row0 + k * (kBlock / 64);
+#pragma unroll
+                for (int h = 0; h < EPL; ++h) {
+                    const int b = lane + 64 * h;
+                    if (c < cur.nc && b < cur.nb) cur.d[static_cast<int64_t>(c) * B + b] = tile[b][c];
+                }
+            }
+        }
+        if (!more) break;
+        __syncthreads();                                  // the tile is read out: it may be overwritten
+        t = tn;
+        cur = nxt;
     }
 }
 
-hipError_t relayout(int elem_bytes, const void* src, void* dst, int64_t A, int64_t B, int64_t C, hipStream_t stream) {
-    const int64_t tiles_b = (B + kRelTile - 1) / kRelTile, tiles_c = (C + kRelTile - 1) / kRelTile;
+template <typename W, int EPL>
+static hipError_t launch_relayout(const void* src, void* dst, int64_t A, int64_t B, int64_t C, hipStream_t stream) {
+    constexpr int TB = kRelTile * EPL;
+    const int64_t tiles_b = (B + TB - 1) / TB, tiles_c = (C + kRelTile - 1) / kRelTile;
     const int64_t tiles = A * tiles_b * tiles_c;
     if (tiles <= 0) return hipSuccess;
-    if (tiles > INT32_MAX) return hipErrorInvalidConfiguration;
-    const dim3 grid(static_cast<unsigned>(tiles));
-    switch (elem_bytes) {
-        case 2:
-            hipLaunchKernelGGL((relayout_kernel<uint16_t>), grid, dim3(kBlock), 0, stream, static_cast<const uint16_t*>(src),
-                               static_cast<uint16_t*>(dst), B, C, tiles_b, tiles_c);
-            break;
-        case 4:
-            hipLaunchKernelGGL((relayout_kernel<uint32_t>), grid, dim3(kBlock), 0, stream, static_cast<const uint32_t*>(src),
-                               static_cast<uint32_t*>(dst), B, C, tiles_b, tiles_c);
-            break;
-        case 8:
-            hipLaunchKernelGGL((relayout_kernel<uint64_t>), grid, dim3(kBlock), 0, stream, static_cast<const uint64_t*>(src),
-                               static_cast<uint64_t*>(dst), B, C, tiles_b, tiles_c);
-            break;
-        default:
-            return hipErrorInvalidValue;
-    }
+    const int64_t resident = static_cast<int64_t>(device_info().cu_count) * 8;      // 8 workgroups of 256 lanes per CU
+    const dim3 grid(static_cast<unsigned>(tiles < resident ? tiles : resident));
+    hipLaunchKernelGGL((relayout_kernel<W, EPL>), grid, dim3(kBlock), 0, stream, static_cast<const W*>(src), static_cast<W*>(dst), B, C,
+                       tiles_b, tiles_c, tiles);
     return hipGetLastError();
+}
+
+hipError_t relayout(int elem_bytes, const void* src, void* dst, int64_t A, int64_t B, int64_t C, hipStream_t stream) {
+    switch (elem_bytes) {
+        case 2: return launch_relayout<uint16_t, 1>(src, dst, A, B, C, stream);
+        case 4: return launch_relayout<uint32_t, 1>(src, dst, A, B, C, stream);
+        case 8: return launch_relayout<uint64_t, 1>(src, dst, A, B, C, stream);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace lsq
