@@ -26,12 +26,11 @@ constexpr int kRelTile = 64;
 
 // Persistent workgroups, tiles round-robin; the NEXT tile's global loads are issued (into registers) before the current
 // tile's stores, so a workgroup always has a tile of reads or a tile of writes in flight.
-// EPL: 64-lane groups of b a lane serves on the write side (1 everywhere today); a tile is TB = 64 * EPL rows of b by 64 columns of c.
-template <typename W, int EPL>
+template <typename W>
 __global__ __launch_bounds__(kBlock) void relayout_kernel(const W* __restrict__ src, W* __restrict__ dst, int64_t B, int64_t C,
                                                           int64_t tiles_b, int64_t tiles_c, int64_t tiles) {
-    constexpr int TB = kRelTile * EPL;
-    constexpr int kPerLane = TB * kRelTile / kBlock;       // elements of a tile per lane: 16 (EPL 1), 32 (EPL 2)
+    constexpr int TB = kRelTile;
+    constexpr int kPerLane = TB * kRelTile / kBlock;       // 16 elements of a tile per lane
     __shared__ W tile[TB][kRelTile + 1];
     const int tid = static_cast<int>(threadIdx.x), lane = tid & 63, row0 = tid >> 6;       // 4 waves: wave w takes rows w, w + 4, ...
     // A tile that spans the whole of C is ONE contiguous run of nb * C source elements (read flat: full wave instructions
@@ -120,11 +119,7 @@ __global__ __launch_bounds__(kBlock) void relayout_kernel(const W* __restrict__ 
 #pragma unroll
             for (int k = 0; k < kRelTile / (kBlock / 64); ++k) {
                 const int c = row0 + k * (kBlock / 64);
-#pragma unroll
-                for (int h = 0; h < EPL; ++h) {
-                    const int b = lane + 64 * h;
-                    if (c < cur.nc && b < cur.nb) cur.d[static_cast<int64_t>(c) * B + b] = tile[b][c];
-                }
+                if (c < cur.nc && lane < cur.nb) cur.d[static_cast<int64_t>(c) * B + lane] = tile[lane][c];
             }
         }
         if (!more) break;
@@ -134,24 +129,24 @@ __global__ __launch_bounds__(kBlock) void relayout_kernel(const W* __restrict__ 
     }
 }
 
-template <typename W, int EPL>
+template <typename W>
 static hipError_t launch_relayout(const void* src, void* dst, int64_t A, int64_t B, int64_t C, hipStream_t stream) {
-    constexpr int TB = kRelTile * EPL;
+    constexpr int TB = kRelTile;
     const int64_t tiles_b = (B + TB - 1) / TB, tiles_c = (C + kRelTile - 1) / kRelTile;
     const int64_t tiles = A * tiles_b * tiles_c;
     if (tiles <= 0) return hipSuccess;
     const int64_t resident = static_cast<int64_t>(device_info().cu_count) * 8;      // 8 workgroups of 256 lanes per CU
     const dim3 grid(static_cast<unsigned>(tiles < resident ? tiles : resident));
-    hipLaunchKernelGGL((relayout_kernel<W, EPL>), grid, dim3(kBlock), 0, stream, static_cast<const W*>(src), static_cast<W*>(dst), B, C,
+    hipLaunchKernelGGL((relayout_kernel<W>), grid, dim3(kBlock), 0, stream, static_cast<const W*>(src), static_cast<W*>(dst), B, C,
                        tiles_b, tiles_c, tiles);
     return hipGetLastError();
 }
 
 hipError_t relayout(int elem_bytes, const void* src, void* dst, int64_t A, int64_t B, int64_t C, hipStream_t stream) {
     switch (elem_bytes) {
-        case 2: return launch_relayout<uint16_t, 1>(src, dst, A, B, C, stream);
-        case 4: return launch_relayout<uint32_t, 1>(src, dst, A, B, C, stream);
-        case 8: return launch_relayout<uint64_t, 1>(src, dst, A, B, C, stream);
+        case 2: return launch_relayout<uint16_t>(src, dst, A, B, C, stream);
+        case 4: return launch_relayout<uint32_t>(src, dst, A, B, C, stream);
+        case 8: return launch_relayout<uint64_t>(src, dst, A, B, C, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -141,6 +141,11 @@ def check_timed_route(comm, device, limit, n=ROUTE_CHECK_REDUCTIONS):
     return ""
 
 
+def nothung_of(hung):
+    """the 'nobody hung' slot of an agreement: 0, or -1 where this rank saw a reduction / bootstrap that did not finish (MIN)"""
+    return -int(bool(hung))
+
+
 def native_comm(group, device, create=True):
     """The HipComm of (group, device), created on first use -- a COLLECTIVE call then: every rank of the group must make its
     first sharded call at the same point, which data-parallel training does by construction.  None = torch.distributed.
@@ -251,10 +256,6 @@ def native_comm(group, device, create=True):
         comm.checked = checked
     _COMMS[key] = comm
     return comm
-
-
-def nothung_of(hung):
-    return -int(bool(hung))
 
 
 _TEST_HOOKS = {}            # tests only: {"unfenced_fails": True} makes step 5 take the system-fenced branch
