@@ -49,7 +49,7 @@ COLLECTIVE = "collective"      # global_numel=COLLECTIVE: the element count trav
 # an RCCL ("nccl") process group -- see native_comm for the protocol: every step of it is agreed between the ranks over
 # torch.distributed, and any failure leaves ALL of them on torch.distributed.
 # TORCHLSQ_COLLECTIVE=c10d switches the native route off; gloo groups and CPU tensors never take it.
-_COMMS = {}                 # (group key, device index) -> HipComm, or None: this group stays on torch.distributed
+_COMMS = {}                 # (group key, device index) -> (HipComm or None: this group stays on torch.distributed, its process-group object)
 _NATIVE_COLLECTIVE = [os.environ.get("TORCHLSQ_COLLECTIVE", "native").lower() != "c10d"]
 ROUTE_CHECK_REDUCTIONS = 128    # reductions of the timed route's self-check (native_comm step 5)
 
@@ -62,6 +62,11 @@ def set_native_collective(on):
 
 def _group_key(group):
     return 0 if group is None else id(group)
+
+
+def _process_group(group):
+    """the process-group OBJECT behind `group` (None = the default group): what a cache entry is tied to"""
+    return group if group is not None else dist.distributed_c10d._get_default_group()
 
 
 def _agree(values, device, group):
@@ -167,19 +172,22 @@ def native_comm(group, device, create=True):
     if not _NATIVE_COLLECTIVE[0] or not (dist.is_available() and dist.is_initialized()):
         return None
     key = (_group_key(group), device.index)
-    rank, ws = dist.get_rank(group), dist.get_world_size(group)
-    if key in _COMMS:
-        comm = _COMMS[key]
-        # a hit must still belong to THIS world: dist.destroy_process_group() + a new init, or a new group object that got a
-        # recycled id(), would otherwise be handed a communicator of ranks that no longer exist
-        if comm is None or (comm.handle and comm.nranks == ws and comm.rank == rank):
+    pg = _process_group(group)
+    hit = _COMMS.get(key)
+    if hit is not None:
+        # a hit must still belong to THIS world: dist.destroy_process_group() + a new init hands out a new process-group object
+        # (and the entry's own reference keeps an explicit group's id() from being recycled while it is cached) -- one identity
+        # test on the per-step path; a communicator destroyed behind the cache's back is dropped too
+        comm, owner = hit
+        if owner is pg and (comm is None or comm.handle):
             return comm
         del _COMMS[key]
     if not create:
         return None
     if dist.get_backend(group) != "nccl":
-        _COMMS[key] = None
+        _COMMS[key] = (None, pg)
         return None
+    rank, ws = dist.get_rank(group), dist.get_world_size(group)
     limit = float(os.environ.get("TORCHLSQ_COMM_CHECK_S", "60"))       # (tests: a negative limit = "it never finished")
     t0 = time.monotonic()
     checked = {"world": ws}
@@ -194,7 +202,9 @@ def native_comm(group, device, create=True):
     src = dist.get_global_rank(group, 0) if group is not None else 0
     dist.broadcast(uid, src=src, group=group)
     if _agree([ok], device, group)[0] != 1:                     # 2.
-        _COMMS[key] = None
+        _COMMS[key] = (None, pg)
+        LAST_FAILURE.clear()
+        LAST_FAILURE.update(checked, hung=False, why=checked.get("why", "another rank cannot reach RCCL"))
         return None
     comm, err = _create_under_deadline(bytes(uid.cpu().numpy().tobytes()), rank, ws, device, limit if limit > 0 else 60.0)   # 3.
     hung = 0
@@ -254,7 +264,7 @@ def native_comm(group, device, create=True):
                        events="system-fenced (the unfenced form failed the check on some rank)" if unfenced_ok != 1 else
                               "no system-scope fence (checked)", seconds=round(time.monotonic() - t0, 3))
         comm.checked = checked
-    _COMMS[key] = comm
+    _COMMS[key] = (comm, pg)
     return comm
 
 
@@ -265,7 +275,7 @@ LAST_FAILURE = {}           # why the last native_comm creation fell back (recor
 def destroy_native_comms():
     """tear the library's communicators down -- REQUIRED before dist.destroy_process_group() when the native route was used
     (collective per communicator)"""
-    for key, comm in list(_COMMS.items()):
+    for key, (comm, _owner) in list(_COMMS.items()):
         if comm is not None and comm.handle:
             comm.destroy()
         del _COMMS[key]

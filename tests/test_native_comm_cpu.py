@@ -35,7 +35,8 @@ def test_a_lookup_never_decides_for_later_calls(world_of_one, monkeypatch):
     assert D.native_comm(None, dev, create=False) is None
     assert not D._COMMS and not asked, "a look-up cached a decision"
     assert D.native_comm(None, dev) is None and asked == [1]           # the creating call decides (gloo: torch.distributed) ...
-    assert D._COMMS == {(0, 0): None}                                  # ... and only that is cached
+    assert list(D._COMMS) == [(0, 0)] and D._COMMS[(0, 0)][0] is None   # ... and only that is cached, tied to this process group
+    assert D.native_comm(None, dev) is None and asked == [1]           # (a hit: nothing is asked again)
 
 
 def test_a_cached_communicator_of_another_world_is_dropped(world_of_one, monkeypatch):
@@ -43,16 +44,13 @@ def test_a_cached_communicator_of_another_world_is_dropped(world_of_one, monkeyp
     D = world_of_one
     dev = torch.device("cuda", 0)
 
-    class Stale:
-        handle, nranks, rank = 1, 8, 5
-
-    class Mine:
-        handle, nranks, rank = 1, 1, 0
+    class Comm:
+        handle = 1
     monkeypatch.setattr(dist, "get_backend", lambda group=None: "gloo")
-    D._COMMS[(0, 0)] = Stale()
+    D._COMMS[(0, 0)] = (Comm(), object())                  # a communicator of a process group that is gone
     assert D.native_comm(None, dev, create=False) is None and (0, 0) not in D._COMMS
-    mine = Mine()
-    D._COMMS[(0, 0)] = mine
+    mine = Comm()
+    D._COMMS[(0, 0)] = (mine, D._process_group(None))
     assert D.native_comm(None, dev, create=False) is mine
     mine.handle = None                      # destroyed behind the cache's back
-    assert D.native_comm(None, dev, create=False) is None
+    assert D.native_comm(None, dev, create=False) is None and (0, 0) not in D._COMMS
