@@ -70,6 +70,7 @@ WORKLOADS = {
     #   *_channels_last   x and grad both in channels-last memory order (per-channel on axis 1 = the memory order's LAST axis)
     #   *_mixed_layout    channels-last x, contiguous (NCHW) grad: the host layer re-orders grad first (one copy, +2 storage
     #                     elements of traffic per element)
+    "cfg2_bf16": ("cfg2", "bfloat16", None),              # not a BASELINE config: config 2's per-tensor operator on bf16 storage (10 B per element)
     "cfg2_misaligned": ("cfg2", "float32", None),
     "cfg5_misaligned": ("cfg5", "float32", None), "cfg5_bf16_misaligned": ("cfg5", "bfloat16", None),
     "cfg5_channels_last": ("cfg5", "float32", None), "cfg5_mixed_layout": ("cfg5", "float32", None),
