@@ -54,3 +54,26 @@ def test_a_cached_communicator_of_another_world_is_dropped(world_of_one, monkeyp
     assert D.native_comm(None, dev, create=False) is mine
     mine.handle = None                      # destroyed behind the cache's back
     assert D.native_comm(None, dev, create=False) is None and (0, 0) not in D._COMMS
+
+
+def test_transposition_detection_is_pure_stride_logic():
+    """torchlsq._hip_host._transposition (what decides whether a grad in another dense order goes through lsq_hip_relayout): two
+    dense orders that differ by ONE swap of adjacent dimension groups give (A, B, C) with g's memory [A][B][C] and x's [A][C][B];
+    anything else -- the same order, size-1 dims that make two formats one memory, a non-dense view, a double permutation -- None"""
+    from torchlsq import extension as E
+    g = torch.empty(6, 96, 7, 5)
+    x = torch.empty(6, 96, 7, 5).contiguous(memory_format=torch.channels_last)
+    assert E._transposition(g, x) == (6, 96, 35) and E._transposition(x, g) == (6, 35, 96)
+    assert E._transposition(g, g.clone()) is None
+    one = torch.empty(4, 8, 1, 1)
+    assert E._transposition(one, one.contiguous(memory_format=torch.channels_last)) is None        # H*W == 1: one and the same memory
+    btf = torch.empty(3, 50, 20)
+    bft = torch.empty(3, 20, 50).permute(0, 2, 1)                                                   # shape [3,50,20], memory [B][F][T]
+    assert E._transposition(btf, bft) == (3, 50, 20)
+    assert E._transposition(btf[:, ::2], bft[:, ::2]) is None                                       # not dense
+    d5 = torch.empty(2, 3, 4, 5, 6)
+    assert E._transposition(d5, d5.permute(0, 3, 4, 1, 2).contiguous().permute(0, 3, 4, 1, 2)) == (2, 12, 30)   # [A][(1,2)][(3,4)] -> [A][(3,4)][(1,2)]
+    assert E._transposition(d5, d5.permute(0, 4, 3, 2, 1).contiguous().permute(0, 4, 3, 2, 1)) is None          # a full reversal is no single swap
+    # whole-tensor transposition (no common prefix): A == 1
+    m = torch.empty(33, 129)
+    assert E._transposition(m, torch.empty(129, 33).t()) == (1, 33, 129)
