@@ -91,3 +91,30 @@ def test_per_channel_beyond_2_31_elements(dev):
     r = O.bwd_pc(gn, xn, s.cpu().numpy(), b.cpu().numpy(), outer, C, inner, -8, 7, -128, 127, True, 1.0, False, numel_for_scaler=n)
     assert torch.equal(y[40:41].cpu(), torch.from_numpy(oy.reshape(xn.shape)).to(torch.bfloat16))
     assert torch.equal(dx[40:41].cpu(), torch.from_numpy(r.dx.reshape(xn.shape)).to(torch.bfloat16))
+
+
+def test_last_axis_beyond_2_31_elements(dev):
+    shape = (266003, 8192)                     # [tokens, features], quantized along the features: 2.18e9 elements, a prime row count
+    n = shape[0] * shape[1]
+    assert n > (1 << 31)
+    x, g = _fill(n, 77, 0.5, 1.0, dev).view(shape), _fill(n, 78, 0.0, 1e-3, dev).view(shape)
+    from torchlsq import synth
+    s, b = synth.uniform_like(8192, 79, 0.01, 0.05, device=dev), synth.normal_like(8192, 80, 0.0, 0.1, device=dev)
+    q = (0, 127, 0, 255, True, 1.0, False, False, False)
+    ops = torch.ops.torchlsq_native
+    y = ops.lsq_forward_per_channel(x, s, b, 1, *q)
+    dx, wide = ops.lsq_backward_per_channel_wide(g, x, s, b, 1, *q, n)
+    parts = []
+    for lo, hi in ((0, 133000), (133000, 266003)):
+        assert torch.equal(ops.lsq_forward_per_channel(x[lo:hi], s, b, 1, *q), y[lo:hi]), "y differs in rows [%d, %d)" % (lo, hi)
+        da, wa = ops.lsq_backward_per_channel_wide(g[lo:hi], x[lo:hi], s, b, 1, *q, n)
+        assert torch.equal(da, dx[lo:hi]), "dx differs in rows [%d, %d)" % (lo, hi)
+        parts.append(wa)
+        del da
+    np.testing.assert_allclose((parts[0] + parts[1]).cpu().numpy(), wide.cpu().numpy(), rtol=1e-6, atol=1e-12)
+    lo = 266003 - 100                          # the last hundred rows against the oracle
+    xn, gn = x[lo:].float().cpu().numpy(), g[lo:].float().cpu().numpy()
+    oy = O.fwd_pc(xn, s.cpu().numpy(), b.cpu().numpy(), 100, 8192, 1, 0, 127, 0, 255)
+    r = O.bwd_pc(gn, xn, s.cpu().numpy(), b.cpu().numpy(), 100, 8192, 1, 0, 127, 0, 255, True, 1.0, False, numel_for_scaler=n)
+    assert torch.equal(y[lo:].cpu(), torch.from_numpy(oy.reshape(xn.shape)).to(torch.bfloat16))
+    assert torch.equal(dx[lo:].cpu(), torch.from_numpy(r.dx.reshape(xn.shape)).to(torch.bfloat16))
