@@ -63,6 +63,24 @@ rows1 = [("cfg1 forward op (per-tensor), default overload", lambda: f1(x1, s1, b
          ("cfg1 forward + backward ops (the bench's step)", lambda: (f1(x1, s1, b1, *q1), b1op(g1, x1, s1, b1, *q1))),
          ("two ATen single-launch ops: torch.add(x, g); torch.mul(x, g)", lambda: (torch.add(x1, g1), torch.mul(x1, g1))),
          ("functional.lsq(...) forward + .backward(g) (C++ front op + autograd node)", step_functional)]
+# the module in its steady state (observer off, LSQ learning on): what a QAT model pays per activation quantizer and step
+from torchlsq.quantized import LSQFakeQuantizer
+from torch.ao.quantization.observer import MovingAverageMinMaxObserver
+mod = LSQFakeQuantizer(MovingAverageMinMaxObserver, "activation", init_batches=1).to(dev).train()
+for _ in range(4):
+    mod(x1)
+xm = x1.clone().requires_grad_(True)
+
+
+def step_module():
+    y = mod(xm)
+    y.backward(g1)
+    xm.grad = None; mod.scale.grad = None; mod.shift.grad = None
+
+
+rows1 += [("functional.lsq(...) forward only (requires_grad inputs)", lambda: lsq(xr, sr, br, 0, 127, 0, 255)),
+          ("LSQFakeQuantizer(x) forward only, steady state", lambda: mod(xm)),
+          ("LSQFakeQuantizer(x) forward + .backward(g)", step_module)]
 print("# BASELINE config 1 [4,64,56,56] fp32 (0.8 M elements: ~3 us of GPU time per op -- the host is the bottleneck)")
 for name, fn in rows1:
     print("%-78s %6.2f us" % (name, per_call(fn)))
