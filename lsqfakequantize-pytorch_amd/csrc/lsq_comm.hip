@@ -229,8 +229,12 @@ int lsq_hip_comm_create(const void* id, int32_t rank, int32_t nranks, const lsq_
     c->side = c->n_cand > 0 ? c->cand[0] : nullptr;
     int rc = e == hipSuccess ? create_events(c, system_fence) : hip_status(e, "comm_create: side stream");
     c->next_join.store(0);
-    if (rc != LSQ_OK) {      // (a communicator that cannot get a stream is not worth tearing down carefully)
+    if (rc != LSQ_OK) {      // give back what was made so far: events, candidate streams (the first may be a parked one), the RCCL communicator
         destroy_events(c);
+        for (int i = 0; i < c->n_cand; ++i) {
+            if (i == 0) park_stream(c->cand[0], c->device);
+            else (void)hipStreamDestroy(c->cand[i]);
+        }
         r->CommDestroy(c->comm);
         delete c;
         return rc;
