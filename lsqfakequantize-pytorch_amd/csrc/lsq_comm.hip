@@ -114,6 +114,7 @@ struct lsq_comm {
     hipStream_t side;                      // the stream the overlapped reductions run on
     hipStream_t cand[kCandidates];         // ... chosen among these by lsq_hip_comm_tune (cand[0] until then)
     int n_cand;
+    int first_was_parked;                  // cand[0] was once some communicator's side stream (taken from the parked list): never destroyed
     std::atomic<int> picked;               // lsq_hip_comm_info's side-stream choice: 0 not tuned, 2 none ran apart, 2 + k = cand[k - 1]
     int event_system_fence;                // the events below were created with (1) / without (0) the system-scope fence
     hipEvent_t ready[kTickets];            // recorded on the caller's stream: the buffer's producer has been enqueued
@@ -223,6 +224,7 @@ int lsq_hip_comm_create(const void* id, int32_t rank, int32_t nranks, const lsq_
     c->picked.store(0);
     for (int i = 0; i < kCandidates && e == hipSuccess; ++i) {
         c->cand[i] = i == 0 ? take_parked_stream(c->device) : nullptr;
+        if (i == 0) c->first_was_parked = c->cand[0] != nullptr;
         if (!c->cand[i]) e = hipStreamCreateWithFlags(&c->cand[i], hipStreamNonBlocking);
         if (e == hipSuccess) c->n_cand = i + 1;
     }
@@ -232,7 +234,7 @@ int lsq_hip_comm_create(const void* id, int32_t rank, int32_t nranks, const lsq_
     if (rc != LSQ_OK) {      // give back what was made so far: events, candidate streams (the first may be a parked one), the RCCL communicator
         destroy_events(c);
         for (int i = 0; i < c->n_cand; ++i) {
-            if (i == 0) park_stream(c->cand[0], c->device);
+            if (i == 0 && c->first_was_parked) park_stream(c->cand[0], c->device);
             else (void)hipStreamDestroy(c->cand[i]);
         }
         r->CommDestroy(c->comm);
@@ -316,8 +318,12 @@ int lsq_hip_comm_destroy(lsq_comm* c) {
     // The side stream itself is NOT destroyed: the host layer may have handed it to its allocator as a consumer of buffers
     // (torch: record_stream), which records an event on it when such a buffer is freed -- possibly long after this call
     // (seen: a segmentation fault at interpreter exit).  It is parked for the next communicator of this device instead.
-    for (int i = 0; i < c->n_cand; ++i)
-        if (c->cand[i] && c->cand[i] != c->side) (void)hipStreamDestroy(c->cand[i]);
+    // (so is a first candidate that came from the parked list and lost the tuning: it WAS somebody's side stream)
+    for (int i = 0; i < c->n_cand; ++i) {
+        if (!c->cand[i] || c->cand[i] == c->side) continue;
+        if (i == 0 && c->first_was_parked) park_stream(c->cand[0], c->device);
+        else (void)hipStreamDestroy(c->cand[i]);
+    }
     if (c->side) park_stream(c->side, c->device);
     int rc = r ? rccl_status(r, r->CommDestroy(c->comm), "ncclCommDestroy") : LSQ_OK;
     delete c;
